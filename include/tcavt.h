@@ -1,0 +1,235 @@
+/*
+ * tcavt.h -- C ABI of the MI355X (gfx950) hot path for the multimodal-LLM
+ * vehicle-trajectory-prediction forward/backward pass.
+ *
+ * The reference (imjaegyun/Traffic-Context-Augmented-Vehicle-Trajectory-
+ * Prediction-Framework-Using-Multimodal-LLM) has no FFI of its own: its only
+ * shared interface is the Python class surface of scripts/train.py:352-964.
+ * Each entry point below names the reference code (file:line) whose arithmetic
+ * it replaces.  The Python host side (package `tcavt_amd`, module model.py)
+ * mirrors the reference classes and calls these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()) unless marked host
+ *   - no allocation, no synchronisation, no host<->device copy inside a call:
+ *     the caller owns all buffers incl. workspaces; calls are stream-ordered
+ *     on `stream` (a hipStream_t passed as void*) and graph-capturable
+ *   - return value 0 = ok; otherwise a TCAVT_ERR_* code, and
+ *     tcavt_last_error() returns a thread-local message
+ *   - "bf16" buffers are raw 16-bit brain-float (upper half of an IEEE f32)
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS
+ */
+#ifndef TCAVT_H
+#define TCAVT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tcavt_stream_t; /* hipStream_t */
+
+#define TCAVT_ABI_VERSION 1
+
+#define TCAVT_OK 0
+#define TCAVT_ERR_ARG 1  /* shape / alignment / null-pointer contract violated */
+#define TCAVT_ERR_HIP 2  /* a HIP runtime call failed */
+#define TCAVT_ERR_ARCH 3 /* device is not gfx950 */
+
+#define TCAVT_F32 0
+#define TCAVT_BF16 1
+
+int tcavt_abi_version(void);
+const char* tcavt_last_error(void);
+/* Selects `device`, verifies it is gfx950, reports its CU count. */
+int tcavt_init(int device, int* num_cus);
+
+/* ------------------------------------------------------------------------
+ * Dense contraction  C[M,N] = A[M,K] . W[N,K]^T (+ A2[M,K2] . W2[N,K2]^T)
+ * bf16 operands, fp32 MFMA accumulation, fused epilogue.
+ * Replaces every nn.Linear on the bf16 part of the path:
+ *   - Llama q/k/v/o/gate/up/down projections (transformers modeling_llama.py
+ *     :174-176,254-256,279-280 as called from scripts/train.py:446-452)
+ *   - the LoRA update  y += (alpha/r) * B(A(x))  on q_proj/v_proj
+ *     (scripts/train.py:433-440) via the second K-source (A2 = 4*x.A^T, W2 = B)
+ *   - BlipQFormer linears (scripts/train.py:401-406), LlamaMultiModal.q_proj
+ *     (:493,521), cross_attn in/out projections and dec_proj/dec_unproj
+ *     (:754-757,794-799)
+ * Epilogue flags (combinable where it makes sense):
+ *   BIAS      acc += bias[n]
+ *   RELU      acc = max(acc, 0)
+ *   RESIDUAL  acc += residual[m][n]            (fp32, may alias C when C is fp32)
+ *   SILU_MUL  W holds gate/up rows interleaved in blocks of 16
+ *             (rows 32j..32j+15 = gate features 16j.., rows 32j+16..32j+31 = up
+ *             features 16j..); C[m][f] = silu(gate_f) * up_f, C has N/2 columns
+ *   ROPE      rotary embedding (half-split convention, head_dim 64) applied to
+ *             columns [0, rope_cols) with position = m % rope_L, cos/sin tables
+ *             [rope_L][32] fp32 (modeling_llama.py:113-160)
+ * Constraints: K % 64 == 0, K2 % 64 == 0, N % 16 == 0, ld* % 8 == 0,
+ *              16-byte aligned base pointers; SILU_MUL/ROPE need N % 128 == 0.
+ * ---------------------------------------------------------------------- */
+#define TCAVT_EPI_BIAS 1
+#define TCAVT_EPI_RELU 2
+#define TCAVT_EPI_RESIDUAL 4
+#define TCAVT_EPI_SILU_MUL 8
+#define TCAVT_EPI_ROPE 16
+
+typedef struct tcavt_gemm_args {
+  const void* A;   int64_t lda;  /* bf16 [M][K]  */
+  const void* W;   int64_t ldw;  /* bf16 [N][K]  */
+  const void* A2;  int64_t lda2; /* bf16 [M][K2] or NULL */
+  const void* W2;  int64_t ldw2; /* bf16 [N][K2] or NULL */
+  void* C;         int64_t ldc;  /* out_dtype [M][N] ([M][N/2] for SILU_MUL) */
+  const float* bias;             /* fp32 [N] or NULL */
+  const float* residual; int64_t ldr; /* fp32 [M][N] or NULL */
+  const float* rope_cos;         /* fp32 [rope_L][32] */
+  const float* rope_sin;
+  int32_t M, N, K, K2;
+  int32_t out_dtype;             /* TCAVT_F32 | TCAVT_BF16 */
+  int32_t epilogue;              /* TCAVT_EPI_* flags */
+  int32_t rope_L, rope_cols;
+  int32_t tile;                  /* 0 = auto, 128 or 256 = force square tile */
+} tcavt_gemm_args;
+
+int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Llama RMSNorm: out = bf16( x * rsqrt(mean(x^2) + eps) * gamma ), x fp32 [M][H]
+ * (modeling_llama.py:62-67; F1/F7 of SURVEY.md section 8a).
+ * out_f32 (optional) receives the un-rounded fp32 result (final norm ->
+ * hidden_states[-1], scripts/train.py:553).  H % 8 == 0, H <= 8192.
+ * ---------------------------------------------------------------------- */
+int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
+                  float* out_f32, int M, int H, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * nn.LayerNorm over the last dim with optional fused residual add:
+ *   y = LN(x + residual) * gamma + beta      (post-LN blocks of
+ * nn.TransformerEncoderLayer / DecoderLayer used at scripts/train.py:358,402,405
+ * and LayerNorms at :662,672,760).  Writes fp32 and/or bf16 copies.
+ * D % 4 == 0, D <= 4096.
+ * ---------------------------------------------------------------------- */
+int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
+                    const float* beta, float eps, float* out_f32, void* out_bf16,
+                    int M, int D, tcavt_stream_t stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */
+int tcavt_cast_f32_bf16(const float* x, void* out_bf16, int64_t n, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused input embedding build (scripts/train.py:521-528):
+ *   h[b][i]      = img[b][i] + vis_mod               i <  Nq   (img = q_proj output)
+ *   h[b][Nq + j] = table[ids[b][j]] + txt_mod        j <  Lt
+ * table bf16 [V][H]; ids int64 [B][Lt]; img fp32 [B][Nq][H]; h fp32 [B][Nq+Lt][H].
+ * Ids outside [0,V) are reported through *bad_id_flag (device int, set to 1).
+ * ---------------------------------------------------------------------- */
+int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
+                     const float* vis_mod, const float* txt_mod, float* h, int B,
+                     int Nq, int Lt, int H, int V, int* bad_id_flag,
+                     tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Causal grouped-query attention over the fused sequence
+ * (modeling_llama.py:191-213 semantics = HF sdpa path with a causal AND
+ * key-valid mask).
+ *   qkv  bf16 [B*L][(nq + 2*nkv) * 64]   (q heads | k heads | v heads, RoPE applied)
+ *   out  bf16 [B*L][nq * 64]
+ *   kv_len int32 [B]: keys j < kv_len[b] are valid (right padding); a query i
+ *   attends keys j <= i with j < kv_len[b]; padded queries are still computed.
+ * head_dim is 64; nq % nkv == 0; L <= 544.  softmax in fp32, scale given.
+ * ---------------------------------------------------------------------- */
+int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B,
+                          int L, int nq, int nkv, float scale, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Generic small multi-head attention, fp32 softmax (nn.MultiheadAttention
+ * core after the in-projection: scripts/train.py:359,403,406,663,754).
+ *   q  [B][Lq] rows of stride ldq, head h at column offset h*dh
+ *   k,v [B][Lk] rows of stride ldk / ldv
+ *   key_len int32 [B] or NULL: keys j >= key_len[b] are masked (src_key_padding_mask)
+ *   out [B][Lq][nh*dh], leading dim ldo
+ * in_dtype/out_dtype: TCAVT_F32 or TCAVT_BF16 (q,k,v share in_dtype).
+ * No causal mask.  Lk <= 544, Lq*Lk*4 bytes must fit 64 KiB.
+ * ---------------------------------------------------------------------- */
+int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+              int64_t ldv, void* out, int64_t ldo, const int32_t* key_len, int B,
+              int Lq, int Lk, int nh, int dh, float scale, int in_dtype,
+              int out_dtype, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * fp32 dense layer  C[M,N] = A[M,K] . W[N,K]^T + bias (+ReLU) (+residual)
+ * for the parts of the path that must stay fp32 (raw-pixel lane polygons,
+ * LTSF head: scripts/train.py:357-365,741-765).  Any M,N,K; flags = EPI_BIAS |
+ * EPI_RELU | EPI_RESIDUAL.
+ * ---------------------------------------------------------------------- */
+int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
+                   const float* bias, const float* residual, int64_t ldr, float* C,
+                   int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * LanePolygonEncoder front and back (scripts/train.py:362-383):
+ *   poly_embed:  x[b][p] = W_in . polygon[b][p] + b_in + pos[p]      (Linear(2,d))
+ *   masked_mean: emb[b] = mean_{p < len[b]} enc[b][p]  (zeros when len[b] == 0)
+ * ---------------------------------------------------------------------- */
+int tcavt_poly_embed(const float* polygon, const float* w_in, const float* b_in,
+                     const float* pos, float* x, int B, int P, int D,
+                     tcavt_stream_t stream);
+int tcavt_masked_mean(const float* enc, const int32_t* len, float* emb, int B, int P,
+                      int D, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * TransformerLTSF front (scripts/train.py:837-839, 701-716):
+ *   xp[b][c][t] = conv_w[c][0]*x[b][0][t] + conv_w[c][1]*x[b][1][t] + conv_b[c]
+ *   enc[b][c][s] = sum_t enc_w[c][s][t]*(xp[b][c][t]-xp[b][c][T-1]) + enc_b[c][s]
+ *                  + xp[b][c][T-1] + pos[c][s]
+ * x [B][2][T]; out enc [B][C][T] and its (T,B,C)-ordered copy tok [T*B... see .hip]
+ * ---------------------------------------------------------------------- */
+int tcavt_ltsf_front(const float* x, const float* conv_w, const float* conv_b,
+                     const float* enc_w, const float* enc_b, const float* pos,
+                     float* enc_tok, int B, int C, int T, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * LTSF_NLinearDecoder front (scripts/train.py:768-785):
+ *   dec[b][c][s] = sum_t dec_w[c][s][t]*(e[b][c][t]-e[b][c][T-1]) + dec_b[c][s]
+ *                  + e[b][c][T-1] + lane_adj[b][c*To+s]
+ * e is given token-major: e_tok [B][T][C] (output layout of the attention block).
+ * out dec [B][C*To]
+ * ---------------------------------------------------------------------- */
+int tcavt_ltsf_decode(const float* e_tok, const float* dec_w, const float* dec_b,
+                      const float* lane_adj, float* dec, int B, int C, int T, int To,
+                      tcavt_stream_t stream);
+
+/* [B][C][To] -> [B][To][C] transpose (decoded.permute(0,2,1), train.py:793),
+ * optional bf16 copy for the following bf16 contraction */
+int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf16, int B, int C,
+                       int To, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Final head (scripts/train.py:804-805, 941-943):
+ *   out[b][f][s] = w[f] . fused[b][s] + bias[f] + x[b][f][T-1]
+ * fused [B][To][C]; x [B][F][T]; out [B][F][To]
+ * ---------------------------------------------------------------------- */
+int tcavt_out_head(const float* fused, const float* w, const float* bias,
+                   const float* x, float* out, int B, int To, int C, int F, int T,
+                   tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * De-normalise + loss + metrics (scripts/train.py:945-962, 1302-1325;
+ * scripts/test.py:1342-1382; ablation_study_without_lora.py:1233-1238).
+ *   pred [B][K][2][To] (K candidates; K = 1 for the plain path), gt [B][2][To],
+ *   norm_stat [B][4] = (min_x, max_x, min_y, max_y)
+ *   sums[0] = sum_b sum_t (dx^2)   sums[1] = sum_b sum_t (dy^2)   (K must be 1; MSE numerators)
+ *   sums[2] = sum_b min_k ADE      sums[3] = sum_b min_k FDE      sums[4] = sum_b min_k RMSE
+ *   argmin [B][3] int32: index of the minimising candidate for ADE/FDE/RMSE
+ *   (first minimum, as torch.min / np.argmin)
+ * sums must be zeroed by the caller; accumulated with one atomicAdd per block.
+ * ---------------------------------------------------------------------- */
+int tcavt_traj_metrics(const float* pred, const float* gt, const float* norm_stat,
+                       float* sums, int32_t* argmin, float* per_sample, int B, int K,
+                       int To, tcavt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCAVT_H */

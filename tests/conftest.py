@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """Initialise the C-ABI library on cuda:0 (fails loudly if the .so is missing)."""
+    import torch
+    from tcavt_amd import capi
+
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    ncu = capi.init(0)
+    return {"device": torch.device("cuda:0"), "num_cus": ncu}

@@ -1,0 +1,259 @@
+"""Kernel-level numerics on a real MI355X: every C-ABI entry point against a plain
+PyTorch fp32 evaluation of the same op on the same inputs (bf16-rounded where the
+kernel consumes bf16).  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 384, 256), (300, 208, 128), (1024, 768, 512)])
+def test_gemm_plain(gpu, tile, M, N, K):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    ref = a.float() @ w.float().T
+    out32 = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=tile)
+    torch.cuda.synchronize()
+    # fp32 accumulation of exact bf16 products: only summation order differs
+    assert _rel(out32, ref) < 2e-6
+    out16 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=tile)
+    assert torch.equal(out16, _bf(out32))  # bf16 output is the RNE rounding of the fp32 result
+
+
+def test_gemm_asymmetric_identity(gpu):
+    """A = I against an asymmetric W catches a transposed C write."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    K = N = 128
+    a = _bf(torch.eye(K)).to(dev)
+    w = _bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251).to(dev)
+    out = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=128)
+    assert torch.equal(out, w.float().T.contiguous())
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_bias_relu_residual_dual(gpu, tile):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K, K2 = 520, 256, 192, 64
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    a2 = _bf(torch.randn(M, K2, generator=g)).to(dev)
+    w2 = _bf(torch.randn(N, K2, generator=g) * 0.1).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    ref = torch.relu(a.float() @ w.float().T + a2.float() @ w2.float().T + bias) + res
+    out = ops.gemm_bf16(a, w, out_dtype=torch.float32, bias=bias, relu=True, residual=res, a2=a2, w2=w2, tile=tile)
+    assert _rel(out, ref) < 2e-6
+    # in-place residual (C aliases residual), as the decoder's h += ... uses it
+    h = res.clone()
+    ops.gemm_bf16(a, w, out=h, residual=h, tile=tile)
+    assert _rel(h, a.float() @ w.float().T + res) < 2e-6
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_silu_mul(gpu, tile):
+    from tcavt_amd import ops
+    from tcavt_amd.layout import interleave_gate_up
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(6)
+    M, I, K = 384, 512, 128
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    wg = _bf(torch.randn(I, K, generator=g) * 0.2)
+    wu = _bf(torch.randn(I, K, generator=g) * 0.2)
+    wgu = interleave_gate_up(wg, wu).to(dev)
+    gate = a.float() @ wg.to(dev).float().T
+    up = a.float() @ wu.to(dev).float().T
+    ref = torch.nn.functional.silu(gate) * up
+    out = ops.gemm_bf16(a, wgu, out_dtype=torch.float32, silu_mul=True, tile=tile)
+    assert out.shape == (M, I)
+    assert _rel(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_rope(gpu, tile):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, L, K = 3, 40, 128
+    nq, nkv = 4, 1
+    N = (nq + 2 * nkv) * 64
+    a = _bf(torch.randn(B * L, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.1).to(dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    ang = torch.arange(L).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    raw = (a.float() @ w.float().T).view(B, L, N // 64, 64)
+    x1, x2 = raw[..., :32], raw[..., 32:]
+    c, s = cos[None, :, None, :], sin[None, :, None, :]
+    rot = torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
+    ref = raw.clone()
+    ref[:, :, : nq + nkv] = rot[:, :, : nq + nkv]
+    out = ops.gemm_bf16(a, w, out_dtype=torch.float32, rope=(cos, sin, (nq + nkv) * 64), tile=tile)
+    assert _rel(out, ref.reshape(B * L, N)) < 2e-6
+
+
+@pytest.mark.parametrize("H", [256, 2048])
+def test_rmsnorm(gpu, H):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(H)
+    x = (torch.randn(77, H, generator=g) * 3).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    ob = torch.empty(77, H, dtype=torch.bfloat16, device=dev)
+    of = torch.empty(77, H, dtype=torch.float32, device=dev)
+    ops.rmsnorm(x, gamma, 1e-5, ob, of)
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    assert _rel(of, ref) < 1e-6
+    assert torch.equal(ob, _bf(of))
+
+
+@pytest.mark.parametrize("D", [64, 768])
+def test_layernorm_residual(gpu, D):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(D)
+    x = torch.randn(50, D, generator=g).to(dev)
+    r = torch.randn(50, D, generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    of = torch.empty_like(x)
+    ob = torch.empty(50, D, dtype=torch.bfloat16, device=dev)
+    ops.layernorm(x, gamma, beta, 1e-5, residual=r, out_f32=of, out_bf16=ob)
+    ref = torch.nn.functional.layer_norm(x + r, (D,), gamma, beta, 1e-5)
+    assert (of - ref).abs().max().item() < 5e-6
+    assert torch.equal(ob, _bf(of))
+
+
+def test_cast_and_embed(gpu):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(1003, generator=g).to(dev)
+    assert torch.equal(ops.cast_bf16(x), _bf(x))
+    B, Nq, Lt, H, V = 3, 4, 9, 256, 50
+    table = _bf(torch.randn(V, H, generator=g)).to(dev)
+    ids = torch.randint(0, V, (B, Lt), generator=g).to(dev)
+    img = torch.randn(B, Nq, H, generator=g).to(dev)
+    vm, tm = torch.randn(H, generator=g).to(dev), torch.randn(H, generator=g).to(dev)
+    h = torch.empty(B, Nq + Lt, H, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.embed_fuse(table, ids, img, vm, tm, h, flag)
+    ref = torch.cat([img + vm, table[ids].float() + tm], dim=1)
+    assert torch.equal(h, ref)
+    assert flag.item() == 0
+    ids[0, 0] = V + 5
+    ops.embed_fuse(table, ids, img, vm, tm, h, flag)
+    assert flag.item() == 1
+
+
+def _attn_ref(qkv, B, L, nq, nkv, kv_len, scale):
+    x = qkv.float().view(B, L, nq + 2 * nkv, 64)
+    q = x[:, :, :nq].permute(0, 2, 1, 3)
+    k = x[:, :, nq:nq + nkv].permute(0, 2, 1, 3).repeat_interleave(nq // nkv, dim=1)
+    v = x[:, :, nq + nkv:].permute(0, 2, 1, 3).repeat_interleave(nq // nkv, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    i = torch.arange(L, device=qkv.device)
+    mask = (i[None, :] <= i[:, None])[None] & (i[None, None, :] < kv_len[:, None, None])
+    s = s.masked_fill(~mask[:, None], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * L, nq * 64)
+
+
+@pytest.mark.parametrize("B,L,nq,nkv", [(2, 64, 4, 1), (3, 256, 8, 2), (2, 200, 4, 2), (1, 528, 4, 1)])
+def test_attn_causal_gqa(gpu, B, L, nq, nkv):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(L + nq)
+    qkv = _bf(torch.randn(B * L, (nq + 2 * nkv) * 64, generator=g)).to(dev)
+    kv_len = torch.tensor([L, max(17, L // 2), 33][:B], dtype=torch.int32, device=dev)
+    out = torch.empty(B * L, nq * 64, dtype=torch.bfloat16, device=dev)
+    ops.attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, 0.125)
+    ref = _attn_ref(qkv, B, L, nq, nkv, kv_len, 0.125)
+    # P is rounded to bf16 before the PV product and the output is bf16: 2^-9 relative per element
+    assert _rel(out, ref) < 4e-3
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+def test_attn_spiked_row(gpu):
+    """Force the online-softmax rescale: one late key dominates one query row."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    B, L, nq, nkv = 1, 128, 4, 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(B * L, (nq + 2 * nkv) * 64, generator=g) * 0.5
+    x[100, 0:64] = 4.0            # query 100, head 0
+    x[90, nq * 64:(nq + 1) * 64] = 4.0  # key 90 aligned with it (tile 2, after tiles 0/1 were accumulated)
+    qkv = _bf(x).to(dev)
+    kv_len = torch.tensor([L], dtype=torch.int32, device=dev)
+    out = torch.empty(B * L, nq * 64, dtype=torch.bfloat16, device=dev)
+    ops.attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, 0.125)
+    ref = _attn_ref(qkv, B, L, nq, nkv, kv_len, 0.125)
+    assert (out.float() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("Lq,Lk,nh,dh,dtype", [(18, 18, 8, 96, torch.float32), (64, 64, 4, 16, torch.float32),
+                                                (30, 256, 2, 1024, torch.bfloat16), (16, 6, 8, 96, torch.float32)])
+def test_mha_small(gpu, Lq, Lk, nh, dh, dtype):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    B = 3
+    g = torch.Generator(device="cpu").manual_seed(Lq * Lk + dh)
+    E = nh * dh
+    q = (torch.randn(B, Lq, E, generator=g)).to(dtype).to(dev)
+    k = (torch.randn(B, Lk, E, generator=g)).to(dtype).to(dev)
+    v = (torch.randn(B, Lk, E, generator=g)).to(dtype).to(dev)
+    key_len = torch.tensor([Lk, max(1, Lk // 2), max(1, Lk - 1)], dtype=torch.int32, device=dev)
+    out = torch.empty(B, Lq, E, dtype=torch.float32, device=dev)
+    scale = 1.0 / math.sqrt(dh)
+    ops.mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=key_len)
+    qh = q.float().view(B, Lq, nh, dh).transpose(1, 2)
+    kh = k.float().view(B, Lk, nh, dh).transpose(1, 2)
+    vh = v.float().view(B, Lk, nh, dh).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    j = torch.arange(Lk, device=dev)
+    s = s.masked_fill((j[None, :] >= key_len[:, None])[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Lq, E)
+    assert _rel(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 192, 64), (100, 64, 2048), (33, 70, 18), (960, 2, 64)])
+def test_gemm_f32(gpu, M, N, K):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    out = ops.gemm_f32(a, w, bias=bias, relu=True, residual=res)
+    ref = torch.relu(a.double() @ w.double().T + bias.double()) + res.double()
+    assert _rel(out, ref.float()) < 1e-6

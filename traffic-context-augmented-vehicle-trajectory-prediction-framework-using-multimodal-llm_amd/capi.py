@@ -1,0 +1,133 @@
+"""ctypes binding of the C-ABI library declared in ``include/tcavt.h``.
+
+This is the only way the Python host side reaches the GPU: there is no eager /
+PyTorch fallback for any op on the hot path.  If ``libtcavt_hip.so`` is missing
+or fails to load, importing :func:`lib` raises -- loudly, by design.
+
+torch is imported first so that the HIP runtime already mapped by PyTorch
+(``libamdhip64.so.7``) is the one our library binds to; device pointers and
+streams then belong to the same runtime instance.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtcavt_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE = 1, 2, 4, 8, 16
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    """Mirror of ``tcavt_gemm_args`` (include/tcavt.h)."""
+
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64),
+        ("W", c_void_p), ("ldw", c_int64),
+        ("A2", c_void_p), ("lda2", c_int64),
+        ("W2", c_void_p), ("ldw2", c_int64),
+        ("C", c_void_p), ("ldc", c_int64),
+        ("bias", c_void_p),
+        ("residual", c_void_p), ("ldr", c_int64),
+        ("rope_cos", c_void_p),
+        ("rope_sin", c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("K2", ctypes.c_int32),
+        ("out_dtype", ctypes.c_int32),
+        ("epilogue", ctypes.c_int32),
+        ("rope_L", ctypes.c_int32), ("rope_cols", ctypes.c_int32),
+        ("tile", ctypes.c_int32),
+    ]
+
+
+# name -> argtypes (return type is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "tcavt_abi_version": [],
+    "tcavt_last_error": [],
+    "tcavt_init": [c_int, ctypes.POINTER(c_int)],
+    "tcavt_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
+    "tcavt_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
+    "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                         c_int, c_void_p, c_void_p],
+    "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                  c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
+    "tcavt_gemm_f32": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                       c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_poly_embed": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_masked_mean": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_ltsf_front": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                         c_int, c_void_p],
+    "tcavt_ltsf_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_transpose_ct": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_out_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                       c_void_p],
+    "tcavt_traj_metrics": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                           c_void_p],
+}
+_RESTYPES = {"tcavt_last_error": ctypes.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class TcavtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libtcavt_hip.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TcavtError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m tcavt_amd.build`). "
+            "There is no CPU/PyTorch fallback for the hot path."
+        )
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if handle.tcavt_abi_version() != 1:
+        raise TcavtError("libtcavt_hip.so ABI version mismatch")
+    _lib = handle
+    return handle
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tcavt_last_error()
+        raise TcavtError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+_initialised = set()
+
+
+def init(device_index=0):
+    """Verify the device is gfx950 and return its CU count."""
+    n = c_int(0)
+    check(lib().tcavt_init(int(device_index), ctypes.byref(n)), "tcavt_init")
+    _initialised.add(int(device_index))
+    return n.value
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (0 = the null stream)."""
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())

@@ -1,0 +1,295 @@
+// Attention kernels for gfx950.
+//
+// (1) attn_causal_gqa_kernel -- the Llama decoder attention (SURVEY.md row F4;
+//     HF modeling_llama.py:191-213 with the sdpa causal AND key-valid mask).
+//     One workgroup per (sample, kv head); its `group` waves are the query heads
+//     that share that kv head, so K and V are fetched from HBM exactly once per
+//     (sample, kv head) and live in LDS for the whole workgroup:
+//       K   [Lp][64]  bf16, 128-byte rows, 16-byte chunks XOR-swizzled by (row>>1)&7
+//       V^T [64][Lp+4] bf16 (transposed while staging so the PV product reads
+//                           k-contiguous 8-byte pieces; +4 pad => conflict-free)
+//     Per 32-query block a wave walks the 32-key tiles up to the diagonal:
+//       S^T = K . Q^T        v_mfma_f32_32x32x16_bf16, key on the accumulator
+//                            row, query on the lane -> row softmax is lane-local
+//       O^T += V^T . P^T     the S^T accumulator, converted to bf16 in place, IS
+//                            the B operand (no LDS round trip for P)
+//     Online softmax in fp32 (exp2 with log2e folded into the scale).
+//
+// (2) mha_small_kernel -- generic fp32-softmax multi-head attention for the short
+//     sequences of the Q-Former, the lane-polygon encoder, the LTSF block and the
+//     head_dim-1024 cross-attention (scripts/train.py:359,403,406,663,754).
+#include "common.hpp"
+
+namespace tcavt {
+
+__device__ __forceinline__ bf16x8 cvt8(const float* v) {
+  u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+             pack_bf16x2(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+__global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
+                                                              bf16_t* __restrict__ out,
+                                                              const int* __restrict__ kv_len_p,
+                                                              int L, int Lp, int nq, int nkv,
+                                                              float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int group = nq / nkv;
+  const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ld = (nq + 2 * nkv) * 64;
+  const int koff = nq * 64 + kvh * 64, voff = (nq + nkv) * 64 + kvh * 64;
+  const int vstride = Lp + 4;  // elements
+  char* Ks = smem;
+  bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + Lp * 128);
+  const bf16_t* base = qkv + (long)b * L * ld;
+
+  // ---- stage K (swizzled rows) and V^T
+  const int nthreads = blockDim.x;
+  for (int idx = threadIdx.x; idx < Lp * 8; idx += nthreads) {
+    const int row = idx >> 3, c = idx & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < L) v = *reinterpret_cast<const u32x4*>(base + (long)row * ld + koff + c * 8);
+    *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+  }
+  for (int idx = threadIdx.x; idx < (Lp >> 1) * 8; idx += nthreads) {
+    const int kp = idx >> 3, c = idx & 7;
+    const int r0 = 2 * kp, r1 = 2 * kp + 1;
+    u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+    if (r0 < L) a = *reinterpret_cast<const u32x4*>(base + (long)r0 * ld + voff + c * 8);
+    if (r1 < L) bb = *reinterpret_cast<const u32x4*>(base + (long)r1 * ld + voff + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned int lo = (a[e] & 0xffffu) | (bb[e] << 16);
+      const unsigned int hi = (a[e] >> 16) | (bb[e] & 0xffff0000u);
+      *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e) * vstride + r0) = lo;
+      *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e + 1) * vstride + r0) = hi;
+    }
+  }
+  __syncthreads();
+
+  const int kv_len = min(kv_len_p[b], L);
+  const int head = kvh * group + wave;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nqb = (L + 31) >> 5;
+  const int kv_tiles = (kv_len + 31) >> 5;
+  const int kswz = (r >> 1) & 7;
+
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int qi = qb * 32 + r;  // this lane's query row
+    const int qrow = min(qi, L - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + head * 64 + s * 16 + hh * 8);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float mrun = -1e30f, lrun = 0.f;
+
+    const int ntile = min(qb + 1, kv_tiles);
+    for (int kt = 0; kt < ntile; ++kt) {
+      f32x16 sacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+      const char* krow = Ks + (kt * 32 + r) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + hh) ^ kswz) << 4));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+      }
+      // scale + mask + tile max
+      float p[16];
+      float tmax = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const bool ok = (kk <= qi) && (kk < kv_len);
+        p[i] = ok ? sacc[i] * scale_log2e : -1e30f;
+        tmax = fmaxf(tmax, p[i]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mnew = fmaxf(mrun, tmax);
+      const float alpha = exp2f(mrun - mnew);
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        p[i] = (p[i] > -1e29f) ? exp2f(p[i] - mnew) : 0.f;
+        psum += p[i];
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      lrun = lrun * alpha + psum;
+      mrun = mnew;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      // O^T += V^T . P^T  (two 16-key k-steps; P registers 8*s2.. are the B operand)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = cvt8(&p[8 * s2]);
+        const int kbase = kt * 32 + 16 * s2 + 4 * hh;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16_t* vrow = Vt + (dt * 32 + r) * vstride + kbase;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 8);
+          const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+          if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+        }
+      }
+    }
+    // ---- normalise + store: lane holds d = dt*32 + (i&3) + 8*(i>>2) + 4*hh of query qi
+    if (qi < L) {
+      const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+      bf16_t* orow = out + ((long)b * L + qi) * (nq * 64) + head * 64;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * hh;
+        u32x2 a = {pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                   pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+        u32x2 c = {pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                   pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d) = a;
+        *reinterpret_cast<u32x2*>(orow + 32 + d) = c;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic small attention.  One workgroup (256 threads) per (batch, head).
+// scores [Lq][Lk] fp32 live in LDS.  Phase 1: thread t owns score (i, j) pairs
+// strided over Lq*Lk and walks the head dim; phase 2: one wave per query row does
+// the softmax; phase 3: thread t owns (i, d) outputs strided over Lq*dh.
+// K and V rows are read from global/L2 (sequences here are <= 544 keys, the
+// per-(b,h) K/V footprint is <= 2 MB and is re-read from L2).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q, long ldq,
+                                                        const TI* __restrict__ k, long ldk,
+                                                        const TI* __restrict__ v, long ldv,
+                                                        TO* __restrict__ out, long ldo,
+                                                        const int* __restrict__ key_len, int Lq,
+                                                        int Lk, int nh, int dh, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [Lq][Lk]
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const int klen = key_len ? min(key_len[b], Lk) : Lk;
+  const TI* qb = q + (long)b * Lq * ldq + h * dh;
+  const TI* kb = k + (long)b * Lk * ldk + h * dh;
+  const TI* vb = v + (long)b * Lk * ldv + h * dh;
+  const int tid = threadIdx.x;
+
+  // phase 1: scores.  A wave handles one (i, j) at a time with lanes over d so
+  // that K/Q reads are contiguous; reduction by wave_sum.
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int ij = wave; ij < Lq * Lk; ij += 4) {
+    const int i = ij / Lk, j = ij - i * Lk;
+    float acc = 0.f;
+    if (j < klen) {
+      const TI* qr = qb + (long)i * ldq;
+      const TI* kr = kb + (long)j * ldk;
+      for (int d = lane; d < dh; d += 64) acc += ldf<TI>(qr + d) * ldf<TI>(kr + d);
+      acc = wave_sum(acc);
+    }
+    if (lane == 0) sc[ij] = (j < klen) ? acc * scale : -1e30f;
+  }
+  __syncthreads();
+  // phase 2: softmax per row (one wave per row)
+  for (int i = wave; i < Lq; i += 4) {
+    float* row = sc + i * Lk;
+    float m = -1e30f;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, row[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+      const float e = (row[j] > -1e29f) ? __expf(row[j] - m) : 0.f;
+      row[j] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    for (int j = lane; j < Lk; j += 64) row[j] *= inv;
+  }
+  __syncthreads();
+  // phase 3: out[i][d] = sum_j P[i][j] V[j][d]; consecutive threads -> consecutive d
+  for (int id = tid; id < Lq * dh; id += 256) {
+    const int i = id / dh, d = id - i * dh;
+    const float* row = sc + i * Lk;
+    float acc = 0.f;
+    for (int j = 0; j < klen; ++j) acc += row[j] * ldf<TI>(vb + (long)j * ldv + d);
+    TO* o = out + ((long)b * Lq + i) * ldo + h * dh + d;
+    if constexpr (sizeof(TO) == 2) *o = f32_to_bf16(acc);
+    else *o = acc;
+  }
+}
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B, int L,
+                                     int nq, int nkv, float scale, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv && out && kv_len, "attn_causal_gqa: null pointer");
+  TCAVT_CHECK_ARG(B > 0 && L > 0 && L <= 544, "attn_causal_gqa: L=%d must be in [1, 544]", L);
+  TCAVT_CHECK_ARG(nkv > 0 && nq % nkv == 0 && nq / nkv <= 8, "attn_causal_gqa: nq/nkv must be an integer <= 8");
+  TCAVT_CHECK_ARG(aligned16(qkv) && aligned16(out), "attn_causal_gqa: unaligned pointer");
+  const int Lp = (L + 31) & ~31;
+  const int lds = Lp * 128 + 64 * (Lp + 4) * 2;
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_causal_gqa_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) {
+      set_error("attn_causal_gqa: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+    lds_set = 160 * 1024;
+  }
+  const int group = nq / nkv;
+  hipLaunchKernelGGL(attn_causal_gqa_kernel, dim3(B * nkv), dim3(group * 64), lds,
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
+                     static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
+  TCAVT_CHECK_LAUNCH("attn_causal_gqa");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
+                         int64_t ldv, void* out, int64_t ldo, const int32_t* key_len, int B, int Lq,
+                         int Lk, int nh, int dh, float scale, int in_dtype, int out_dtype,
+                         tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(q && k && v && out, "mha: null pointer");
+  TCAVT_CHECK_ARG(B > 0 && Lq > 0 && Lk > 0 && nh > 0 && dh > 0, "mha: bad shape");
+  const long lds = (long)Lq * Lk * 4;
+  TCAVT_CHECK_ARG(lds <= 64 * 1024, "mha: Lq*Lk*4 = %ld bytes exceeds the 64 KiB score buffer", lds);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid(B * nh), block(256);
+  if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32)
+    hipLaunchKernelGGL((mha_small_kernel<float, float>), grid, block, lds, s, (const float*)q, ldq,
+                       (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+  else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16)
+    hipLaunchKernelGGL((mha_small_kernel<float, bf16_t>), grid, block, lds, s, (const float*)q, ldq,
+                       (const float*)k, ldk, (const float*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+  else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32)
+    hipLaunchKernelGGL((mha_small_kernel<bf16_t, float>), grid, block, lds, s, (const bf16_t*)q, ldq,
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+  else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_BF16)
+    hipLaunchKernelGGL((mha_small_kernel<bf16_t, bf16_t>), grid, block, lds, s, (const bf16_t*)q, ldq,
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+  else {
+    set_error("mha: bad dtype %d/%d", in_dtype, out_dtype);
+    return TCAVT_ERR_ARG;
+  }
+  TCAVT_CHECK_LAUNCH("mha");
+  return TCAVT_OK;
+}

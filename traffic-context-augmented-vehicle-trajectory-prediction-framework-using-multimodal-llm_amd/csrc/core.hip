@@ -1,0 +1,281 @@
+// Library plumbing: error channel, device check, and the HBM-bound row kernels
+// (RMSNorm, LayerNorm(+residual), fp32->bf16 cast, fused embedding build).
+// These are bandwidth-bound: every access is 16 bytes per lane, one row per
+// wave (H = 2048 fp32 = 8 KiB = 8 float4 per lane) so the only cross-lane
+// traffic is one wave reduction.
+#include "common.hpp"
+#include <string.h>
+
+namespace tcavt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------
+// RMSNorm (HF modeling_llama.py:62-67): var = mean(x^2) in fp32,
+// y = x * rsqrt(var + eps) * gamma.  One wave per row, NV float4 per lane.
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ gamma, float eps,
+                                                      bf16_t* __restrict__ out_bf16,
+                                                      float* __restrict__ out_f32, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * H);
+  const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
+  const int nvec = H >> 2;
+  f32x4 v[NV];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      v[i] = xr[idx];
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      const f32x4 g = gr[idx];
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rs * g[e];
+      if (out_bf16) {
+        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
+      }
+      if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm with optional residual add (torch.nn.LayerNorm semantics: biased
+// variance, eps inside the sqrt).  One wave per row.
+// ---------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ res,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ out_f32,
+                                                        bf16_t* __restrict__ out_bf16, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * D);
+  const f32x4* rr = res ? reinterpret_cast<const f32x4*>(res + (long)row * D) : nullptr;
+  const int nvec = D >> 2;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      v[i] = xr[idx];
+      if (rr) v[i] += rr[idx];
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[idx];
+      const f32x4 b = reinterpret_cast<const f32x4*>(beta)[idx];
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rs * g[e] + b[e];
+      if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * D + idx * 4) = y;
+      if (out_bf16) {
+        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(out_bf16 + (long)row * D + idx * 4) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x,
+                                                   bf16_t* __restrict__ out, long n) {
+  const long nvec = n >> 3;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i];
+    const f32x4 b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+    u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
+               pack_bf16x2(b[2], b[3])};
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+  // tail (n % 8 elements)
+  const long tail0 = nvec << 3;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n - tail0) out[tail0 + gid] = f32_to_bf16(x[tail0 + gid]);
+}
+
+// ---------------------------------------------------------------------------
+// Fused embedding build (scripts/train.py:521-528): one wave per output row,
+// 8 elements per lane per step (16-byte bf16 table reads, 2 x float4 writes).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restrict__ table,
+                                                         const int64_t* __restrict__ ids,
+                                                         const float* __restrict__ img,
+                                                         const float* __restrict__ vis_mod,
+                                                         const float* __restrict__ txt_mod,
+                                                         float* __restrict__ h, int B, int Nq, int Lt,
+                                                         int H, int V, int* bad_flag) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int L = Nq + Lt;
+  if (row >= (long)B * L) return;
+  const int b = (int)(row / L), i = (int)(row % L);
+  float* out = h + row * H;
+  if (i < Nq) {
+    const float* src = img + ((long)b * Nq + i) * H;
+    for (int c = lane * 4; c < H; c += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + c);
+      const f32x4 m = *reinterpret_cast<const f32x4*>(vis_mod + c);
+      *reinterpret_cast<f32x4*>(out + c) = a + m;
+    }
+  } else {
+    int64_t id = ids[(long)b * Lt + (i - Nq)];
+    if (id < 0 || id >= V) {
+      if (lane == 0) *bad_flag = 1;
+      id = 0;
+    }
+    const bf16_t* src = table + id * H;
+    for (int c = lane * 8; c < H; c += 512) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(src + c);
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(txt_mod + c);
+      const f32x4 m1 = *reinterpret_cast<const f32x4*>(txt_mod + c + 4);
+      f32x4 o0, o1;
+      o0[0] = __uint_as_float(t[0] << 16) + m0[0];
+      o0[1] = __uint_as_float(t[0] & 0xffff0000u) + m0[1];
+      o0[2] = __uint_as_float(t[1] << 16) + m0[2];
+      o0[3] = __uint_as_float(t[1] & 0xffff0000u) + m0[3];
+      o1[0] = __uint_as_float(t[2] << 16) + m1[0];
+      o1[1] = __uint_as_float(t[2] & 0xffff0000u) + m1[1];
+      o1[2] = __uint_as_float(t[3] << 16) + m1[2];
+      o1[3] = __uint_as_float(t[3] & 0xffff0000u) + m1[3];
+      *reinterpret_cast<f32x4*>(out + c) = o0;
+      *reinterpret_cast<f32x4*>(out + c + 4) = o1;
+    }
+  }
+}
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+extern "C" int tcavt_abi_version(void) { return TCAVT_ABI_VERSION; }
+
+extern "C" const char* tcavt_last_error(void) { return g_err; }
+
+extern "C" int tcavt_init(int device, int* num_cus) {
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    set_error("tcavt_init: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+    return TCAVT_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    set_error("tcavt_init: hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    return TCAVT_ERR_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("tcavt_init: device %d is %s; this library is built for gfx950 only", device,
+              prop.gcnArchName);
+    return TCAVT_ERR_ARCH;
+  }
+  if (num_cus) *num_cus = prop.multiProcessorCount;
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
+                             float* out_f32, int M, int H, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "rmsnorm: null pointer");
+  TCAVT_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8192, "rmsnorm: H=%d must be a multiple of 8 and <= 8192", H);
+  TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma), "rmsnorm: unaligned input");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((M + 3) / 4), block(256);
+  bf16_t* ob = static_cast<bf16_t*>(out_bf16);
+  const int nvec = H / 4;
+  if (nvec <= 64) hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+  else if (nvec <= 128) hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+  else if (nvec <= 256) hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+  else if (nvec <= 512) hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+  else hipLaunchKernelGGL(rmsnorm_kernel<32>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+  TCAVT_CHECK_LAUNCH("rmsnorm");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
+                               const float* beta, float eps, float* out_f32, void* out_bf16, int M,
+                               int D, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && gamma && beta && (out_f32 || out_bf16), "layernorm: null pointer");
+  TCAVT_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "layernorm: D=%d must be a multiple of 4 and <= 4096", D);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((M + 3) / 4), block(256);
+  bf16_t* ob = static_cast<bf16_t*>(out_bf16);
+  const int nvec = D / 4;
+  if (nvec <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
+  else if (nvec <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
+  else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
+  TCAVT_CHECK_LAUNCH("layernorm");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_cast_f32_bf16(const float* x, void* out_bf16, int64_t n, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && out_bf16 && n > 0, "cast: null pointer or n <= 0");
+  TCAVT_CHECK_ARG(aligned16(x) && aligned16(out_bf16), "cast: unaligned pointer");
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     static_cast<bf16_t*>(out_bf16), (long)n);
+  TCAVT_CHECK_LAUNCH("cast_f32_bf16");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
+                                const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
+                                int Lt, int H, int V, int* bad_id_flag, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && h && bad_id_flag, "embed_fuse: null pointer");
+  TCAVT_CHECK_ARG(B > 0 && Nq >= 0 && Lt >= 0 && Nq + Lt > 0 && H % 8 == 0 && V > 0, "embed_fuse: bad shape");
+  const long rows = (long)B * (Nq + Lt);
+  hipLaunchKernelGGL(embed_fuse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
+                     vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
+  TCAVT_CHECK_LAUNCH("embed_fuse");
+  return TCAVT_OK;
+}

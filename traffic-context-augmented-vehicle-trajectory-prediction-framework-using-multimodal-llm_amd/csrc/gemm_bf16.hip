@@ -1,0 +1,344 @@
+// bf16 x bf16 -> fp32-accumulate contraction for gfx950 (MI355X), hand-tiled for
+// 64-wide waves and v_mfma_f32_16x16x32_bf16.
+//
+//   C[M,N] = A[M,K] . W[N,K]^T (+ A2[M,K2] . W2[N,K2]^T)   + fused epilogue
+//
+// Both operands are K-contiguous (activations [tokens][features], nn.Linear
+// weights [out][in]), so they are staged with the same code: 64-deep K-tiles go
+// global -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4, no VGPR round trip),
+// double-buffered.  An LDS row is one tile row's 128 bytes; the eight 16-byte
+// chunks of a row are XOR-swizzled with (row>>1)&7 so that every ds_read_b128
+// fragment read is bank-conflict free.  Because LDS-DMA writes lane-linear, the
+// swizzle is applied to the per-lane SOURCE address and to the fragment READ
+// address (same involution), never to the destination.
+//
+// The MFMA is issued "swapped": the weight rows are the A operand and the token
+// rows the B operand, so each lane ends with 4 consecutive output FEATURES of
+// one token in a register quad -> 8/16-byte row-contiguous epilogue accesses,
+// and RoPE / SiLU*up partners are lane-local.
+//
+// Replaces the nn.Linear contractions listed in include/tcavt.h (reference:
+// scripts/train.py:401-406,446-452,493,754-757 and HF modeling_llama.py
+// :174-176,254-256,279-280).
+#include "common.hpp"
+
+namespace tcavt {
+
+struct GemmP {
+  const bf16_t* A;
+  const bf16_t* W;
+  const bf16_t* A2;
+  const bf16_t* W2;
+  void* C;
+  const float* bias;
+  const float* residual;
+  const float* cosT;
+  const float* sinT;
+  long lda, ldw, lda2, ldw2, ldc, ldr;
+  int M, N, K, K2;
+  int out_bf16, flags, rope_L, rope_cols;
+  int tiles_m, tiles_n;
+};
+
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2 };
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)src,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void store_quad(const GemmP& p, int m, int n, f32x4 v) {
+  if (p.out_bf16) {
+    u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = o;
+  } else {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP p) {
+  constexpr int NW = WARPS_M * WARPS_N;
+  constexpr int ROWS = BM + BN;
+  constexpr int TILE_BYTES = ROWS * 128;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int ROUNDS = ROWS / (8 * NW);
+  static_assert(ROWS % (8 * NW) == 0, "staging rounds must be whole");
+  static_assert(BM % 16 == 0 && BN % 16 == 0, "tile rows");
+  static_assert(EPI != EPI_ROPE || WTN % 64 == 0, "RoPE needs whole heads per wave");
+  static_assert(EPI != EPI_SILU || WTN % 32 == 0, "SiLU needs gate/up pairs per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+  // ---- block -> tile: XCD-aware remap (bijective), then 4-tile-tall super rows
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 4;
+    const int per_group = GM * p.tiles_n;
+    const int g = wgid / per_group, in_g = wgid - g * per_group;
+    const int gsz = min(GM, p.tiles_m - g * GM);
+    tile_m = g * GM + in_g % gsz;
+    tile_n = in_g / gsz;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-lane staging sources (main K source), one per round
+  const bf16_t* src[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int g = r * NW + wave;
+    const int row = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    if (g * 8 < BM) {
+      const int m = min(m0 + row, p.M - 1);
+      src[r] = p.A + (long)m * p.lda + c * 8;
+    } else {
+      const int n = min(n0 + row - BM, p.N - 1);
+      src[r] = p.W + (long)n * p.ldw + c * 8;
+    }
+  }
+  const int nt1 = p.K >> 6, nt = nt1 + (p.K2 >> 6);
+
+  auto stage = [&](int buf, int t) {
+    char* base = smem + buf * TILE_BYTES;
+    if (t < nt1) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) glds16(src[r] + t * 64, base + (r * NW + wave) * 1024);
+    } else {
+      const int k0 = (t - nt1) * 64;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int g = r * NW + wave;
+        const int row = g * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const bf16_t* s;
+        if (g * 8 < BM) {
+          const int m = min(m0 + row, p.M - 1);
+          s = p.A2 + (long)m * p.lda2 + k0 + c * 8;
+        } else {
+          const int n = min(n0 + row - BM, p.N - 1);
+          s = p.W2 + (long)n * p.ldw2 + k0 + c * 8;
+        }
+        glds16(s, base + g * 1024);
+      }
+    }
+  };
+
+  // ---- fragment read addressing
+  const int fsw = (lane >> 1) & 7;  // == (row>>1)&7 for row = 16*j + (lane&15)
+  const int off0 = (((lane >> 4)) ^ fsw) * 16;
+  const int off1 = ((4 + (lane >> 4)) ^ fsw) * 16;
+  const int xrow = (wm * WTM + (lane & 15)) * 128;
+  const int wrow = (BM + wn * WTN + (lane & 15)) * 128;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int off = ks ? off1 : off0;
+      bf16x8 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(base + wrow + i * 2048 + off);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        xf[j] = *reinterpret_cast<const bf16x8*>(base + xrow + j * 2048 + off);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: stage t+1 while computing t; one drain+barrier per K-tile
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt - 1; ++t) {
+    stage(cur ^ 1, t + 1);
+    compute(cur);
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+
+  // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
+  const int nq = 4 * (lane >> 4);
+  const int ml = lane & 15;
+  if constexpr (EPI == EPI_GENERIC) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + ml;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn * WTN + i * 16 + nq;
+        if (n >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.flags & TCAVT_EPI_RELU) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        if (p.flags & TCAVT_EPI_RESIDUAL)
+          v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+        store_quad(p, m, n, v);
+      }
+    }
+  } else if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + ml;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; i += 2) {
+        const int n = ((n0 + wn * WTN) >> 1) + (i >> 1) * 16 + nq;
+        const f32x4 g = acc[i][j], u = acc[i + 1][j];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+        store_quad(p, m, n, v);
+      }
+    }
+  } else {  // EPI_ROPE
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + ml;
+      if (m >= p.M) continue;
+      const int pos = m % p.rope_L;
+#pragma unroll
+      for (int hh = 0; hh < TN / 4; ++hh) {
+        const int nb = n0 + wn * WTN + hh * 64;
+        const bool rot = nb < p.rope_cols;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int d = i * 16 + nq;
+          f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
+          if (rot) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
+            const f32x4 s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
+            const f32x4 l2 = lo * c - hi * s;
+            const f32x4 h2 = hi * c + lo * s;
+            lo = l2; hi = h2;
+          }
+          store_quad(p, m, nb + d, lo);
+          store_quad(p, m, nb + 32 + d, hi);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
+static int launch(const GemmP& p0, hipStream_t stream) {
+  GemmP p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      set_error("gemm_bf16: hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n), block(WARPS_M * WARPS_N * 64);
+  hipLaunchKernelGGL(kfn, grid, block, lds, stream, p);
+  TCAVT_CHECK_LAUNCH("gemm_bf16");
+  return TCAVT_OK;
+}
+
+template <int EPI>
+static int dispatch_tile(const GemmP& p, int tile, hipStream_t stream) {
+  if (tile == 256) return launch<256, 256, 2, 4, EPI>(p, stream);
+  return launch<128, 128, 2, 2, EPI>(p, stream);
+}
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a != nullptr, "gemm_bf16: null args");
+  TCAVT_CHECK_ARG(a->A && a->W && a->C, "gemm_bf16: null A/W/C");
+  TCAVT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "gemm_bf16: bad M/N/K %d/%d/%d", a->M, a->N, a->K);
+  TCAVT_CHECK_ARG(a->K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a->K);
+  TCAVT_CHECK_ARG(a->N % 16 == 0, "gemm_bf16: N=%d must be a multiple of 16", a->N);
+  TCAVT_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K,
+                  "gemm_bf16: lda/ldw must be >= K and multiples of 8");
+  TCAVT_CHECK_ARG(aligned16(a->A) && aligned16(a->W) && aligned16(a->C), "gemm_bf16: A/W/C must be 16-byte aligned");
+  TCAVT_CHECK_ARG(a->out_dtype == TCAVT_F32 || a->out_dtype == TCAVT_BF16, "gemm_bf16: bad out_dtype");
+  const int n_out = (a->epilogue & TCAVT_EPI_SILU_MUL) ? a->N / 2 : a->N;
+  TCAVT_CHECK_ARG(a->ldc >= n_out && a->ldc % 4 == 0, "gemm_bf16: ldc=%ld too small or not a multiple of 4", (long)a->ldc);
+  int K2 = 0;
+  if (a->A2 || a->W2 || a->K2) {
+    TCAVT_CHECK_ARG(a->A2 && a->W2 && a->K2 > 0 && a->K2 % 64 == 0,
+                    "gemm_bf16: second K-source needs A2, W2 and K2 %% 64 == 0");
+    TCAVT_CHECK_ARG(a->lda2 % 8 == 0 && a->ldw2 % 8 == 0 && a->lda2 >= a->K2 && a->ldw2 >= a->K2 &&
+                        aligned16(a->A2) && aligned16(a->W2),
+                    "gemm_bf16: bad lda2/ldw2/alignment");
+    K2 = a->K2;
+  }
+  const int epi = a->epilogue;
+  if (epi & TCAVT_EPI_BIAS) TCAVT_CHECK_ARG(a->bias && aligned16(a->bias), "gemm_bf16: BIAS needs an aligned bias pointer");
+  if (epi & TCAVT_EPI_RESIDUAL)
+    TCAVT_CHECK_ARG(a->residual && aligned16(a->residual) && a->ldr >= a->N && a->ldr % 4 == 0,
+                    "gemm_bf16: RESIDUAL needs residual pointer and ldr >= N");
+  if (epi & TCAVT_EPI_SILU_MUL)
+    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~TCAVT_EPI_SILU_MUL), "gemm_bf16: SILU_MUL needs N %% 128 == 0 and no other flag");
+  if (epi & TCAVT_EPI_ROPE) {
+    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~TCAVT_EPI_ROPE), "gemm_bf16: ROPE needs N %% 128 == 0 and no other flag");
+    TCAVT_CHECK_ARG(a->rope_cos && a->rope_sin && a->rope_L > 0 && a->rope_cols % 64 == 0 &&
+                        aligned16(a->rope_cos) && aligned16(a->rope_sin),
+                    "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
+  }
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256, "gemm_bf16: tile must be 0, 128 or 256");
+
+  GemmP p;
+  p.A = static_cast<const bf16_t*>(a->A);
+  p.W = static_cast<const bf16_t*>(a->W);
+  p.A2 = static_cast<const bf16_t*>(a->A2);
+  p.W2 = static_cast<const bf16_t*>(a->W2);
+  p.C = a->C;
+  p.bias = a->bias;
+  p.residual = a->residual;
+  p.cosT = a->rope_cos;
+  p.sinT = a->rope_sin;
+  p.lda = a->lda; p.ldw = a->ldw; p.lda2 = a->lda2; p.ldw2 = a->ldw2; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = K2;
+  p.out_bf16 = a->out_dtype == TCAVT_BF16;
+  p.flags = epi;
+  p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
+  p.tiles_m = p.tiles_n = 0;
+
+  int tile = a->tile;
+  if (tile == 0) {
+    // 256x256 tiles only when they still fill the chip (>= 256 tiles)
+    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    tile = (t256 >= 256) ? 256 : 128;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU>(p, tile, s);
+  if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE>(p, tile, s);
+  return dispatch_tile<EPI_GENERIC>(p, tile, s);
+}

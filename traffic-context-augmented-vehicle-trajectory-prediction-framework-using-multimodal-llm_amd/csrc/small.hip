@@ -1,0 +1,308 @@
+// fp32 kernels for the parts of the path that must not drop to bf16: the
+// lane-polygon encoder sees raw pixel coordinates up to 3839 (scripts/train.py:364,
+// scripts/graph.py:7-216), and the LTSF head / metrics work in pixel space
+// (scripts/train.py:945-962).  All of them are tiny next to the decoder stack, so
+// they are written for clarity and coalesced access, not for MFMA.
+#include "common.hpp"
+
+namespace tcavt {
+
+// ---------------------------------------------------------------------------
+// C[M,N] = A[M,K] . W[N,K]^T (+bias)(+relu)(+residual), fp32 FMA in k order.
+// 64x64 tile, 16x16 threads, 4x4 outputs per thread, K-tile 16 staged
+// transposed in LDS ([k][row], +1 pad) so the inner loop reads float4 rows.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long lda,
+                                                       const float* __restrict__ W, long ldw,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ res, long ldr,
+                                                       float* __restrict__ C, long ldc, int M, int N,
+                                                       int K, int flags) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Ws[16][68];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  const int lr = tid >> 2, lk = (tid & 3) * 4;  // row 0..63, k offset 0,4,8,12
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + lk + e;
+      const int m = m0 + lr, n = n0 + lr;
+      As[lk + e][lr] = (m < M && k < K) ? A[(long)m * lda + k] : 0.f;
+      Ws[lk + e][lr] = (n < N && k < K) ? W[(long)n * ldw + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(&Ws[k][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = acc[i][j];
+      if (flags & TCAVT_EPI_BIAS) v += bias[n];
+      if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
+      if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
+      C[(long)m * ldc + n] = v;
+    }
+  }
+}
+
+// x[b][p][:] = W_in[:, 0]*px + W_in[:, 1]*py + b_in + pos[p]   (train.py:364-365)
+__global__ void poly_embed_kernel(const float* __restrict__ poly, const float* __restrict__ w,
+                                  const float* __restrict__ bi, const float* __restrict__ pos,
+                                  float* __restrict__ x, int B, int P, int D) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * P * D) return;
+  const int d = (int)(idx % D);
+  const long bp = idx / D;
+  const int p = (int)(bp % P);
+  const float px = poly[bp * 2], py = poly[bp * 2 + 1];
+  x[idx] = fmaf(w[d * 2 + 1], py, fmaf(w[d * 2], px, 0.f)) + bi[d] + pos[p * D + d];
+}
+
+// emb[b][d] = mean_{p<len[b]} enc[b][p][d], zeros when len == 0   (train.py:372-382)
+__global__ void masked_mean_kernel(const float* __restrict__ enc, const int* __restrict__ len,
+                                   float* __restrict__ emb, int B, int P, int D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * D) return;
+  const int b = idx / D, d = idx % D;
+  const int n = min(len[b], P);
+  float s = 0.f;
+  for (int p = 0; p < n; ++p) s += enc[((long)b * P + p) * D + d];
+  emb[idx] = n > 0 ? s / (float)n : 0.f;
+}
+
+// TransformerLTSF front: Conv1d(k=1) token projection + per-channel N-Linear
+// encoder + positional term (train.py:837-839, 701-716).  One block per sample,
+// one thread per (c, s).  Output token-major tok[b][s][c].
+__global__ void ltsf_front_kernel(const float* __restrict__ x, const float* __restrict__ cw,
+                                  const float* __restrict__ cb, const float* __restrict__ ew,
+                                  const float* __restrict__ eb, const float* __restrict__ pos,
+                                  float* __restrict__ tok, int B, int C, int T) {
+  extern __shared__ float xs[];  // [2][T]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) xs[i] = x[(long)b * 2 * T + i];
+  __syncthreads();
+  for (int cs = threadIdx.x; cs < C * T; cs += blockDim.x) {
+    const int c = cs / T, s = cs % T;
+    const float w0 = cw[c * 2], w1 = cw[c * 2 + 1], bb = cb[c];
+    const float last = fmaf(w1, xs[T + T - 1], fmaf(w0, xs[T - 1], 0.f)) + bb;
+    float acc = 0.f;
+    const float* wr = ew + ((long)c * T + s) * T;
+    for (int t = 0; t < T; ++t) {
+      const float xp = fmaf(w1, xs[T + t], fmaf(w0, xs[t], 0.f)) + bb;
+      acc = fmaf(wr[t], xp - last, acc);
+    }
+    tok[((long)b * T + s) * C + c] = acc + eb[c * T + s] + last + pos[c * T + s];
+  }
+}
+
+// LTSF_NLinearDecoder front (train.py:768-785): per-channel Linear(T -> To) on
+// (e - e_last), + e_last + lane_adj.  e given token-major [B][T][C].
+__global__ void ltsf_decode_kernel(const float* __restrict__ e, const float* __restrict__ dw,
+                                   const float* __restrict__ db, const float* __restrict__ lane,
+                                   float* __restrict__ dec, int B, int C, int T, int To) {
+  extern __shared__ float es[];  // [T][C]
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < T * C; i += blockDim.x) es[i] = e[(long)b * T * C + i];
+  __syncthreads();
+  for (int cs = threadIdx.x; cs < C * To; cs += blockDim.x) {
+    const int c = cs / To, s = cs % To;
+    const float last = es[(T - 1) * C + c];
+    const float* wr = dw + ((long)c * To + s) * T;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = fmaf(wr[t], es[t * C + c] - last, acc);
+    dec[(long)b * C * To + cs] = acc + db[c * To + s] + last + lane[(long)b * C * To + cs];
+  }
+}
+
+__global__ void transpose_ct_kernel(const float* __restrict__ in, float* __restrict__ of,
+                                    bf16_t* __restrict__ ob, int B, int C, int To) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][To][C]
+  if (idx >= (long)B * C * To) return;
+  const int c = (int)(idx % C);
+  const long bs = idx / C;
+  const int s = (int)(bs % To);
+  const long b = bs / To;
+  const float v = in[(b * C + c) * To + s];
+  if (of) of[idx] = v;
+  if (ob) ob[idx] = f32_to_bf16(v);
+}
+
+// out[b][f][s] = w[f] . fused[b][s] + bias[f] + x[b][f][T-1]   (train.py:804-805,941-943)
+__global__ void out_head_kernel(const float* __restrict__ fused, const float* __restrict__ w,
+                                const float* __restrict__ bias, const float* __restrict__ x,
+                                float* __restrict__ out, int B, int To, int C, int F, int T) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F * To) return;
+  const int s = idx % To, f = (idx / To) % F, b = idx / (To * F);
+  const float* fr = fused + ((long)b * To + s) * C;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) acc = fmaf(w[f * C + c], fr[c], acc);
+  out[idx] = acc + bias[f] + x[((long)b * F + f) * T + T - 1];
+}
+
+// ---------------------------------------------------------------------------
+// De-normalise + squared error + ADE/FDE/RMSE with min over K candidates.
+// One block (64 threads = one wave) per sample; lanes over time steps.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void traj_metrics_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ gt,
+                                                          const float* __restrict__ ns,
+                                                          float* __restrict__ sums,
+                                                          int* __restrict__ argmin,
+                                                          float* __restrict__ per_sample, int B, int K,
+                                                          int To) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float minx = ns[b * 4], maxx = ns[b * 4 + 1], miny = ns[b * 4 + 2], maxy = ns[b * 4 + 3];
+  const float rx = maxx - minx, ry = maxy - miny;
+  float best_ade = 0.f, best_fde = 0.f, best_rmse = 0.f;
+  int ia = 0, ifd = 0, ir = 0;
+  float sx_tot = 0.f, sy_tot = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float* px = pred + (((long)b * K + k) * 2) * To;
+    const float* py = px + To;
+    const float* gx = gt + (long)b * 2 * To;
+    const float* gy = gx + To;
+    float sx = 0.f, sy = 0.f, se = 0.f, last = 0.f;
+    for (int t = lane; t < To; t += 64) {
+      const float dx = (px[t] * rx + minx) - (gx[t] * rx + minx);
+      const float dy = (py[t] * ry + miny) - (gy[t] * ry + miny);
+      sx += dx * dx;
+      sy += dy * dy;
+      const float err = sqrtf(dx * dx + dy * dy);
+      se += err;
+      if (t == To - 1) last = err;
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    se = wave_sum(se);
+    last = wave_sum(last);
+    const float ade = se / (float)To;
+    const float rmse = sqrtf((sx + sy) / (float)(2 * To));
+    if (k == 0 || ade < best_ade) { best_ade = ade; ia = k; }
+    if (k == 0 || last < best_fde) { best_fde = last; ifd = k; }
+    if (k == 0 || rmse < best_rmse) { best_rmse = rmse; ir = k; }
+    if (k == 0) { sx_tot = sx; sy_tot = sy; }
+  }
+  if (lane == 0) {
+    atomicAdd(&sums[0], sx_tot);
+    atomicAdd(&sums[1], sy_tot);
+    atomicAdd(&sums[2], best_ade);
+    atomicAdd(&sums[3], best_fde);
+    atomicAdd(&sums[4], best_rmse);
+    if (argmin) { argmin[b * 3] = ia; argmin[b * 3 + 1] = ifd; argmin[b * 3 + 2] = ir; }
+    if (per_sample) { per_sample[b * 3] = best_ade; per_sample[b * 3 + 1] = best_fde; per_sample[b * 3 + 2] = best_rmse; }
+  }
+}
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+extern "C" int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
+                              const float* bias, const float* residual, int64_t ldr, float* C,
+                              int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0, "gemm_f32: null pointer or bad shape");
+  TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32: BIAS without bias");
+  TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
+  TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32: unsupported flag");
+  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)lda, W,
+                     (long)ldw, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
+  TCAVT_CHECK_LAUNCH("gemm_f32");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_poly_embed(const float* polygon, const float* w_in, const float* b_in,
+                                const float* pos, float* x, int B, int P, int D, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(polygon && w_in && b_in && pos && x && B > 0 && P > 0 && D > 0, "poly_embed: bad args");
+  const long n = (long)B * P * D;
+  hipLaunchKernelGGL(poly_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), polygon, w_in, b_in, pos, x, B, P, D);
+  TCAVT_CHECK_LAUNCH("poly_embed");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_masked_mean(const float* enc, const int32_t* len, float* emb, int B, int P, int D,
+                                 tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(enc && len && emb && B > 0 && P > 0 && D > 0, "masked_mean: bad args");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3((B * D + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), enc, len, emb, B, P, D);
+  TCAVT_CHECK_LAUNCH("masked_mean");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_ltsf_front(const float* x, const float* conv_w, const float* conv_b,
+                                const float* enc_w, const float* enc_b, const float* pos,
+                                float* enc_tok, int B, int C, int T, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && conv_w && conv_b && enc_w && enc_b && pos && enc_tok && B > 0 && C > 0 && T > 0,
+                  "ltsf_front: bad args");
+  hipLaunchKernelGGL(ltsf_front_kernel, dim3(B), dim3(256), 2 * T * sizeof(float),
+                     static_cast<hipStream_t>(stream), x, conv_w, conv_b, enc_w, enc_b, pos, enc_tok, B, C, T);
+  TCAVT_CHECK_LAUNCH("ltsf_front");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_ltsf_decode(const float* e_tok, const float* dec_w, const float* dec_b,
+                                 const float* lane_adj, float* dec, int B, int C, int T, int To,
+                                 tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(e_tok && dec_w && dec_b && lane_adj && dec && B > 0 && C > 0 && T > 0 && To > 0,
+                  "ltsf_decode: bad args");
+  TCAVT_CHECK_ARG((long)T * C * 4 <= 48 * 1024, "ltsf_decode: T*C too large for LDS");
+  hipLaunchKernelGGL(ltsf_decode_kernel, dim3(B), dim3(256), T * C * sizeof(float),
+                     static_cast<hipStream_t>(stream), e_tok, dec_w, dec_b, lane_adj, dec, B, C, T, To);
+  TCAVT_CHECK_LAUNCH("ltsf_decode");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf16, int B, int C, int To,
+                                  tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(in && (out_f32 || out_bf16) && B > 0 && C > 0 && To > 0, "transpose_ct: bad args");
+  const long n = (long)B * C * To;
+  hipLaunchKernelGGL(transpose_ct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out_f32, static_cast<bf16_t*>(out_bf16), B, C, To);
+  TCAVT_CHECK_LAUNCH("transpose_ct");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_out_head(const float* fused, const float* w, const float* bias, const float* x,
+                              float* out, int B, int To, int C, int F, int T, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(fused && w && bias && x && out && B > 0 && To > 0 && C > 0 && F > 0 && T > 0,
+                  "out_head: bad args");
+  const int n = B * F * To;
+  hipLaunchKernelGGL(out_head_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     fused, w, bias, x, out, B, To, C, F, T);
+  TCAVT_CHECK_LAUNCH("out_head");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_traj_metrics(const float* pred, const float* gt, const float* norm_stat,
+                                  float* sums, int32_t* argmin, float* per_sample, int B, int K, int To,
+                                  tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(pred && gt && norm_stat && sums && B > 0 && K > 0 && To > 0, "traj_metrics: bad args");
+  hipLaunchKernelGGL(traj_metrics_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), pred, gt,
+                     norm_stat, sums, argmin, per_sample, B, K, To);
+  TCAVT_CHECK_LAUNCH("traj_metrics");
+  return TCAVT_OK;
+}
