@@ -1,0 +1,222 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; not needed on the GPU box)
+
+What is executed from the reference (imported by path, never copied):
+  * scripts/ablation_study_without_lora.py : MultiModalTrajectoryModel and every class under it
+    (LanePolygonEncoder, BlipQFormer, LlamaMultiModal, LlamaWithCrossAttnPEFT,
+    SelfAttentionBlock, LTSF_*, TransformerLTSF) -- line-for-line the classes of
+    scripts/train.py:352-964 without the `peft` import.
+  * scripts/baseline_cv.py : ConstantVelocityPredictor, build_dataset_from_tracks_sliding,
+    MultiModalTrajectoryDataset, custom_collate_fn.
+Shims (not reference code): `AutoModelForCausalLM.from_pretrained` is rebound, inside the
+imported module's namespace only, to build a local random `LlamaForCausalLM(LlamaConfig)`
+of the requested shape (no network fetch); the tokenizer to a stub.  LoRA (`peft` is not
+installed) is a 6-line module implementing y = W x + (alpha/r) B A x on q_proj / v_proj
+(targets: modify_scripts/modify_train.py:518), eval mode (dropout off).
+
+Weights come from tcavt_amd.weights.make_weights(cfg, seed) and are loaded into the
+reference modules with load_state_dict(strict=True); the .npz files therefore hold only
+inputs, expected outputs and the (preset, seed) needed to regenerate the weights.
+"""
+import importlib.util
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tcavt_amd import config as tconfig  # noqa: E402
+from tcavt_amd import synth  # noqa: E402
+from tcavt_amd.weights import make_weights, is_lora_key, LLAMA_PREFIX  # noqa: E402
+
+REF = "/root/reference/scripts"
+
+
+def _import(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _llama_factory(ll):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    class Factory:
+        @staticmethod
+        def from_pretrained(name, **kw):
+            cfg = LlamaConfig(
+                hidden_size=ll.hidden, intermediate_size=ll.inter, num_hidden_layers=ll.layers,
+                num_attention_heads=ll.n_q_heads, num_key_value_heads=ll.n_kv_heads, head_dim=ll.head_dim,
+                vocab_size=ll.vocab, max_position_embeddings=131072, rms_norm_eps=ll.rms_eps,
+                rope_theta=ll.rope_theta, tie_word_embeddings=True, attention_bias=False, mlp_bias=False,
+                rope_scaling={"factor": ll.rope_factor, "high_freq_factor": ll.rope_high_freq_factor,
+                              "low_freq_factor": ll.rope_low_freq_factor,
+                              "original_max_position_embeddings": ll.rope_original_max_pos, "rope_type": "llama3"})
+            return LlamaForCausalLM(cfg)
+
+    return Factory
+
+
+class _Tok:
+    pad_token = "<pad>"
+    eos_token = "<eos>"
+
+    @staticmethod
+    def from_pretrained(name, **kw):
+        return _Tok()
+
+
+class LoRALinear(nn.Module):
+    """y = W x + (alpha/r) * B(A(x)); PEFT's LoRA layer in eval mode, restated."""
+
+    def __init__(self, base, A, B, scale):
+        super().__init__()
+        self.base, self.A, self.B, self.scale = base, nn.Parameter(A), nn.Parameter(B), scale
+
+    def forward(self, x):
+        return self.base(x) + self.scale * ((x @ self.A.T) @ self.B.T)
+
+
+def build_reference_model(ref, cfg, weights):
+    ref.AutoModelForCausalLM = _llama_factory(cfg.llama)
+    ref.AutoTokenizer = _Tok
+    model = ref.MultiModalTrajectoryModel(
+        seq_len=cfg.seq_len, out_len=cfg.out_len, individual=cfg.individual, feature_size=cfg.feature_size,
+        d_model=cfg.d_model, lane_polygon_d_model=cfg.lane_polygon_d_model,
+        lane_polygon_nhead=cfg.lane_polygon_nhead, lane_polygon_layers=cfg.lane_polygon_layers,
+        max_polygon_points=cfg.max_polygon_points, use_post_mlp=cfg.use_post_mlp,
+        post_mlp_hidden_dim=cfg.post_mlp_hidden_dim, base_model_name="local-random-llama",
+        vision_dim=cfg.vision_dim, q_hidden_size=cfg.q_hidden_size, q_nhead=cfg.q_nhead,
+        q_enc_layers=cfg.q_enc_layers, q_dec_layers=cfg.q_dec_layers,
+        q_num_query_tokens=cfg.q_num_query_tokens, ltsf_nhead=cfg.ltsf_nhead, ltsf_dropout=cfg.ltsf_dropout)
+    sd = {k: torch.from_numpy(v) for k, v in weights.items() if not is_lora_key(k)}
+    model.load_state_dict(sd, strict=True)
+    if cfg.use_lora:
+        scale = cfg.lora_alpha / cfg.lora_r
+        layers = model.mllm.llama_wrapper.llama_model.model.layers
+        for i, layer in enumerate(layers):
+            for proj in ("q_proj", "v_proj"):
+                key = f"{LLAMA_PREFIX}layers.{i}.self_attn.{proj}."
+                A = torch.from_numpy(weights[key + "lora_A.weight"])
+                B = torch.from_numpy(weights[key + "lora_B.weight"])
+                setattr(layer.self_attn, proj, LoRALinear(getattr(layer.self_attn, proj), A, B, scale))
+    model.eval()
+    return model
+
+
+CASES = [
+    # name, preset, T, To, lora, B, text_len, ragged, empty_polygon_every, seed
+    ("tiny_6_12_lora_ragged", "tiny", 6, 12, True, 3, 20, True, 3, 11),
+    ("tiny_18_30_nolora_ragged", "tiny", 18, 30, False, 2, 24, True, 0, 12),
+    ("tiny_6_30_lora_full", "tiny", 6, 30, True, 2, 16, False, 0, 13),
+]
+
+
+def run_model_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_every, seed):
+    cfg = tconfig.PRESETS[preset](seq_len=T, out_len=To, use_lora=lora)
+    weights = make_weights(cfg, seed)
+    model = build_reference_model(ref, cfg, weights)
+    batch = synth.make_batch(cfg, B, text_len=text_len, seed=seed, ragged=ragged, min_text=4,
+                             empty_polygon_every=empty_every)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    ns = [tuple(float(v) for v in row) for row in batch["norm_stat"]]
+    pl = [int(v) for v in batch["lane_polygon_len"]]
+    with torch.no_grad():
+        poly_emb = model.lane_polygon_encoder(t["lane_polygon"], pl)
+        img_tokens = model.mllm.qformer(t["vision_emb"])
+        final_hidden, n_img = model.mllm(t["vision_emb"], None, input_ids=t["input_ids"],
+                                         attention_mask=t["attention_mask"], labels=t["labels"])
+        loss, decoded = model(t["traj_emb"], t["vision_emb"], None, t["lane_polygon"], pl, y=t["target_traj"],
+                              norm_stat=ns, input_ids=t["input_ids"], attention_mask=t["attention_mask"],
+                              labels=t["labels"])
+        decoded_only = model(t["traj_emb"], t["vision_emb"], None, t["lane_polygon"], pl,
+                             input_ids=t["input_ids"], attention_mask=t["attention_mask"])
+    assert torch.equal(decoded, decoded_only) and n_img == cfg.q_num_query_tokens
+    out = dict(batch)
+    out.update({
+        "preset": np.array(preset), "seed": np.array(seed), "use_lora": np.array(lora),
+        "seq_len": np.array(T), "out_len": np.array(To),
+        "exp_poly_emb": poly_emb.numpy(), "exp_img_tokens": img_tokens.numpy(),
+        "exp_final_hidden": final_hidden.numpy(), "exp_decoded": decoded.numpy(),
+        "exp_loss": np.array(loss.item(), np.float64),
+    })
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"[golden] {name}: loss={loss.item():.6f} decoded[0,:,0]={decoded[0, :, 0].tolist()}")
+
+
+def run_cv_case():
+    """Config 1 (baseline_cv.py): dataset builder + collate + CV predictor + evaluate_cv's printed
+    minADE/minFDE/minRMSE on 64 synthetic tracks (pickle written to a temp dir)."""
+    import pickle
+    import random
+    import re
+    import tempfile
+
+    cv = _import(os.path.join(REF, "baseline_cv.py"), "ref_baseline_cv")
+    tracks = synth.make_tracks(n_tracks=64, n_frames=400, seed=0)
+    ins, outs = cv.build_dataset_from_tracks_sliding(tracks, seq_len=6, out_len=30, stride=6, max_step=50.0,
+                                                     max_speed_diff=30.0, image_width=3840, image_height=2160,
+                                                     downsample=5)
+    ds = cv.TrajectoryDataset(ins, outs)
+    idx = list(range(0, len(ds), max(1, len(ds) // 16)))[:16]
+    coll = cv.custom_collate_fn([ds[i] for i in idx])
+    model = cv.ConstantVelocityPredictor(6, 30)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        pred = model(coll["traj_emb"], num_candidates=10, noise_scale=0.1)  # (B,K,To,2)
+    torch.manual_seed(0)
+    noise = torch.stack([torch.randn(len(idx), 2) for _ in range(10)], dim=1)  # the draws it consumed
+
+    # full evaluate_cv run (baseline_cv.py:280-360) on the same tracks; it only prints its result
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        pkl = os.path.join(tmp, "all_data.pkl")
+        with open(pkl, "wb") as f:
+            pickle.dump(tracks, f)
+        os.chdir(tmp)
+        try:
+            random.seed(0)
+            torch.manual_seed(0)
+            buf = io.StringIO()
+            with redirect_stdout(buf):
+                cv.evaluate_cv({"all_data_pkl": pkl, "seq_len": 6, "out_len": 30, "batch_size": 16, "stride": 6,
+                                "downsample": 5, "max_step": 50.0, "max_speed_diff": 30.0, "image_width": 3840,
+                                "image_height": 2160})
+        finally:
+            os.chdir(cwd)
+    m = re.search(r"minADE=([0-9.]+), minFDE=([0-9.]+), minRMSE=([0-9.]+)", buf.getvalue())
+    printed = np.array([float(m.group(i)) for i in (1, 2, 3)])
+    np.savez_compressed(
+        os.path.join(HERE, "cv_64tracks.npz"),
+        n_windows=np.array(len(ins)), sample_idx=np.array(idx),
+        traj_emb=coll["traj_emb"].numpy(), target_traj=coll["target_traj"].numpy(),
+        norm_stat=np.array(coll["norm_stat"], np.float64), cv_pred=pred.numpy(), cv_noise=noise.numpy(),
+        all_norm_stat=np.array([s["norm_stat"] for s in ins], np.float64),
+        all_track_id=np.array([s["track_id"] for s in ins]),
+        all_poly_len=np.array([len(s["lane_polygon"]) for s in ins]),
+        evaluate_cv_printed=printed,
+    )
+    print(f"[golden] cv_64tracks: windows={len(ins)} pred{tuple(pred.shape)} evaluate_cv={printed.tolist()}")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    with redirect_stdout(io.StringIO()):
+        ref = _import(os.path.join(REF, "ablation_study_without_lora.py"), "ref_nolora")
+    for case in CASES:
+        run_model_case(ref, *case)
+    run_cv_case()
+
+
+if __name__ == "__main__":
+    main()
