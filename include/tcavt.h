@@ -57,6 +57,7 @@ int tcavt_init(int device, int* num_cus);
  *     (:493,521), cross_attn in/out projections and dec_proj/dec_unproj
  *     (:754-757,794-799)
  * Epilogue flags (combinable where it makes sense):
+ *   (first)   acc *= acc_scale  (LoRA alpha/r on the down-projection)
  *   BIAS      acc += bias[n]
  *   RELU      acc = max(acc, 0)
  *   RESIDUAL  acc += residual[m][n]            (fp32, may alias C when C is fp32)
@@ -90,6 +91,7 @@ typedef struct tcavt_gemm_args {
   int32_t epilogue;              /* TCAVT_EPI_* flags */
   int32_t rope_L, rope_cols;
   int32_t tile;                  /* 0 = auto, 128 or 256 = force square tile */
+  float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -128,6 +130,16 @@ int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* im
                      const float* vis_mod, const float* txt_mod, float* h, int B,
                      int Nq, int Lt, int H, int V, int* bad_id_flag,
                      tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * attention_mask -> per-sample valid key count of the fused sequence
+ * (scripts/train.py:531-532: mask = [ones(B,Nq), attention_mask]):
+ *   kv_len[b] = Nq + sum_j mask[b][j]
+ * The collate function right-pads (train.py:330-331), so a valid mask is a prefix
+ * of ones; *not_prefix_flag (device int) is set to 1 if some mask is not.
+ * ---------------------------------------------------------------------- */
+int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_len,
+                        int* not_prefix_flag, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Causal grouped-query attention over the fused sequence
@@ -207,12 +219,12 @@ int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf16, int B, i
 
 /* ------------------------------------------------------------------------
  * Final head (scripts/train.py:804-805, 941-943):
- *   out[b][f][s] = w[f] . fused[b][s] + bias[f] + x[b][f][T-1]
+ *   out[b][f][s] = w[f] . fused[b][s] + bias[f] (+ x[b][f][T-1] when add_last != 0)
  * fused [B][To][C]; x [B][F][T]; out [B][F][To]
  * ---------------------------------------------------------------------- */
 int tcavt_out_head(const float* fused, const float* w, const float* bias,
                    const float* x, float* out, int B, int To, int C, int F, int T,
-                   tcavt_stream_t stream);
+                   int add_last, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * De-normalise + loss + metrics (scripts/train.py:945-962, 1302-1325;

@@ -1,0 +1,69 @@
+"""Host-logic dry run on CPU: the whole model.forward call sequence is executed against a stub
+library that accepts every call, so the Python side's buffer shapes, leading dimensions and
+argument orders go through the wrappers' host-side guards (ops._need) without a GPU.
+No arithmetic happens here; numerics are the GPU tests' job."""
+import ctypes
+
+import pytest
+import torch
+
+from tests.util import batch_tensors, load_case
+
+
+class _StubLib:
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        if not name.startswith("tcavt_"):
+            raise AttributeError(name)
+
+        def fn(*args):
+            self.calls.append(name)
+            return 0
+
+        return fn
+
+
+@pytest.fixture
+def dry(monkeypatch):
+    from tcavt_amd import ops
+
+    stub = _StubLib()
+    monkeypatch.setattr(ops, "lib", lambda: stub)
+    monkeypatch.setattr(ops, "stream_ptr", lambda: None)
+    monkeypatch.setattr(ops, "_ALLOW_CPU", True)
+    return stub
+
+
+@pytest.mark.parametrize("name", ["tiny_6_12_lora_ragged", "tiny_18_30_nolora_ragged"])
+def test_forward_call_sequence_passes_host_guards(dry, name):
+    from tcavt_amd import model
+
+    cfg, weights, fx = load_case(name)
+    t = batch_tensors(fx)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights).eval()
+    with torch.no_grad():
+        loss, decoded = m(t["traj_emb"], t["vision_emb"], None, t["lane_polygon"], t["lane_polygon_len"],
+                          y=t["target_traj"], norm_stat=t["norm_stat"], input_ids=t["input_ids"],
+                          attention_mask=t["attention_mask"], labels=t["labels"])
+    assert decoded.shape == (t["traj_emb"].shape[0], 2, cfg.out_len)
+    n_layers = cfg.llama.layers
+    assert dry.calls.count("tcavt_attn_causal_gqa") == n_layers
+    assert dry.calls.count("tcavt_rmsnorm") == 2 * n_layers + 1
+    assert dry.calls.count("tcavt_embed_fuse") == 1
+    gemms = dry.calls.count("tcavt_gemm_bf16")
+    assert gemms >= n_layers * (5 if cfg.use_lora else 4)
+
+
+def test_guard_catches_short_buffer(dry):
+    from tcavt_amd import capi, ops
+
+    table = torch.zeros(16, 64, dtype=torch.bfloat16)
+    ids = torch.zeros(2, 5, dtype=torch.int64)
+    img = torch.zeros(2 * 3, 64)
+    h_ok = torch.zeros(2 * 8, 64)
+    flag = torch.zeros(1, dtype=torch.int32)
+    ops.embed_fuse(table, ids, img, torch.zeros(64), torch.zeros(64), h_ok, flag)
+    with pytest.raises(capi.TcavtError, match="kernel needs"):
+        ops.embed_fuse(table, ids, img, torch.zeros(64), torch.zeros(64), torch.zeros(2 * 7, 64), flag)

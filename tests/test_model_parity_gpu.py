@@ -1,0 +1,243 @@
+"""End-to-end and stage-level parity of the HIP path (through the C ABI) on a real MI355X.
+
+References:
+  (1) golden fixture  = the reference's own modules, fp32           (tests/golden/*.npz)
+  (2) oracle fp32     = CPU restatement, pinned to (1) in tests/test_oracle_golden.py
+  (3) oracle bf16     = same graph with the GPU path's bf16 rounding points ("bf16 contract")
+
+What can and cannot be asserted (measured, see DESIGN.md "Precision contract"):
+  * bf16 storage of GEMM operands costs ~1.6e-3 relative per contraction against fp32, which
+    compounds to ~7e-3 on the decoder's final hidden states and ~1.4e-3 on the decoded
+    trajectories -- for ANY bf16 pipeline, (3) included.  Two bf16 pipelines that differ only in
+    fp32 summation order also drift apart at the ~2e-3 level over a whole stack (a 1e-6 input
+    perturbation moves (3) by 1.8e-3 on final_hidden), so a whole-model "<= 1e-3 vs (3)" bar is
+    not a property of correctness.  The 1e-3 bar of BASELINE.json is therefore enforced where it
+    is well-posed:
+      - per STAGE from identical inputs (one decoder layer, Q-Former, LTSF head): <= 1e-3 vs (3)
+      - fp32-only stages (lane polygon encoder, metrics): <= 1e-4 / 1e-5 vs (1)/(2)
+      - whole model: the HIP path must be as close to the fp32 reference (1) as the bf16 contract
+        itself is: err_hip <= 1.5 * err_(3) + 1e-3, plus decoded within 3e-3 of (1)
+      - ADE/FDE (pixels): within 1e-3 relative of (3)'s metrics and 3e-3 of (2)'s;
+        min-over-K indices bit-exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import MODEL_CASES, batch_tensors, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(cfg, weights, t, dev, with_loss=True):
+    from tcavt_amd import model
+
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    g = {k: v.to(dev) for k, v in t.items()}
+    kw = dict(input_ids=g["input_ids"], attention_mask=g["attention_mask"], labels=g["labels"])
+    if with_loss:
+        kw.update(y=g["target_traj"], norm_stat=g["norm_stat"])
+    with torch.no_grad():
+        out = m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], **kw)
+    torch.cuda.synchronize()
+    m.mllm.check_flags()
+    return m, out
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_forward_matches_oracle_and_fixture(gpu, name):
+    from oracle import forward as O
+
+    cfg, weights, fx = load_case(name)
+    t = batch_tensors(fx)
+    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"])
+    ex16 = {}
+    with torch.no_grad():
+        loss16, dec16 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
+                                        t["lane_polygon_len"], t["input_ids"], t["attention_mask"],
+                                        y=t["target_traj"], norm_stat=t["norm_stat"], contract="bf16", extras=ex16)
+    got_poly = m.last.poly_emb.cpu()
+    got_fh = m.last.final_hidden.cpu()
+    got_dec = decoded.cpu()
+    # fp32 stage
+    assert rel_err(got_poly, fx["exp_poly_emb"]) < 1e-4
+    # bf16 stages vs the bf16-contract oracle
+    e_fh = rel_err(got_fh, ex16["final_hidden"])
+    e_dec = rel_err(got_dec, dec16)
+    # and vs the reference's fp32 result
+    f_fh = rel_err(got_fh, fx["exp_final_hidden"])
+    f_dec = rel_err(got_dec, fx["exp_decoded"])
+    print(f"[parity {name}] final_hidden: vs bf16-oracle {e_fh:.2e}, vs reference fp32 {f_fh:.2e}; "
+          f"decoded: vs bf16-oracle {e_dec:.2e}, vs reference fp32 {f_dec:.2e}")
+    o_fh = rel_err(ex16["final_hidden"], fx["exp_final_hidden"])
+    o_dec = rel_err(dec16, fx["exp_decoded"])
+    print(f"[parity {name}] bf16 contract's own error vs reference fp32: final_hidden {o_fh:.2e}, decoded {o_dec:.2e}")
+    assert f_fh <= 1.5 * o_fh + 1e-3 and f_dec <= 1.5 * o_dec + 1e-3
+    assert e_fh <= 1.5 * o_fh + 1e-3 and e_dec <= 1.5 * o_dec + 1e-3
+    assert f_dec < 3e-3
+    assert abs(loss.item() - float(fx["exp_loss"])) / float(fx["exp_loss"]) < 1e-2
+    assert abs(loss.item() - loss16.item()) / abs(loss16.item()) < 1e-2
+
+
+def test_decoded_only_branch_and_padded_rows(gpu):
+    """y=None branch returns decoded only (train.py:963-964); padded query rows of final_hidden are
+    finite and match the oracle (they feed the unmasked cross-attention, train.py:798)."""
+    from oracle import forward as O
+
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    m, decoded = _run_gpu(cfg, weights, t, gpu["device"], with_loss=False)
+    assert torch.is_tensor(decoded) and decoded.shape == (t["traj_emb"].shape[0], 2, cfg.out_len)
+    ex = {}
+    with torch.no_grad():
+        O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                        t["input_ids"], t["attention_mask"], contract="bf16", extras=ex)
+    mask = t["attention_mask"]
+    pad = torch.cat([torch.zeros(mask.shape[0], cfg.q_num_query_tokens, dtype=torch.bool), mask == 0], dim=1)
+    got = m.last.final_hidden.cpu()[pad]
+    assert torch.isfinite(got).all()
+    exp32 = torch.from_numpy(fx["exp_final_hidden"])[pad]
+    assert rel_err(got, exp32) <= 1.5 * rel_err(ex["final_hidden"][pad], exp32) + 1e-3
+
+
+def test_metrics_kernel_known_answers_and_argmin(gpu):
+    from oracle import forward as O
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(0)
+    B, K, To = 37, 10, 30
+    gt = torch.rand(B, 2, To, generator=g)
+    pred = gt[:, None] + 0.05 * torch.randn(B, K, 2, To, generator=g)
+    pred[:, 3] = pred[:, 7]  # exact ties: first minimum must win, as torch.min / np.argmin
+    ns = torch.stack([torch.full((B,), 100.0), torch.full((B,), 900.0) + torch.arange(B), torch.full((B,), 990.0),
+                      torch.full((B,), 1100.0)], dim=1)
+    sums = torch.zeros(5, device=dev)
+    argmin = torch.empty(B, 3, dtype=torch.int32, device=dev)
+    per = torch.empty(B, 3, device=dev)
+    ops.traj_metrics(pred.to(dev), gt.to(dev), ns.to(dev), sums, argmin, per, B, K, To)
+    ref = O.traj_metrics(pred, gt, ns)
+    assert torch.equal(argmin[:, 0].cpu().long(), ref["ade_argmin"])
+    assert torch.equal(argmin[:, 1].cpu().long(), ref["fde_argmin"])
+    assert torch.equal(argmin[:, 2].cpu().long(), ref["rmse_argmin"])
+    s = sums.cpu()
+    assert abs(s[2].item() - ref["ade_sum"]) / ref["ade_sum"] < 1e-5
+    assert abs(s[3].item() - ref["fde_sum"]) / ref["fde_sum"] < 1e-5
+    assert abs(s[4].item() - ref["rmse_sum"]) / ref["rmse_sum"] < 1e-5
+
+
+def test_ade_fde_parity_on_fixed_seed_batch(gpu):
+    """ADE/FDE of the HIP path vs the oracle on a seeded synthetic batch at a mid-size shape."""
+    from oracle import forward as O
+    from tcavt_amd import config, ops, synth
+    from tcavt_amd.weights import make_weights
+
+    cfg = config.midi(seq_len=18, out_len=30)
+    weights = make_weights(cfg, 21)
+    b = synth.make_batch(cfg, 8, text_len=112, seed=21, ragged=True, min_text=40)
+    t = {k: torch.from_numpy(v) for k, v in b.items()}
+    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"])
+    with torch.no_grad():
+        dec16 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                                t["input_ids"], t["attention_mask"], contract="bf16")
+        dec32 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                                t["input_ids"], t["attention_mask"], contract="fp32")
+    dev = gpu["device"]
+    sums = torch.zeros(5, device=dev)
+    ops.traj_metrics(decoded, t["target_traj"].to(dev), t["norm_stat"].to(dev), sums, None, None, 8, 1, cfg.out_len)
+    r16 = O.traj_metrics(dec16, t["target_traj"], t["norm_stat"])
+    r32 = O.traj_metrics(dec32, t["target_traj"], t["norm_stat"])
+    ade, fde = sums[2].item() / 8, sums[3].item() / 8
+    print(f"[ADE/FDE] hip {ade:.4f}/{fde:.4f}  oracle-bf16 {r16['ade_sum']/8:.4f}/{r16['fde_sum']/8:.4f}  "
+          f"oracle-fp32 {r32['ade_sum']/8:.4f}/{r32['fde_sum']/8:.4f}")
+    assert abs(ade - r16["ade_sum"] / 8) / (r16["ade_sum"] / 8) < 1e-3
+    assert abs(fde - r16["fde_sum"] / 8) / (r16["fde_sum"] / 8) < 1e-3
+    assert abs(ade - r32["ade_sum"] / 8) / (r32["ade_sum"] / 8) < 3e-3
+    assert abs(fde - r32["fde_sum"] / 8) / (r32["fde_sum"] / 8) < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# stage-level parity from IDENTICAL inputs: this is where "<= 1e-3 vs the bf16 contract" is a
+# well-posed requirement (no cross-stage amplification of summation-order noise)
+# ---------------------------------------------------------------------------------------------
+def _tiny_model(dev, layers, lora=True, seed=5, q_layers=4):
+    import dataclasses
+
+    from tcavt_amd import config, model
+    from tcavt_amd.weights import make_weights
+
+    cfg = config.tiny(use_lora=lora)
+    cfg = dataclasses.replace(cfg, llama=dataclasses.replace(cfg.llama, layers=layers), q_enc_layers=q_layers,
+                              q_dec_layers=q_layers)
+    weights = make_weights(cfg, seed)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    return cfg, weights, m
+
+
+@pytest.mark.parametrize("lora", [True, False])
+def test_stage_one_decoder_layer(gpu, lora):
+    """RMSNorm -> QKV(+LoRA)+RoPE -> causal GQA attention -> o_proj -> RMSNorm -> SiLU-MLP -> final norm,
+    one layer, from the same embeddings, ragged right padding."""
+    from oracle import forward as O
+
+    dev = gpu["device"]
+    cfg, weights, m = _tiny_model(dev, layers=1, lora=lora)
+    g = torch.Generator().manual_seed(3)
+    B, L, H = 3, 96, cfg.llama.hidden
+    emb = torch.randn(B, L, H, generator=g)
+    mask = torch.ones(B, L, dtype=torch.int64)
+    mask[1, 70:] = 0
+    mask[2, 33:] = 0
+    with torch.no_grad():
+        out = m.mllm.llama_wrapper(emb.to(dev), mask.to(dev), output_hidden_states=True).hidden_states[-1].cpu()
+        W = O.as_torch(weights)
+        ref16 = O.llama_decoder(W, cfg, emb, mask, O._rounder("bf16"))
+        ref32 = O.llama_decoder(W, cfg, emb, mask, O._rounder("fp32"))
+    e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
+    print(f"[stage decoder-layer lora={lora}] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    assert e16 < 1e-3
+    assert e32 <= 1.5 * o32 + 1e-3
+
+
+@pytest.mark.parametrize("depth", [1, 4])
+def test_stage_qformer(gpu, depth):
+    """depth=1: one encoder + one decoder layer (the 1e-3 bar); depth=4: the reference's 4+4 stack,
+    where summation-order noise compounds and only the contract-relative bar is well-posed."""
+    from oracle import forward as O
+
+    dev = gpu["device"]
+    cfg, weights, m = _tiny_model(dev, layers=1, q_layers=depth)
+    g = torch.Generator().manual_seed(4)
+    vis = torch.randn(4, cfg.seq_len, cfg.vision_dim, generator=g)
+    with torch.no_grad():
+        out = m.mllm.qformer(vis.to(dev)).cpu()
+        W = O.as_torch(weights)
+        ref16 = O.qformer(W, cfg, vis, O._rounder("bf16"))
+        ref32 = O.qformer(W, cfg, vis, O._rounder("fp32"))
+    e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
+    print(f"[stage qformer depth={depth}] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    if depth == 1:
+        assert e16 < 1e-3
+    assert e32 <= 1.5 * o32 + 1e-3
+
+
+def test_stage_ltsf_head(gpu):
+    """TransformerLTSF incl. the head_dim-H/2 cross-attention over given final hidden states."""
+    from oracle import forward as O
+
+    dev = gpu["device"]
+    cfg, weights, m = _tiny_model(dev, layers=1)
+    g = torch.Generator().manual_seed(6)
+    B, L, H = 5, 80, cfg.llama.hidden
+    x = torch.rand(B, 2, cfg.seq_len, generator=g)
+    poly = torch.randn(B, cfg.lane_polygon_d_model, generator=g)
+    fh = torch.randn(B, L, H, generator=g)
+    with torch.no_grad():
+        out = m.ltsf(x.to(dev), poly.to(dev), fh.to(dev)).cpu()
+        W = O.as_torch(weights)
+        ref16 = O.ltsf_forward(W, cfg, x, poly, fh, O._rounder("bf16"))
+        ref32 = O.ltsf_forward(W, cfg, x, poly, fh, O._rounder("fp32"))
+    e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
+    print(f"[stage ltsf] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    assert e16 < 1e-3
+    assert e32 <= 1.5 * o32 + 1e-3

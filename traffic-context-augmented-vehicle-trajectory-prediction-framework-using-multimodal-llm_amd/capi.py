@@ -40,6 +40,7 @@ class GemmArgs(ctypes.Structure):
         ("epilogue", ctypes.c_int32),
         ("rope_L", ctypes.c_int32), ("rope_cols", ctypes.c_int32),
         ("tile", ctypes.c_int32),
+        ("acc_scale", ctypes.c_float),
     ]
 
 
@@ -54,6 +55,7 @@ _SIGNATURES = {
     "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_void_p, c_void_p],
+    "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                   c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
@@ -66,7 +68,7 @@ _SIGNATURES = {
     "tcavt_ltsf_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_transpose_ct": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_out_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                       c_void_p],
+                       c_int, c_void_p],
     "tcavt_traj_metrics": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p],
 }

@@ -11,8 +11,13 @@
 //     Per 32-query block a wave walks the 32-key tiles up to the diagonal:
 //       S^T = K . Q^T        v_mfma_f32_32x32x16_bf16, key on the accumulator
 //                            row, query on the lane -> row softmax is lane-local
-//       O^T += V^T . P^T     the S^T accumulator, converted to bf16 in place, IS
-//                            the B operand (no LDS round trip for P)
+//       O^T += V^T . P^T     v_mfma_f32_32x32x16_f16: the S^T accumulator, converted
+//                            in place, IS the B operand (no LDS round trip for P).
+//                            P lives in [0,1], so it is carried as fp16 (11-bit
+//                            significand) rather than bf16 (8-bit): bf16 P alone costs
+//                            1.3e-3 relative on a decoder layer's output.  V (bf16 from
+//                            the QKV epilogue) converts to fp16 exactly (clamped to the
+//                            fp16 range) while it is transposed into LDS.
 //     Online softmax in fp32 (exp2 with log2e folded into the scale).
 //
 // (2) mha_small_kernel -- generic fp32-softmax multi-head attention for the short
@@ -22,10 +27,22 @@
 
 namespace tcavt {
 
-__device__ __forceinline__ bf16x8 cvt8(const float* v) {
-  u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-             pack_bf16x2(v[6], v[7])};
-  return __builtin_bit_cast(bf16x8, o);
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+__device__ __forceinline__ f16x8 cvt8_f16(const float* v) {
+  f16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = static_cast<_Float16>(v[i]);  // RNE
+  return o;
+}
+
+// two bf16 (same feature, keys r0 and r1) -> packed fp16 pair, clamped to the fp16 range
+__device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits, unsigned int k1_bits) {
+  const float a = fminf(fmaxf(__uint_as_float(k0_bits << 16), -65504.f), 65504.f);
+  const float b = fminf(fmaxf(__uint_as_float(k1_bits << 16), -65504.f), 65504.f);
+  const unsigned short ha = __builtin_bit_cast(unsigned short, static_cast<_Float16>(a));
+  const unsigned short hb = __builtin_bit_cast(unsigned short, static_cast<_Float16>(b));
+  return static_cast<unsigned int>(ha) | (static_cast<unsigned int>(hb) << 16);
 }
 
 __global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
@@ -61,8 +78,8 @@ __global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __re
     if (r1 < L) bb = *reinterpret_cast<const u32x4*>(base + (long)r1 * ld + voff + c * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const unsigned int lo = (a[e] & 0xffffu) | (bb[e] << 16);
-      const unsigned int hi = (a[e] >> 16) | (bb[e] & 0xffff0000u);
+      const unsigned int lo = bf16pair_to_f16pair(a[e] & 0xffffu, bb[e] & 0xffffu);
+      const unsigned int hi = bf16pair_to_f16pair(a[e] >> 16, bb[e] >> 16);
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e) * vstride + r0) = lo;
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e + 1) * vstride + r0) = hi;
     }
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __re
       // O^T += V^T . P^T  (two 16-key k-steps; P registers 8*s2.. are the B operand)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = cvt8(&p[8 * s2]);
+        const f16x8 pf = cvt8_f16(&p[8 * s2]);
         const int kbase = kt * 32 + 16 * s2 + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -135,9 +152,9 @@ __global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __re
           const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow);
           const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + 8);
           const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-          if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+          const f16x8 vf = __builtin_bit_cast(f16x8, vv);
+          if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
+          else o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
         }
       }
     }

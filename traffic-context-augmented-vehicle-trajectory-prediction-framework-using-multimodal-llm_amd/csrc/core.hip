@@ -192,9 +192,36 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
   }
 }
 
+// kv_len[b] = Nq + popcount(mask[b]); flags masks that are not a prefix of ones.
+__global__ __launch_bounds__(64) void mask_to_kvlen_kernel(const int64_t* __restrict__ mask, int Lt, int Nq,
+                                                           int* __restrict__ kv_len, int* __restrict__ flag) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float cnt = 0.f, bad = 0.f;
+  for (int j = lane; j < Lt; j += 64) {
+    const bool on = mask[(long)b * Lt + j] != 0;
+    cnt += on ? 1.f : 0.f;
+    if (on && j > 0 && mask[(long)b * Lt + j - 1] == 0) bad += 1.f;
+  }
+  cnt = wave_sum(cnt);
+  bad = wave_sum(bad);
+  if (lane == 0) {
+    kv_len[b] = Nq + (int)cnt;
+    if (bad > 0.f) *flag = 1;
+  }
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
+
+extern "C" int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_len,
+                                   int* not_prefix_flag, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(mask && kv_len && not_prefix_flag && B > 0 && Lt > 0 && Nq >= 0, "mask_to_kvlen: bad args");
+  hipLaunchKernelGGL(mask_to_kvlen_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), mask, Lt, Nq,
+                     kv_len, not_prefix_flag);
+  TCAVT_CHECK_LAUNCH("mask_to_kvlen");
+  return TCAVT_OK;
+}
 
 extern "C" int tcavt_abi_version(void) { return TCAVT_ABI_VERSION; }
 

@@ -38,6 +38,7 @@ struct GemmP {
   int M, N, K, K2;
   int out_bf16, flags, rope_L, rope_cols;
   int tiles_m, tiles_n;
+  float acc_scale;
 };
 
 enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2 };
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
       for (int i = 0; i < TN; ++i) {
         const int n = n0 + wn * WTN + i * 16 + nq;
         if (n >= p.N) continue;
-        f32x4 v = acc[i][j];
+        f32x4 v = acc[i][j] * p.acc_scale;
         if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         if (p.flags & TCAVT_EPI_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
       if (m >= p.M) continue;
 #pragma unroll
       for (int i = 0; i < TN; i += 2) {
+        if (n0 + wn * WTN + i * 16 >= p.N) continue;  // partial last tile column
         const int n = ((n0 + wn * WTN) >> 1) + (i >> 1) * 16 + nq;
         const f32x4 g = acc[i][j], u = acc[i + 1][j];
         f32x4 v;
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
 #pragma unroll
       for (int hh = 0; hh < TN / 4; ++hh) {
         const int nb = n0 + wn * WTN + hh * 64;
+        if (nb >= p.N) continue;  // partial last tile column (N % BN != 0)
         const bool rot = nb < p.rope_cols;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -330,6 +333,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.flags = epi;
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
   p.tiles_m = p.tiles_n = 0;
+  p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale;
+  if (epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE))
+    TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
 
   int tile = a->tile;
   if (tile == 0) {

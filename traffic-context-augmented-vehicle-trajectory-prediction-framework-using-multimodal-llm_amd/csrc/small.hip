@@ -152,14 +152,14 @@ __global__ void transpose_ct_kernel(const float* __restrict__ in, float* __restr
 // out[b][f][s] = w[f] . fused[b][s] + bias[f] + x[b][f][T-1]   (train.py:804-805,941-943)
 __global__ void out_head_kernel(const float* __restrict__ fused, const float* __restrict__ w,
                                 const float* __restrict__ bias, const float* __restrict__ x,
-                                float* __restrict__ out, int B, int To, int C, int F, int T) {
+                                float* __restrict__ out, int B, int To, int C, int F, int T, int add_last) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * F * To) return;
   const int s = idx % To, f = (idx / To) % F, b = idx / (To * F);
   const float* fr = fused + ((long)b * To + s) * C;
   float acc = 0.f;
   for (int c = 0; c < C; ++c) acc = fmaf(w[f * C + c], fr[c], acc);
-  out[idx] = acc + bias[f] + x[((long)b * F + f) * T + T - 1];
+  out[idx] = acc + bias[f] + (add_last ? x[((long)b * F + f) * T + T - 1] : 0.f);
 }
 
 // ---------------------------------------------------------------------------
@@ -287,12 +287,13 @@ extern "C" int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf1
 }
 
 extern "C" int tcavt_out_head(const float* fused, const float* w, const float* bias, const float* x,
-                              float* out, int B, int To, int C, int F, int T, tcavt_stream_t stream) {
+                              float* out, int B, int To, int C, int F, int T, int add_last,
+                              tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(fused && w && bias && x && out && B > 0 && To > 0 && C > 0 && F > 0 && T > 0,
                   "out_head: bad args");
   const int n = B * F * To;
   hipLaunchKernelGGL(out_head_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     fused, w, bias, x, out, B, To, C, F, T);
+                     fused, w, bias, x, out, B, To, C, F, T, add_last);
   TCAVT_CHECK_LAUNCH("out_head");
   return TCAVT_OK;
 }

@@ -12,15 +12,18 @@ from . import capi
 from .capi import BF16, EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_ROPE, EPI_SILU_MUL, F32, check, lib, ptr, stream_ptr
 
 __all__ = [
-    "gemm_bf16", "rmsnorm", "layernorm", "cast_bf16", "embed_fuse", "attn_causal_gqa", "mha", "gemm_f32",
+    "gemm_bf16", "rmsnorm", "layernorm", "cast_bf16", "embed_fuse", "mask_to_kvlen", "attn_causal_gqa", "mha", "gemm_f32",
     "poly_embed", "masked_mean", "ltsf_front", "ltsf_decode", "transpose_ct", "out_head", "traj_metrics",
 ]
+
+
+_ALLOW_CPU = False  # tests only: host-logic dry run with a stubbed library (tests/test_host_dryrun.py)
 
 
 def _req(t, dtype, name):
     if t is None:
         return
-    if not t.is_cuda:
+    if not t.is_cuda and not _ALLOW_CPU:
         raise capi.TcavtError(f"{name}: tensor must live on the GPU (no CPU fallback)")
     if t.dtype != dtype:
         raise capi.TcavtError(f"{name}: expected {dtype}, got {t.dtype}")
@@ -28,8 +31,14 @@ def _req(t, dtype, name):
         raise capi.TcavtError(f"{name}: tensor must be contiguous")
 
 
+def _need(t, numel, name):
+    """Host-side guard: the buffer must hold at least what the kernel's grid will touch."""
+    if t is not None and t.numel() < numel:
+        raise capi.TcavtError(f"{name}: buffer has {t.numel()} elements, kernel needs {numel}")
+
+
 def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False, residual=None, a2=None,
-              w2=None, silu_mul=False, rope=None, tile=0):
+              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0):
     """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K] bf16, w [N,K] bf16.
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
@@ -73,10 +82,19 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
         args.rope_cos, args.rope_sin = cos.data_ptr(), sin.data_ptr()
         args.rope_L, args.rope_cols = cos.shape[0], cols
         epi |= EPI_ROPE
+    if out.shape[0] < M or out.shape[1] < n_out:
+        raise capi.TcavtError(f"gemm_bf16.out: shape {tuple(out.shape)} smaller than ({M}, {n_out})")
+    if a2 is not None and (a2.shape[0] < M or w2.shape[0] < N or w2.shape[1] != a2.shape[1]):
+        raise capi.TcavtError("gemm_bf16: a2/w2 shapes do not match (M, K2) / (N, K2)")
+    if bias is not None:
+        _need(bias, N, "gemm_bf16.bias")
+    if residual is not None and (residual.shape[0] < M or residual.shape[1] < N):
+        raise capi.TcavtError("gemm_bf16.residual: smaller than (M, N)")
     args.M, args.N, args.K = M, N, K
     args.out_dtype = BF16 if out.dtype == torch.bfloat16 else F32
     args.epilogue = epi
     args.tile = tile
+    args.acc_scale = acc_scale
     check(lib().tcavt_gemm_bf16(ctypes.byref(args), stream_ptr()), "tcavt_gemm_bf16")
     return out
 
@@ -85,6 +103,9 @@ def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None):
     _req(x, torch.float32, "rmsnorm.x")
     _req(gamma, torch.float32, "rmsnorm.gamma")
     M, H = x.shape
+    _need(gamma, H, "rmsnorm.gamma")
+    _need(out_bf16, M * H, "rmsnorm.out_bf16")
+    _need(out_f32, M * H, "rmsnorm.out_f32")
     check(lib().tcavt_rmsnorm(ptr(x), ptr(gamma), eps, ptr(out_bf16), ptr(out_f32), M, H, stream_ptr()),
           "tcavt_rmsnorm")
 
@@ -93,6 +114,9 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out_f32=None, out_bf16=No
     _req(x, torch.float32, "layernorm.x")
     _req(residual, torch.float32, "layernorm.residual")
     M, D = x.shape
+    for t, n, nm in ((gamma, D, "gamma"), (beta, D, "beta"), (residual, M * D, "residual"), (out_f32, M * D, "out_f32"),
+                     (out_bf16, M * D, "out_bf16")):
+        _need(t, n, "layernorm." + nm)
     check(lib().tcavt_layernorm(ptr(x), ptr(residual), ptr(gamma), ptr(beta), eps, ptr(out_f32), ptr(out_bf16), M,
                                 D, stream_ptr()), "tcavt_layernorm")
 
@@ -110,16 +134,33 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag):
     _req(ids, torch.int64, "embed.ids")
     _req(img, torch.float32, "embed.img")
     B, Lt = ids.shape
-    Nq = img.shape[1]
     V, H = table.shape
+    Nq = img.numel() // (B * H)
+    _need(img, B * Nq * H, "embed.img")
+    _need(h, B * (Nq + Lt) * H, "embed.h")
+    _need(vis_mod, H, "embed.vis_mod")
+    _need(txt_mod, H, "embed.txt_mod")
+    _need(bad_flag, 1, "embed.bad_flag")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
                                  V, ptr(bad_flag), stream_ptr()), "tcavt_embed_fuse")
+
+
+def mask_to_kvlen(mask, Nq, kv_len, flag):
+    _req(mask, torch.int64, "mask_to_kvlen.mask")
+    B, Lt = mask.shape
+    _need(kv_len, B, "mask_to_kvlen.kv_len")
+    _need(flag, 1, "mask_to_kvlen.flag")
+    check(lib().tcavt_mask_to_kvlen(ptr(mask), B, Lt, Nq, ptr(kv_len), ptr(flag), stream_ptr()),
+          "tcavt_mask_to_kvlen")
 
 
 def attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, scale):
     _req(qkv, torch.bfloat16, "attn.qkv")
     _req(out, torch.bfloat16, "attn.out")
     _req(kv_len, torch.int32, "attn.kv_len")
+    _need(qkv, B * L * (nq + 2 * nkv) * 64, "attn.qkv")
+    _need(out, B * L * nq * 64, "attn.out")
+    _need(kv_len, B, "attn.kv_len")
     check(lib().tcavt_attn_causal_gqa(ptr(qkv), ptr(out), ptr(kv_len), B, L, nq, nkv, scale, stream_ptr()),
           "tcavt_attn_causal_gqa")
 
@@ -128,6 +169,17 @@ def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None
     """q/k/v may be column slices of wider row-major buffers: pass the slice's data_ptr tensor and ld."""
     in_dt = BF16 if q.dtype == torch.bfloat16 else F32
     out_dt = BF16 if out.dtype == torch.bfloat16 else F32
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise capi.TcavtError("mha: q, k, v must share a dtype")
+    lq, lk, lv, lo = (ldq or q.stride(-2)), (ldk or k.stride(-2)), (ldv or v.stride(-2)), (ldo or out.stride(-2))
+    E = nh * dh
+    for t, rows, ld, nm in ((q, B * Lq, lq, "q"), (k, B * Lk, lk, "k"), (v, B * Lk, lv, "v"), (out, B * Lq, lo, "out")):
+        if ld < E:
+            raise capi.TcavtError(f"mha.{nm}: leading dimension {ld} < nh*dh = {E}")
+        avail = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+        if avail < (rows - 1) * ld + E:
+            raise capi.TcavtError(f"mha.{nm}: buffer too small for {rows} rows of stride {ld}")
+    _need(key_len, B, "mha.key_len")
     check(lib().tcavt_mha(ptr(q), ldq if ldq else q.stride(-2), ptr(k), ldk if ldk else k.stride(-2), ptr(v),
                           ldv if ldv else v.stride(-2), ptr(out), ldo if ldo else out.stride(-2), ptr(key_len), B,
                           Lq, Lk, nh, dh, scale, in_dt, out_dt, stream_ptr()), "tcavt_mha")
@@ -142,6 +194,12 @@ def gemm_f32(a, w, out=None, bias=None, relu=False, residual=None):
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (
         EPI_RESIDUAL if residual is not None else 0)
+    if w.shape[1] != K or out.shape[0] < M or out.shape[1] < N:
+        raise capi.TcavtError(f"gemm_f32: shape mismatch a{tuple(a.shape)} w{tuple(w.shape)} out{tuple(out.shape)}")
+    if bias is not None:
+        _need(bias, N, "gemm_f32.bias")
+    if residual is not None and (residual.shape[0] < M or residual.shape[1] < N):
+        raise capi.TcavtError("gemm_f32.residual: smaller than (M, N)")
     check(lib().tcavt_gemm_f32(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
                                residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), M, N, K,
                                flags, stream_ptr()), "tcavt_gemm_f32")
@@ -151,34 +209,54 @@ def gemm_f32(a, w, out=None, bias=None, relu=False, residual=None):
 def poly_embed(polygon, w_in, b_in, pos, out):
     B, P, _ = polygon.shape
     D = w_in.shape[0]
+    _need(pos, P * D, "poly_embed.pos")
+    _need(out, B * P * D, "poly_embed.out")
     check(lib().tcavt_poly_embed(ptr(polygon), ptr(w_in), ptr(b_in), ptr(pos), ptr(out), B, P, D, stream_ptr()),
           "tcavt_poly_embed")
 
 
 def masked_mean(enc, lens, out, B, P, D):
+    _need(enc, B * P * D, "masked_mean.enc")
+    _need(lens, B, "masked_mean.lens")
+    _need(out, B * D, "masked_mean.out")
     check(lib().tcavt_masked_mean(ptr(enc), ptr(lens), ptr(out), B, P, D, stream_ptr()), "tcavt_masked_mean")
 
 
 def ltsf_front(x, conv_w, conv_b, enc_w, enc_b, pos, out, B, C, T):
+    for t, n, nm in ((x, B * 2 * T, "x"), (conv_w, C * 2, "conv_w"), (conv_b, C, "conv_b"), (enc_w, C * T * T, "enc_w"),
+                     (enc_b, C * T, "enc_b"), (pos, C * T, "pos"), (out, B * T * C, "out")):
+        _need(t, n, "ltsf_front." + nm)
     check(lib().tcavt_ltsf_front(ptr(x), ptr(conv_w), ptr(conv_b), ptr(enc_w), ptr(enc_b), ptr(pos), ptr(out), B, C,
                                  T, stream_ptr()), "tcavt_ltsf_front")
 
 
 def ltsf_decode(e_tok, dec_w, dec_b, lane_adj, out, B, C, T, To):
+    for t, n, nm in ((e_tok, B * T * C, "e_tok"), (dec_w, C * To * T, "dec_w"), (dec_b, C * To, "dec_b"),
+                     (lane_adj, B * C * To, "lane_adj"), (out, B * C * To, "out")):
+        _need(t, n, "ltsf_decode." + nm)
     check(lib().tcavt_ltsf_decode(ptr(e_tok), ptr(dec_w), ptr(dec_b), ptr(lane_adj), ptr(out), B, C, T, To,
                                   stream_ptr()), "tcavt_ltsf_decode")
 
 
 def transpose_ct(x, out_f32, out_bf16, B, C, To):
+    for t, nm in ((x, "x"), (out_f32, "out_f32"), (out_bf16, "out_bf16")):
+        _need(t, B * C * To, "transpose_ct." + nm)
     check(lib().tcavt_transpose_ct(ptr(x), ptr(out_f32), ptr(out_bf16), B, C, To, stream_ptr()),
           "tcavt_transpose_ct")
 
 
-def out_head(fused, w, bias, x, out, B, To, C, F, T):
-    check(lib().tcavt_out_head(ptr(fused), ptr(w), ptr(bias), ptr(x), ptr(out), B, To, C, F, T, stream_ptr()),
+def out_head(fused, w, bias, x, out, B, To, C, F, T, add_last=True):
+    for t, n, nm in ((fused, B * To * C, "fused"), (w, F * C, "w"), (bias, F, "bias"), (x, B * F * T, "x"),
+                     (out, B * F * To, "out")):
+        _need(t, n, "out_head." + nm)
+    check(lib().tcavt_out_head(ptr(fused), ptr(w), ptr(bias), ptr(x), ptr(out), B, To, C, F, T, int(add_last),
+                               stream_ptr()),
           "tcavt_out_head")
 
 
 def traj_metrics(pred, gt, norm_stat, sums, argmin, per_sample, B, K, To):
+    for t, n, nm in ((pred, B * K * 2 * To, "pred"), (gt, B * 2 * To, "gt"), (norm_stat, B * 4, "norm_stat"),
+                     (sums, 5, "sums"), (argmin, B * 3, "argmin"), (per_sample, B * 3, "per_sample")):
+        _need(t, n, "traj_metrics." + nm)
     check(lib().tcavt_traj_metrics(ptr(pred), ptr(gt), ptr(norm_stat), ptr(sums), ptr(argmin), ptr(per_sample), B,
                                    K, To, stream_ptr()), "tcavt_traj_metrics")
