@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Headline benchmark: trajectories/sec of the multimodal-LLM trajectory-prediction hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`,
+     one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment)
+
+Workload (BASELINE.json configs[1], "train.py multimodal-LLM, 1xMI355X bf16, batch 32, LoRA rank
+8, seq_len 256"): one step = one pass of MultiModalTrajectoryModel.forward (reference
+scripts/train.py:914-964, loss included) over one batch of 32 synthetic samples per GPU with
+fused LLM length L = 16 query tokens + 240 text tokens = 256, T_in/T_out = 18/30, Llama-3.2-1B
+shape (16 layers, hidden 2048, 32/8 heads x 64, MLP 8192, vocab 128256), LoRA r=8 alpha=32 on
+q_proj/v_proj, random-init weights, inputs resident in HBM before the timed region.
+Data parallel: every rank runs the same step on its own shard of the global batch (weak scaling);
+the forward has no data-path collective.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     -- dominant kernel (gate|up projection GEMM with SiLU*up epilogue), timed in situ with
+                  HIP events on the launching stream during the timed steps
+  cpu_baseline -- the CPU oracle (oracle/forward.py, "port") on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_SAMPLE = 509.8  # forward, L=256, 18->30
+ATTN_MB_PER_SAMPLE = 41.9  # q,k,v in + o out, 16 layers, bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--text-len", type=int, default=240)
+    ap.add_argument("--seq-len", type=int, default=18)
+    ap.add_argument("--out-len", type=int, default=30)
+    ap.add_argument("--preset", default="llama32_1b")
+    ap.add_argument("--no-lora", action="store_true")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    return ap.parse_args()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use (affinity / cgroup share), capped at the box's 16-core share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("TCAVT_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(cfg, args):
+    """Oracle ("port") on the host cores: B=cpu_batch samples of the same workload, fp32."""
+    from oracle import forward as O
+    from tcavt_amd import synth
+    from tcavt_amd.weights import make_weights
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: generating fp32 weights on the host ({cores} threads)")
+    W = make_weights(cfg, seed=1, backend="torch", device="cpu")
+    log("cpu_baseline: timing the oracle")
+    b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True, min_text=128)
+    t = {k: torch.from_numpy(v) for k, v in b.items()}
+
+    def run(labels):
+        with torch.no_grad():
+            return O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                                   t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
+                                   contract="fp32", labels=labels)
+
+    def timed(labels, n):
+        run(labels)  # warm
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            run(labels)
+            ts.append(time.perf_counter() - t0)
+            log(f"cpu_baseline: {'faithful' if labels is not None else 'same-work'} pass {ts[-1]:.2f} s")
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    same_work = timed(None, 3)
+    faithful = timed(t["labels"], 2)
+    return {
+        "value": round(args.cpu_batch / same_work, 4), "unit": "trajectories/sec", "cores": cores, "kind": "port",
+        "sample": f"{args.cpu_batch} samples of the same workload (L={16 + args.text_len}, fp32, torch CPU ops), "
+                  f"median of 3 after 1 warm-up; same work as the GPU path (no lm_head/CE)",
+        "reference_faithful_value": round(args.cpu_batch / faithful, 4),
+        "reference_faithful_note": "adds the lm_head + cross-entropy the reference computes and discards (train.py:547-554)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from tcavt_amd import capi, config, model, synth
+    from tcavt_amd.profiling import KernelTimer
+    from tcavt_amd.weights import make_weights
+
+    capi.init(local_rank)
+    cfg = config.PRESETS[args.preset](seq_len=args.seq_len, out_len=args.out_len, use_lora=not args.no_lora)
+    B, L = args.batch, cfg.q_num_query_tokens + args.text_len
+
+    t0 = time.time()
+    log(f"building {args.preset} model on {dev}")
+    with torch.device(dev):
+        m = model.MultiModalTrajectoryModel.from_config(cfg)
+    W = make_weights(cfg, seed=1, backend="torch", device=dev)
+    m.load_weights(W)
+    del W
+    m.eval()
+    m.mllm.llama_wrapper.gemm_tile = args.tile
+    torch.cuda.empty_cache()
+
+    # rank r works on its own shard of the global batch (seeded by rank): weak scaling
+    b = synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank, ragged=True, min_text=128)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+
+    def step():
+        return m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], y=g["target_traj"],
+                 norm_stat=g["norm_stat"], input_ids=g["input_ids"], attention_mask=g["attention_mask"],
+                 labels=g["labels"])
+
+    with torch.no_grad():
+        loss, decoded = step()  # builds packed weights + workspaces
+        torch.cuda.synchronize()
+        m.mllm.check_flags()
+        if not torch.isfinite(loss).item():
+            raise SystemExit("non-finite loss in warm-up")
+        setup_s = time.time() - t0
+        log(f"setup + first step done in {setup_s:.1f} s; loss {loss.item():.3f}")
+
+        graph = None
+        if not args.no_graph:
+            # hipGraph capture of the whole step (all launches are stream-ordered, allocation-free
+            # after the first call): removes per-launch host cost from the timed loop
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_loss, g_decoded = step()
+
+        def run_step():
+            if graph is not None:
+                graph.replay()
+            else:
+                step()
+
+        log("graph captured" if graph is not None else "eager mode")
+        for _ in range(args.warmup):
+            run_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
+
+        # in-situ kernel timing (eager launches so the event records sit between the kernels)
+        timer = KernelTimer()
+        m.mllm.llama_wrapper.timer = timer
+        for _ in range(max(2, min(5, args.steps))):
+            step()
+        torch.cuda.synchronize()
+        m.mllm.llama_wrapper.timer = None
+        ksum = timer.summary()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    ll = cfg.llama
+    M = B * L
+    gu_ms = ksum["gateup"][1]
+    gu_flops = 2.0 * M * (2 * ll.inter) * ll.hidden
+    gu_tflops = gu_flops / (gu_ms * 1e-3) / 1e12
+    attn_ms = ksum["attn"][1]
+    attn_bytes = B * ATTN_MB_PER_SAMPLE * 1e6 / ll.layers
+    kernels = {}
+    for name, n_, k_ in (("qkv", (ll.n_q_heads + 2 * ll.n_kv_heads) * ll.head_dim, ll.hidden),
+                         ("o", ll.hidden, ll.n_q_heads * ll.head_dim), ("gateup", 2 * ll.inter, ll.hidden),
+                         ("down", ll.hidden, ll.inter)):
+        ms = ksum[name][1]
+        kernels[name] = {"avg_us": round(ms * 1e3, 1), "tflops": round(2.0 * M * n_ * k_ / (ms * 1e-3) / 1e12, 1)}
+    kernels["attn"] = {"avg_us": round(attn_ms * 1e3, 1), "algorithmic_GBps": round(attn_bytes / (attn_ms * 1e-3) / 1e9, 1),
+                       "hbm_frac": round(attn_bytes / (attn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        out = {
+            "metric": "trajectories/sec", "value": round(value, 2), "unit": "trajectories/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": "MultiModalTrajectoryModel.forward incl. loss (train.py:914-964), eval arithmetic; "
+                            "Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head",
+                "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
+                "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",
+                "launch": "eager" if graph is None else "hipGraph replay",
+            },
+            "achieved_model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 1),
+            "roofline": {
+                "kernel": "gemm_bf16_kernel<256,256,2,4,SILU> (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
+                "bound": "mfma", "achieved": round(gu_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(gu_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_timed": ksum["gateup"][0], "avg_launch_us": round(gu_ms * 1e3, 1),
+            },
+            "kernels": kernels,
+            "setup_s": round(setup_s, 1),
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, args) if args.gpus == 1 or world == 1 else None
+            if out["cpu_baseline"]:
+                out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

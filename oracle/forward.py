@@ -227,7 +227,23 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None):
 # --------------------------------------------------------------------------------------
 # A4/A5: LlamaMultiModal.forward, ids branch (train.py:516-554)
 # --------------------------------------------------------------------------------------
-def mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect=None):
+def lm_head_and_loss(W, final_hidden, fused_labels):
+    """The part of the reference's LLM call whose results it discards (train.py:547-554 keeps only
+    hidden_states[-1]): lm_head (tied to embed_tokens) + shifted cross-entropy with ignore_index -100
+    (HF LlamaForCausalLM.forward with labels).  Only bench.py's reference-faithful CPU timing runs it."""
+    logits = final_hidden @ W["mllm.llama_wrapper.llama_model.lm_head.weight"].T
+    shift_logits = logits[:, :-1].reshape(-1, logits.shape[-1])
+    shift_labels = fused_labels[:, 1:].reshape(-1)
+    return F.cross_entropy(shift_logits, shift_labels, ignore_index=-100)
+
+
+def mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect=None, labels=None):
+    """labels given => also run the reference's discarded lm_head + CE (timing fidelity only)."""
+    if labels is not None:
+        final = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect)
+        fused = torch.cat([torch.full((labels.shape[0], cfg.q_num_query_tokens), -100, dtype=labels.dtype), labels], 1)
+        lm_head_and_loss(W, final, fused)
+        return final
     img = linear(qformer(W, cfg, vision, r), W, "mllm.q_proj", r)
     img = img + W["mllm.vision_modality_embedding"]
     txt = r(W[LLAMA + "embed_tokens.weight"])[input_ids] + W["mllm.text_modality_embedding"]
@@ -304,13 +320,14 @@ def denorm(t, norm_stat):
 
 
 def model_forward(W, cfg, x, vision, polygon, polygon_len, input_ids, attention_mask, y=None, norm_stat=None,
-                  contract="fp32", extras=None):
+                  contract="fp32", extras=None, labels=None):
     """Returns decoded [B,2,To] or (loss, decoded) like the reference.  `extras` (dict) receives
-    intermediate tensors (poly_emb, final_hidden) for stage-wise parity checks."""
+    intermediate tensors (poly_emb, final_hidden) for stage-wise parity checks.  `labels` switches
+    on the reference's discarded lm_head + CE work (see lm_head_and_loss)."""
     r = _rounder(contract)
     W = as_torch(W)
     poly_emb = lane_polygon_encoder(W, cfg, polygon, polygon_len)
-    final_hidden = mllm_forward(W, cfg, vision, input_ids, attention_mask, r)
+    final_hidden = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, labels=labels)
     decoded = ltsf_forward(W, cfg, x, poly_emb, final_hidden, r)
     decoded = decoded + x[:, :, -1:]
     if extras is not None:

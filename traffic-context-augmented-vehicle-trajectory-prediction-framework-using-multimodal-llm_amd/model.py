@@ -372,6 +372,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self.config = self.llama_model.config
         self.hidden_size = self.shape.hidden
         self.gemm_tile = 0
+        self.timer = None  # optional profiling.KernelTimer (bench.py roofline leg)
         self._ws = _Workspace()
         self._prep = None
         self._rope = {}
@@ -426,18 +427,33 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         t = ws.get("ll.lora_t", (M, 64), torch.bfloat16, dev) if self.use_lora else None
         scale = 1.0 / math.sqrt(hd)
         tile = self.gemm_tile
+        tm = self.timer
+        mark = (lambda n: tm.start(n)) if tm else (lambda n: None)
+        done = (lambda n: tm.stop(n)) if tm else (lambda n: None)
         for d in P.layers:
             ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
             if self.use_lora:
                 ops.gemm_bf16(xn, d.a_cat, out=t, acc_scale=self.lora_alpha / self.lora_r, tile=128)
+                mark("qkv")
                 ops.gemm_bf16(xn, d.w_qkv, out=qkv, a2=t, w2=d.b_ext, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
+                done("qkv")
             else:
+                mark("qkv")
                 ops.gemm_bf16(xn, d.w_qkv, out=qkv, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
+                done("qkv")
+            mark("attn")
             ops.attn_causal_gqa(qkv, att, kv_len, B, L, nq, nkv, scale)
+            done("attn")
+            mark("o")
             ops.gemm_bf16(att, d.w_o, out=h, residual=h, tile=tile)
+            done("o")
             ops.rmsnorm(h, d.g2, ll.rms_eps, out_bf16=xn)
+            mark("gateup")
             ops.gemm_bf16(xn, d.w_gu, out=act, silu_mul=True, tile=tile)
+            done("gateup")
+            mark("down")
             ops.gemm_bf16(act, d.w_d, out=h, residual=h, tile=tile)
+            done("down")
         ops.rmsnorm(h, P.g_final, ll.rms_eps, out_bf16=out_bf16, out_f32=out_f32)
 
     def forward(self, inputs_embeds, attention_mask, labels=None, output_hidden_states=False):

@@ -33,13 +33,26 @@ def _rng(seed, name):
 
 
 class _Gen:
-    def __init__(self, seed):
+    """backend "numpy": machine-independent PCG64 streams (fixtures, parity tests).
+    backend "torch": torch.randn on `device` (fast init of the 1.2 B-parameter bench model; same
+    scales, different stream -- never used where values are compared against fixtures)."""
+
+    def __init__(self, seed, backend="numpy", device=None):
         self.seed = seed
         self.out = {}
+        self.backend, self.device = backend, device
 
     def normal(self, name, shape, std, mean=0.0):
-        a = _rng(self.seed, name).standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)
-        self.out[name] = a.astype(np.float32)
+        if self.backend == "numpy":
+            a = _rng(self.seed, name).standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)
+            self.out[name] = a.astype(np.float32)
+        else:
+            import torch
+
+            g = torch.Generator(device=self.device)
+            g.manual_seed((int(self.seed) << 32) ^ zlib.crc32(name.encode()))
+            t = torch.randn(tuple(shape), generator=g, device=self.device, dtype=torch.float32)
+            self.out[name] = t.mul_(float(std)).add_(float(mean))
 
     def linear(self, prefix, n_out, n_in, bias=True, gain=0.7):
         self.normal(prefix + ".weight", (n_out, n_in), gain / np.sqrt(n_in))
@@ -72,9 +85,9 @@ class _Gen:
         self.layernorm(prefix + ".norm3", d)
 
 
-def make_weights(cfg: ModelConfig, seed: int = 0):
-    """Return {state-dict key: float32 ndarray} for the whole model."""
-    g = _Gen(seed)
+def make_weights(cfg: ModelConfig, seed: int = 0, backend: str = "numpy", device=None):
+    """Return {state-dict key: float32 ndarray (numpy backend) or tensor (torch backend)}."""
+    g = _Gen(seed, backend, device)
     ll = cfg.llama
     H = ll.hidden
     d = cfg.d_model
