@@ -39,6 +39,7 @@ typedef void* tcavt_stream_t; /* hipStream_t */
 
 #define TCAVT_F32 0
 #define TCAVT_BF16 1
+#define TCAVT_F16 2
 
 int tcavt_abi_version(void);
 const char* tcavt_last_error(void);
@@ -67,6 +68,7 @@ int tcavt_init(int device, int* num_cus);
  *   ROPE      rotary embedding (half-split convention, head_dim 64) applied to
  *             columns [0, rope_cols) with position = m % rope_L, cos/sin tables
  *             [rope_L][32] fp32 (modeling_llama.py:113-160)
+ * out_dtype may be TCAVT_F32, TCAVT_BF16 or TCAVT_F16.
  * Constraints: K % 64 == 0, K2 % 64 == 0, N % 16 == 0, ld* % 8 == 0,
  *              16-byte aligned base pointers; SILU_MUL/ROPE need N % 128 == 0.
  * ---------------------------------------------------------------------- */
@@ -75,6 +77,8 @@ int tcavt_init(int device, int* num_cus);
 #define TCAVT_EPI_RESIDUAL 4
 #define TCAVT_EPI_SILU_MUL 8
 #define TCAVT_EPI_ROPE 16
+#define TCAVT_EPI_BIAS_ROW 32 /* acc += bias[m] (bias per output ROW; used when the roles of
+                                 activations and weights are swapped to emit a transposed result) */
 
 typedef struct tcavt_gemm_args {
   const void* A;   int64_t lda;  /* bf16 [M][K]  */
@@ -92,6 +96,14 @@ typedef struct tcavt_gemm_args {
   int32_t rope_L, rope_cols;
   int32_t tile;                  /* 0 = auto, 128 or 256 = force square tile */
   float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */
+  int32_t in_dtype;              /* operand type of A/W/A2/W2: 0 or TCAVT_BF16, or TCAVT_F16 (generic epilogue only) */
+  /* Batched form (generic epilogue only): batch > 1 runs `batch` independent products; product i uses
+   * A + (i / batch_inner) * sAo + (i % batch_inner) * sAi, likewise W and C (strides in ELEMENTS,
+   * every offset must keep 16-byte alignment).  bias / residual are shared by all products.
+   * This is how the per-(sample, head) products of the head_dim-1024 cross-attention
+   * (scripts/train.py:795-798) are issued: scores = q_bh . k_bh^T and out = p_bh . (v^T_bh)^T. */
+  int32_t batch, batch_inner;
+  int64_t sAo, sAi, sWo, sWi, sCo, sCi;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -153,6 +165,14 @@ int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_
  * ---------------------------------------------------------------------- */
 int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B,
                           int L, int nq, int nkv, float scale, tcavt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Row softmax for the batched cross-attention: P[r][c] = softmax_c(S[r][c]) over c < n_valid,
+ * P[r][c] = 0 for n_valid <= c < n_out.  S fp32 (ld lds), P fp16 or bf16 (ld ldp).
+ * (nn.MultiheadAttention's softmax, no mask: scripts/train.py:798.)
+ * ---------------------------------------------------------------------- */
+int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int out_dtype, int rows,
+                       int n_valid, int n_out, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Generic small multi-head attention, fp32 softmax (nn.MultiheadAttention

@@ -257,3 +257,60 @@ def test_gemm_f32(gpu, M, N, K):
     out = ops.gemm_f32(a, w, bias=bias, relu=True, residual=res)
     ref = torch.relu(a.double() @ w.double().T + bias.double()) + res.double()
     assert _rel(out, ref.float()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_batched_two_level_strides(gpu, dtype):
+    """Per-(sample, head) products with outer/inner strides, as the cross-attention issues them."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, nh, To, L, dh = 3, 2, 30, 96, 128
+    H = nh * dh
+    Lp = 128
+    q = torch.randn(B * To, H, generator=g).to(dtype).to(dev)
+    k = torch.zeros(B * L + 64, H, dtype=dtype, device=dev)
+    k[: B * L] = torch.randn(B * L, H, generator=g).to(dtype).to(dev)
+    S = torch.full((B * nh * To, Lp), float("nan"), device=dev)
+    ops.gemm_batched(q, k, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh, sA=(To * H, dh),
+                     sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=0.25)
+    qf = q.float().view(B, To, nh, dh).permute(0, 2, 1, 3)
+    kf = k[: B * L].float().view(B, L, nh, dh).permute(0, 2, 1, 3)
+    ref = 0.25 * (qf @ kf.transpose(-1, -2))  # [B,nh,To,L]
+    got = S.view(B, nh, To, Lp)[..., :L]
+    assert _rel(got, ref) < 2e-6
+
+
+def test_gemm_swapped_roles_bias_row_f16_out(gpu):
+    """V^T = W_v . X^T + b_v[:, None] per sample, fp16 output (transposed projection)."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(22)
+    B, L, H, Lp = 3, 40, 128, 64
+    x = torch.zeros(B * L + 64, H, dtype=torch.bfloat16, device=dev)
+    x[: B * L] = _bf(torch.randn(B * L, H, generator=g)).to(dev)
+    wv = _bf(torch.randn(H, H, generator=g) * 0.1).to(dev)
+    bv = torch.randn(H, generator=g).to(dev)
+    vT = torch.zeros(H, B * Lp, dtype=torch.float16, device=dev)
+    ops.gemm_batched(wv, x, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1, sA=(0, 0), sW=(L * H, 0),
+                     sC=(Lp, 0), bias_row=bv)
+    ref = (x[: B * L].float() @ wv.float().T + bv).view(B, L, H).permute(2, 0, 1)  # [H,B,L]
+    got = vT.view(H, B, Lp)[:, :, :L].float()
+    assert (got - ref.half().float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert _rel(got, ref) < 5e-4
+
+
+def test_softmax_rows(gpu):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(23)
+    rows, L, Lp = 50, 100, 128
+    S = (torch.randn(rows, Lp, generator=g) * 3).to(dev)
+    P = torch.full((rows, Lp), 7.0, dtype=torch.float16, device=dev)
+    ops.softmax_rows(S, P, rows, L, Lp, Lp, Lp)
+    ref = torch.softmax(S[:, :L], dim=-1)
+    assert (P[:, L:] == 0).all()
+    assert (P[:, :L].float() - ref).abs().max().item() < 1e-3

@@ -16,8 +16,8 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtcavt_hip.so")
 
-F32, BF16 = 0, 1
-EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE = 1, 2, 4, 8, 16
+F32, BF16, F16 = 0, 1, 2
+EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW = 1, 2, 4, 8, 16, 32
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -41,6 +41,9 @@ class GemmArgs(ctypes.Structure):
         ("rope_L", ctypes.c_int32), ("rope_cols", ctypes.c_int32),
         ("tile", ctypes.c_int32),
         ("acc_scale", ctypes.c_float),
+        ("in_dtype", ctypes.c_int32),
+        ("batch", ctypes.c_int32), ("batch_inner", ctypes.c_int32),
+        ("sAo", c_int64), ("sAi", c_int64), ("sWo", c_int64), ("sWi", c_int64), ("sCo", c_int64), ("sCi", c_int64),
     ]
 
 
@@ -55,6 +58,7 @@ _SIGNATURES = {
     "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_void_p, c_void_p],
+    "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,

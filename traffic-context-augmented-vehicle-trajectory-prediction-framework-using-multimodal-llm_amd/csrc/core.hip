@@ -21,6 +21,8 @@ void set_error(const char* fmt, ...) {
 // RMSNorm (HF modeling_llama.py:62-67): var = mean(x^2) in fp32,
 // y = x * rsqrt(var + eps) * gamma.  One wave per row, NV float4 per lane.
 // ---------------------------------------------------------------------------
+// NV > 0: H == NV * 256 exactly, the row lives in NV float4 per lane (no bounds logic, one HBM pass).
+// NV == 0: any H % 4 == 0; two passes over the row (the second one hits L2).
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ gamma, float eps,
@@ -31,29 +33,44 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   if (row >= M) return;
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * H);
   const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
-  const int nvec = H >> 2;
-  f32x4 v[NV];
-  float ss = 0.f;
+  if constexpr (NV > 0) {
+    f32x4 v[NV];
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = i * 64 + lane;
-    if (idx < nvec) {
-      v[i] = xr[idx];
+    for (int i = 0; i < NV; ++i) {
+      v[i] = xr[i * 64 + lane];
       ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-    } else {
-      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  ss = wave_sum(ss);
-  const float rs = rsqrtf(ss / (float)H + eps);
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int idx = i * 64 + lane;
-    if (idx < nvec) {
+    for (int i = 0; i < NV; ++i) {
+      const int idx = i * 64 + lane;
       const f32x4 g = gr[idx];
       f32x4 y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rs * g[e];
+      if (out_bf16) {
+        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
+      }
+      if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
+    }
+  } else {
+    const int nvec = H >> 2;
+    float ss = 0.f;
+    for (int idx = lane; idx < nvec; idx += 64) {
+      const f32x4 t = xr[idx];
+      ss += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    for (int idx = lane; idx < nvec; idx += 64) {
+      const f32x4 t = xr[idx];
+      const f32x4 g = gr[idx];
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = t[e] * rs * g[e];
       if (out_bf16) {
         u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
@@ -192,6 +209,28 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
   }
 }
 
+// Row softmax (one wave per row): P = softmax(S[:, :n_valid]), zero-padded to n_out columns.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long lds,
+                                                           bf16_t* __restrict__ P, long ldp, int f16, int rows,
+                                                           int n_valid, int n_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = S + (long)row * lds;
+  float m = -1e30f;
+  for (int c = lane; c < n_valid; c += 64) m = fmaxf(m, s[c]);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < n_valid; c += 64) sum += __expf(s[c] - m);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  bf16_t* o = P + (long)row * ldp;
+  for (int c = lane; c < n_out; c += 64) {
+    const float v = c < n_valid ? __expf(s[c] - m) * inv : 0.f;
+    o[c] = f16 ? __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)) : f32_to_bf16(v);
+  }
+}
+
 // kv_len[b] = Nq + popcount(mask[b]); flags masks that are not a prefix of ones.
 __global__ __launch_bounds__(64) void mask_to_kvlen_kernel(const int64_t* __restrict__ mask, int Lt, int Nq,
                                                            int* __restrict__ kv_len, int* __restrict__ flag) {
@@ -213,6 +252,18 @@ __global__ __launch_bounds__(64) void mask_to_kvlen_kernel(const int64_t* __rest
 }  // namespace tcavt
 
 using namespace tcavt;
+
+extern "C" int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int out_dtype, int rows,
+                                  int n_valid, int n_out, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(S && P && rows > 0 && n_valid > 0 && n_out >= n_valid && lds >= n_valid && ldp >= n_out,
+                  "softmax_rows: bad args");
+  TCAVT_CHECK_ARG(out_dtype == TCAVT_BF16 || out_dtype == TCAVT_F16, "softmax_rows: out_dtype must be bf16 or fp16");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), S,
+                     (long)lds, static_cast<bf16_t*>(P), (long)ldp, out_dtype == TCAVT_F16 ? 1 : 0, rows, n_valid,
+                     n_out);
+  TCAVT_CHECK_LAUNCH("softmax_rows");
+  return TCAVT_OK;
+}
 
 extern "C" int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_len,
                                    int* not_prefix_flag, tcavt_stream_t stream) {
@@ -251,17 +302,22 @@ extern "C" int tcavt_init(int device, int* num_cus) {
 extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
                              float* out_f32, int M, int H, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "rmsnorm: null pointer");
-  TCAVT_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0 && H <= 8192, "rmsnorm: H=%d must be a multiple of 8 and <= 8192", H);
+  TCAVT_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0, "rmsnorm: H=%d must be a multiple of 8", H);
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma), "rmsnorm: unaligned input");
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((M + 3) / 4), block(256);
   bf16_t* ob = static_cast<bf16_t*>(out_bf16);
-  const int nvec = H / 4;
-  if (nvec <= 64) hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
-  else if (nvec <= 128) hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
-  else if (nvec <= 256) hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
-  else if (nvec <= 512) hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
-  else hipLaunchKernelGGL(rmsnorm_kernel<32>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H);
+#define TCAVT_RMS(NV) hipLaunchKernelGGL(rmsnorm_kernel<NV>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H)
+  switch (H % 256 == 0 ? H / 256 : 0) {
+    case 1: TCAVT_RMS(1); break;
+    case 2: TCAVT_RMS(2); break;
+    case 3: TCAVT_RMS(3); break;
+    case 4: TCAVT_RMS(4); break;
+    case 8: TCAVT_RMS(8); break;
+    case 16: TCAVT_RMS(16); break;
+    default: TCAVT_RMS(0); break;
+  }
+#undef TCAVT_RMS
   TCAVT_CHECK_LAUNCH("rmsnorm");
   return TCAVT_OK;
 }

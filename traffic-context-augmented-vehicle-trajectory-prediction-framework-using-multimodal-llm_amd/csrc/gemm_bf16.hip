@@ -36,9 +36,11 @@ struct GemmP {
   const float* sinT;
   long lda, ldw, lda2, ldw2, ldc, ldr;
   int M, N, K, K2;
-  int out_bf16, flags, rope_L, rope_cols;
+  int out_kind, flags, rope_L, rope_cols;  // out_kind: TCAVT_F32 / TCAVT_BF16 / TCAVT_F16
   int tiles_m, tiles_n;
   float acc_scale;
+  int batch_inner;
+  long sAo, sAi, sWo, sWi, sCo, sCi;
 };
 
 enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2 };
@@ -49,16 +51,27 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+  const unsigned short a = __builtin_bit_cast(unsigned short, static_cast<_Float16>(lo));
+  const unsigned short b = __builtin_bit_cast(unsigned short, static_cast<_Float16>(hi));
+  return static_cast<unsigned int>(a) | (static_cast<unsigned int>(b) << 16);
+}
+
 __device__ __forceinline__ void store_quad(const GemmP& p, int m, int n, f32x4 v) {
-  if (p.out_bf16) {
+  if (p.out_kind == TCAVT_BF16) {
     u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = o;
+  } else if (p.out_kind == TCAVT_F16) {
+    u32x2 o = {pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])};
     *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = o;
   } else {
     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP p) {
   constexpr int NW = WARPS_M * WARPS_N;
   constexpr int ROWS = BM + BN;
@@ -91,6 +104,14 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
     tile_n = in_g / gsz;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (gridDim.y > 1) {  // batched form: product blockIdx.y
+    const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
+    p.A += bo * p.sAo + bi * p.sAi;
+    p.W += bo * p.sWo + bi * p.sWi;
+    const long co = bo * p.sCo + bi * p.sCi;
+    p.C = p.out_kind == TCAVT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + co)
+                                  : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + co);
+  }
 
   // ---- per-lane staging sources (main K source), one per round
   const bf16_t* src[ROUNDS];
@@ -163,7 +184,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          if constexpr (F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i]),
+                                                               __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -193,6 +218,10 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
         if (n >= p.N) continue;
         f32x4 v = acc[i][j] * p.acc_scale;
         if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.flags & TCAVT_EPI_BIAS_ROW) {
+          const float bm = p.bias[m];
+          v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+        }
         if (p.flags & TCAVT_EPI_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
           v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
@@ -248,13 +277,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
-static int launch(const GemmP& p0, hipStream_t stream) {
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
+static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * 128;
-  auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI>;
+  auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI, F16>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -265,16 +294,16 @@ static int launch(const GemmP& p0, hipStream_t stream) {
     }
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n), block(WARPS_M * WARPS_N * 64);
+  dim3 grid(p.tiles_m * p.tiles_n, batch), block(WARPS_M * WARPS_N * 64);
   hipLaunchKernelGGL(kfn, grid, block, lds, stream, p);
   TCAVT_CHECK_LAUNCH("gemm_bf16");
   return TCAVT_OK;
 }
 
-template <int EPI>
-static int dispatch_tile(const GemmP& p, int tile, hipStream_t stream) {
-  if (tile == 256) return launch<256, 256, 2, 4, EPI>(p, stream);
-  return launch<128, 128, 2, 2, EPI>(p, stream);
+template <int EPI, bool F16>
+static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream) {
+  if (tile == 256) return launch<256, 256, 2, 4, EPI, F16>(p, batch, stream);
+  return launch<128, 128, 2, 2, EPI, F16>(p, batch, stream);
 }
 
 }  // namespace tcavt
@@ -290,7 +319,20 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   TCAVT_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K,
                   "gemm_bf16: lda/ldw must be >= K and multiples of 8");
   TCAVT_CHECK_ARG(aligned16(a->A) && aligned16(a->W) && aligned16(a->C), "gemm_bf16: A/W/C must be 16-byte aligned");
-  TCAVT_CHECK_ARG(a->out_dtype == TCAVT_F32 || a->out_dtype == TCAVT_BF16, "gemm_bf16: bad out_dtype");
+  TCAVT_CHECK_ARG(a->out_dtype == TCAVT_F32 || a->out_dtype == TCAVT_BF16 || a->out_dtype == TCAVT_F16,
+                  "gemm_bf16: bad out_dtype");
+  TCAVT_CHECK_ARG(a->in_dtype == 0 || a->in_dtype == TCAVT_BF16 || a->in_dtype == TCAVT_F16, "gemm_bf16: bad in_dtype");
+  const bool f16 = a->in_dtype == TCAVT_F16;
+  const int batch = a->batch > 1 ? a->batch : 1;
+  if (f16 || batch > 1)
+    TCAVT_CHECK_ARG(!(a->epilogue & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)),
+                    "gemm_bf16: fp16 operands / batching are supported by the generic epilogue only");
+  if (batch > 1) {
+    TCAVT_CHECK_ARG(a->batch_inner >= 1 && batch % a->batch_inner == 0, "gemm_bf16: batch must be a multiple of batch_inner");
+    TCAVT_CHECK_ARG(a->sAo % 8 == 0 && a->sAi % 8 == 0 && a->sWo % 8 == 0 && a->sWi % 8 == 0 && a->sCo % 4 == 0 &&
+                        a->sCi % 4 == 0 && batch <= 65535,
+                    "gemm_bf16: batch strides must keep 16-byte (A/W) and 4-element (C) alignment; batch <= 65535");
+  }
   const int n_out = (a->epilogue & TCAVT_EPI_SILU_MUL) ? a->N / 2 : a->N;
   TCAVT_CHECK_ARG(a->ldc >= n_out && a->ldc % 4 == 0, "gemm_bf16: ldc=%ld too small or not a multiple of 4", (long)a->ldc);
   int K2 = 0;
@@ -304,6 +346,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   }
   const int epi = a->epilogue;
   if (epi & TCAVT_EPI_BIAS) TCAVT_CHECK_ARG(a->bias && aligned16(a->bias), "gemm_bf16: BIAS needs an aligned bias pointer");
+  if (epi & TCAVT_EPI_BIAS_ROW) TCAVT_CHECK_ARG(a->bias && !(epi & TCAVT_EPI_BIAS), "gemm_bf16: BIAS_ROW needs bias and excludes BIAS");
   if (epi & TCAVT_EPI_RESIDUAL)
     TCAVT_CHECK_ARG(a->residual && aligned16(a->residual) && a->ldr >= a->N && a->ldr % 4 == 0,
                     "gemm_bf16: RESIDUAL needs residual pointer and ldr >= N");
@@ -329,7 +372,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.sinT = a->rope_sin;
   p.lda = a->lda; p.ldw = a->ldw; p.lda2 = a->lda2; p.ldw2 = a->ldw2; p.ldc = a->ldc; p.ldr = a->ldr;
   p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = K2;
-  p.out_bf16 = a->out_dtype == TCAVT_BF16;
+  p.out_kind = a->out_dtype;
+  p.batch_inner = batch > 1 ? a->batch_inner : 1;
+  p.sAo = a->sAo; p.sAi = a->sAi; p.sWo = a->sWo; p.sWi = a->sWi; p.sCo = a->sCo; p.sCi = a->sCi;
   p.flags = epi;
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
   p.tiles_m = p.tiles_n = 0;
@@ -344,7 +389,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     tile = (t256 >= 256) ? 256 : 128;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU>(p, tile, s);
-  if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE>(p, tile, s);
-  return dispatch_tile<EPI_GENERIC>(p, tile, s);
+  if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
+  if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
+  if (f16) return dispatch_tile<EPI_GENERIC, true>(p, tile, batch, s);
+  return dispatch_tile<EPI_GENERIC, false>(p, tile, batch, s);
 }

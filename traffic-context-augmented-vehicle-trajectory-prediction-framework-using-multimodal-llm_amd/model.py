@@ -87,17 +87,21 @@ class _Workspace:
     def __init__(self):
         self._bufs = {}
 
-    def get(self, name, shape, dtype, device):
+    def get(self, name, shape, dtype, device, zero=False):
+        """zero=True: zero-filled when first allocated (pad regions that kernels never write)."""
         key = (name, tuple(int(s) for s in shape), dtype)
         t = self._bufs.get(key)
         if t is None or t.device != device:
-            t = torch.empty(key[1], dtype=dtype, device=device)
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=device)
             self._bufs[key] = t
         return t
 
 
 def _bf16(t):
     return ops.cast_bf16(t.detach().contiguous())
+
+
+XATTN_PAD = 64  # key counts of the head cross-attention are padded to a multiple of this
 
 
 class _Prepared:
@@ -522,7 +526,9 @@ class LlamaMultiModal(nn.Module, _Prepared):
         kv_len = ws.get("mm.kvlen", (B,), torch.int32, dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), Nq, kv_len, flags[1:2])
         final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
-        final_b = ws.get("mm.finalb", (B * L, H), torch.bfloat16, dev)
+        # bf16 copy for the cross-attention K/V projections; XATTN_PAD zeroed tail rows let those
+        # GEMMs run on key counts padded to a multiple of 64 (TransformerLTSF.forward)
+        final_b = ws.get("mm.finalb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
         LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
         self._last_flags = flags
         if return_bf16:
@@ -646,8 +652,9 @@ class TransformerLTSF(nn.Module, _Prepared):
             enc_w=st(self.nlinear_encoder.encoder_linears, "weight"), enc_b=st(self.nlinear_encoder.encoder_linears, "bias"),
             dec_w=st(dec.decoder_linears, "weight"), dec_b=st(dec.decoder_linears, "bias"),
             pos=self.pos_encoding.detach()[0, :, : self.seq_len].contiguous(),
-            w_dp=_bf16(dec.dec_proj.weight), w_q=_bf16(ca.in_proj_weight[:H]), w_kv=_bf16(ca.in_proj_weight[H:]),
-            b_q=ca.in_proj_bias.detach()[:H].contiguous(), b_kv=ca.in_proj_bias.detach()[H:].contiguous(),
+            w_dp=_bf16(dec.dec_proj.weight), w_q=_bf16(ca.in_proj_weight[:H]), w_k=_bf16(ca.in_proj_weight[H:2 * H]),
+            w_v=_bf16(ca.in_proj_weight[2 * H:]), b_q=ca.in_proj_bias.detach()[:H].contiguous(),
+            b_k=ca.in_proj_bias.detach()[H:2 * H].contiguous(), b_v=ca.in_proj_bias.detach()[2 * H:].contiguous(),
             w_co=_bf16(ca.out_proj.weight), w_un=_bf16(dec.dec_unproj.weight))
 
     def forward(self, x, lane_polygon_emb, final_hidden, final_hidden_bf16=None, _fuse_last_residual=False):
@@ -681,15 +688,32 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.gemm_bf16(dec_tb, P.w_dp, out=proj, bias=dec.dec_proj.bias)
         q = ws.get("lt.q", (B * To, H), torch.bfloat16, dev)
         ops.gemm_bf16(proj, P.w_q, out=q, bias=P.b_q)
+        nh = dec.cross_nhead
+        dh = H // nh
+        Lp = (L + XATTN_PAD - 1) // XATTN_PAD * XATTN_PAD
         if final_hidden_bf16 is None:
-            final_hidden_bf16 = ws.get("lt.fhb", (B * L, H), torch.bfloat16, dev)
+            final_hidden_bf16 = ws.get("lt.fhb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
             ops.cast_bf16(final_hidden.contiguous().view(B * L, H), out=final_hidden_bf16)
-        kv = ws.get("lt.kv", (B * L, 2 * H), torch.bfloat16, dev)
-        ops.gemm_bf16(final_hidden_bf16, P.w_kv, out=kv, bias=P.b_kv)
+        elif final_hidden_bf16.shape[0] < (B - 1) * L + Lp:
+            raise ValueError("final_hidden_bf16 needs XATTN_PAD zeroed tail rows")
+        # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
+        kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
+        ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
+        # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
+        # (roles of weights and activations swapped, batched over samples), so that P.V is again
+        # a K-contiguous A.W^T product
+        vT = ws.get("lt.vT", (H, B * Lp), torch.float16, dev)
+        ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
+                         sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
+        # scores[b,h] = q_bh . k_bh^T / sqrt(dh)  (fp32), softmax -> fp16 probabilities (zero beyond L)
+        S = ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev)
+        ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                         sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh))
+        Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
+        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp)
         att = ws.get("lt.att", (B * To, H), torch.bfloat16, dev)
-        dh = H // dec.cross_nhead
-        ops.mha(q, kv[:, :H], kv[:, H:], att, B, To, L, dec.cross_nhead, dh, 1.0 / math.sqrt(dh), ldq=H, ldk=2 * H,
-                ldv=2 * H, ldo=H)
+        ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                         sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
         cross = ws.get("lt.cross", (B * To, H), torch.bfloat16, dev)
         ops.gemm_bf16(att, P.w_co, out=cross, bias=dec.cross_attn.out_proj.bias)
         fused = ws.get("lt.fused", (B * To, C), torch.float32, dev)

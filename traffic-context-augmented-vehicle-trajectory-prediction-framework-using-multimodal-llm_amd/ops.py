@@ -99,6 +99,62 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
     return out
 
 
+def _avail(t):
+    """Elements addressable from t.data_ptr() to the end of its storage."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: capi.F16}
+
+
+def gemm_batched(a, w, out, *, M, N, K, lda, ldw, ldc, batch, inner, sA, sW, sC, bias_row=None, acc_scale=1.0,
+                 tile=128):
+    """`batch` independent products C_i = A_i . W_i^T with two-level strides (outer, inner) in elements:
+    product i uses a + (i // inner) * sA[0] + (i % inner) * sA[1], likewise w and out.  a/w share a
+    16-bit dtype (bf16 or fp16); out may be fp32, bf16 or fp16.  See tcavt_gemm_args (include/tcavt.h)."""
+    if a.dtype != w.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise capi.TcavtError("gemm_batched: a and w must both be bf16 or both fp16")
+    outer = batch // inner
+    if batch < 1 or batch % inner:
+        raise capi.TcavtError("gemm_batched: batch must be a positive multiple of inner")
+    for t, s, rows, ld, cols, nm in ((a, sA, M, lda, K, "a"), (w, sW, N, ldw, K, "w"), (out, sC, M, ldc, N, "out")):
+        if not t.is_cuda and not _ALLOW_CPU:
+            raise capi.TcavtError(f"gemm_batched.{nm}: tensor must live on the GPU")
+        need = (outer - 1) * s[0] + (inner - 1) * s[1] + (rows - 1) * ld + cols
+        if _avail(t) < need:
+            raise capi.TcavtError(f"gemm_batched.{nm}: buffer has {_avail(t)} elements past its pointer, needs {need}")
+    args = capi.GemmArgs()
+    args.A, args.lda = a.data_ptr(), lda
+    args.W, args.ldw = w.data_ptr(), ldw
+    args.C, args.ldc = out.data_ptr(), ldc
+    args.M, args.N, args.K = M, N, K
+    args.out_dtype = _DT[out.dtype]
+    args.in_dtype = _DT[a.dtype]
+    args.acc_scale = acc_scale
+    args.tile = tile
+    if bias_row is not None:
+        _req(bias_row, torch.float32, "gemm_batched.bias_row")
+        _need(bias_row, M, "gemm_batched.bias_row")
+        args.bias = bias_row.data_ptr()
+        args.epilogue = capi.EPI_BIAS_ROW
+    args.batch, args.batch_inner = batch, inner
+    args.sAo, args.sAi = sA
+    args.sWo, args.sWi = sW
+    args.sCo, args.sCi = sC
+    check(lib().tcavt_gemm_bf16(ctypes.byref(args), stream_ptr()), "tcavt_gemm_bf16(batched)")
+    return out
+
+
+def softmax_rows(s, p, rows, n_valid, n_out, lds, ldp):
+    _req(s, torch.float32, "softmax_rows.s")
+    if p.dtype not in (torch.bfloat16, torch.float16):
+        raise capi.TcavtError("softmax_rows.p: must be bf16 or fp16")
+    if _avail(s) < (rows - 1) * lds + n_valid or _avail(p) < (rows - 1) * ldp + n_out:
+        raise capi.TcavtError("softmax_rows: buffer too small")
+    check(lib().tcavt_softmax_rows(ptr(s), lds, ptr(p), ldp, _DT[p.dtype], rows, n_valid, n_out, stream_ptr()),
+          "tcavt_softmax_rows")
+
+
 def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None):
     _req(x, torch.float32, "rmsnorm.x")
     _req(gamma, torch.float32, "rmsnorm.gamma")
