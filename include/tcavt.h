@@ -215,11 +215,12 @@ int tcavt_masked_mean(const float* enc, const int32_t* len, float* emb, int B, i
  *   xp[b][c][t] = conv_w[c][0]*x[b][0][t] + conv_w[c][1]*x[b][1][t] + conv_b[c]
  *   enc[b][c][s] = sum_t enc_w[c][s][t]*(xp[b][c][t]-xp[b][c][T-1]) + enc_b[c][s]
  *                  + xp[b][c][T-1] + pos[c][s]
- * x [B][2][T]; out enc [B][C][T] and its (T,B,C)-ordered copy tok [T*B... see .hip]
+ * x [B][2][T]; out enc_tok token-major [B][T][C]
  * ---------------------------------------------------------------------- */
 int tcavt_ltsf_front(const float* x, const float* conv_w, const float* conv_b,
                      const float* enc_w, const float* enc_b, const float* pos,
-                     float* enc_tok, int B, int C, int T, tcavt_stream_t stream);
+                     float* enc_tok, float* xp_tok /* optional [B][T][C]: xp, kept for the backward */,
+                     int B, int C, int T, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * LTSF_NLinearDecoder front (scripts/train.py:768-785):
@@ -260,6 +261,68 @@ int tcavt_out_head(const float* fused, const float* w, const float* bias,
 int tcavt_traj_metrics(const float* pred, const float* gt, const float* norm_stat,
                        float* sums, int32_t* argmin, float* per_sample, int B, int K,
                        int To, tcavt_stream_t stream);
+
+/* fp32 dense layer with general element strides: A[m][k] = A[m*rsA + k*csA], W[n][k] = W[n*rsW + k*csW];
+ * C[M,N] = A . W^T (+bias)(+relu)(+residual).  Lets the backward of an fp32 nn.Linear run without
+ * transposes: gx = gy . W  (rsW = 1, csW = ldw)  and  gW = gy^T . x  (rsA = 1, csA = ld_gy; rsW = 1, csW = ld_x). */
+int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, const float* W, int64_t rsW,
+                           int64_t csW, const float* bias, const float* residual, int64_t ldr, float* C,
+                           int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream);
+
+/* ========================================================================
+ * Training step of scripts/train.py (:1168-1183): backward through the trainable part (lane-polygon
+ * encoder + TransformerLTSF; the MLLM is frozen, :1140-1145) and AdamW (:1145).  What autograd does
+ * for the reference is spelled out as kernels here; heavy contractions reuse tcavt_gemm_bf16 on
+ * transposed operands.
+ * ====================================================================== */
+
+/* out[c][r] = in[r][c] for 16-bit elements (bf16 / fp16), `batch` matrices s_in / s_out elements apart;
+ * rows r in [rows, rows_pad) of the source are written as zeros (K-padding of the following GEMM). */
+int tcavt_transpose16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
+                      int rows_pad, int batch, int64_t s_in, int64_t s_out, tcavt_stream_t stream);
+/* fp32 [rows][cols] -> bf16 [cols][rows_pad], zero padded */
+int tcavt_transpose_f32_bf16(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
+                             int cols, int rows_pad, tcavt_stream_t stream);
+/* out[n] (+)= sum_m g[m][n]  (bias gradient); dtype of g: TCAVT_F32 or TCAVT_BF16 */
+int tcavt_colsum(const void* g, int64_t ld, int dtype, float* out, int M, int N, int accumulate,
+                 tcavt_stream_t stream);
+/* g[i] = 0 where the saved post-ReLU activation y[i] <= 0 */
+int tcavt_relu_bwd(float* g, const void* y, int y_dtype, int64_t n, tcavt_stream_t stream);
+/* a[i] += b[i] */
+int tcavt_add_inplace(float* a, const float* b, int64_t n, tcavt_stream_t stream);
+/* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
+int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
+                        float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);
+/* backward of tcavt_mha (fp32 operands): gq, gk, gv share leading dimension ldg */
+int tcavt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                  const float* go, int64_t ldo, float* gq, float* gk, float* gv, int64_t ldg,
+                  const int32_t* key_len, int B, int Lq, int Lk, int nh, int dh, float scale,
+                  tcavt_stream_t stream);
+/* backward of tcavt_softmax_rows (+ the 1/sqrt(dh) score scale): dS bf16, zero padded to n_out */
+int tcavt_softmax_bwd_rows(const void* P_f16, int64_t ldp, const float* dP, int64_t ldd, void* dS_bf16,
+                           int64_t lds, float scale, int rows, int n_valid, int n_out,
+                           tcavt_stream_t stream);
+/* d loss / d decoded for loss = MSE_x + MSE_y in pixel space (train.py:945-961) */
+int tcavt_mse_grad(const float* pred, const float* gt, const float* norm_stat, float* g, int B, int To,
+                   tcavt_stream_t stream);
+/* backward of tcavt_out_head: gf [B][To][C], gw [F][C], gb [F] */
+int tcavt_out_head_bwd(const float* g, const float* fused, const float* w, float* gf, float* gw, float* gb,
+                       int B, int To, int C, int F, tcavt_stream_t stream);
+/* backward of the per-channel N-Linear blocks (tcavt_ltsf_front's encoder, tcavt_ltsf_decode):
+ * in_tok / gin_tok token-major [B][T][C]; g addressed as g[b*g_sb + c*g_sc + s*g_ss]; gin_tok may be NULL */
+int tcavt_nlinear_bwd(const float* in_tok, const float* W, const float* g, int64_t g_sb, int64_t g_sc,
+                      int64_t g_ss, float* gW, float* gbias, float* gin_tok, int B, int C, int T, int S,
+                      tcavt_stream_t stream);
+/* Conv1d(k=1) token projection backward: gxp_tok [B][T][C], x [B][F][T] -> gw [C][F], gb [C] */
+int tcavt_conv1x1_bwd(const float* gxp_tok, const float* x, float* gw, float* gb, int B, int C, int T,
+                      int F, tcavt_stream_t stream);
+int tcavt_poly_embed_bwd(const float* g, const float* polygon, float* gw, float* gb, float* gpos, int B,
+                         int P, int D, tcavt_stream_t stream);
+int tcavt_masked_mean_bwd(const float* gemb, const int32_t* len, float* genc, int B, int P, int D,
+                          tcavt_stream_t stream);
+/* torch.optim.AdamW step over a flat fp32 vector; grad_scale multiplies g first (1/world for DP mean) */
+int tcavt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, float grad_scale, tcavt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,352 @@
+"""Backward pass of the part of the model that scripts/train.py trains, over the C ABI.
+
+In the reference, ``loss.backward()`` (train.py:1182) walks an autograd graph that only covers the
+lane-polygon encoder and ``TransformerLTSF``: every MLLM parameter has ``requires_grad=False``
+(train.py:1140-1142), so the LLM's final hidden states are a constant.  This module spells that
+graph out stage by stage, in reverse, on the activations the forward retained
+(``save_for_backward`` workspaces of model.py).  Nothing here calls torch autograd or torch math.
+
+Precision: fp32 wherever the forward is fp32; the cross-attention projections run their backward
+contractions in bf16 MFMA with fp32 accumulation (standard mixed precision), writing fp32 gradients.
+"""
+import math
+
+import torch
+
+from . import ops
+from .model import XATTN_PAD
+
+
+def _rup(n, m):
+    return (n + m - 1) // m * m
+
+
+class GradBook:
+    """Flat fp32 gradient vector with one view per trainable parameter (and the matching flat
+    parameter vector), ordered by the time the gradient becomes ready in the backward so that
+    contiguous buckets can be all-reduced while the rest of the backward is still running."""
+
+    def __init__(self, named_params, device):
+        self.names = [n for n, _ in named_params]
+        sizes = [p.numel() for _, p in named_params]
+        self.offsets = {}
+        off = 0
+        for (n, p), sz in zip(named_params, sizes):
+            self.offsets[n] = (off, sz, tuple(p.shape))
+            off += _rup(sz, 4)  # keep every view 16-byte aligned
+        self.total = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = {}
+        for n, p in named_params:
+            o, sz, shape = self.offsets[n]
+            view = self.params[o:o + sz].view(shape)
+            view.copy_(p.data)
+            p.data = view  # the nn.Parameter now aliases the flat vector (state_dict() is unchanged)
+            self.g[n] = self.grads[o:o + sz].view(shape)
+
+    def end_of(self, name):
+        o, sz, _ = self.offsets[name]
+        return o + _rup(sz, 4)
+
+
+class Backward:
+    def __init__(self, model, book: GradBook, prefix_ltsf="ltsf.", prefix_poly="lane_polygon_encoder."):
+        self.m, self.book = model, book
+        self.pl, self.pp = prefix_ltsf, prefix_poly
+        self.ws = model.ltsf._ws  # scratch for gradient activations
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        dev = self.book.grads.device
+        return self.ws.get("bw." + name, shape, dtype, dev, zero=zero)
+
+    def lin_bwd_f32(self, x, W, gy, gW, gb, gx=None):
+        """y = x W^T + b (fp32).  x [M,K], W [N,K], gy [M,N] -> gW [N,K], gb [N], optional gx [M,K]."""
+        M, K = x.shape
+        N = W.shape[0]
+        ops.gemm_f32_strided(gy, 1, gy.stride(0), x, 1, x.stride(0), gW, N, K, M)
+        if gb is not None:
+            ops.colsum(gy, gb, M, N)
+        if gx is not None:
+            ops.gemm_f32_strided(gy, gy.stride(0), 1, W, 1, W.stride(0), gx, M, K, N)
+        return gx
+
+    def lin_bwd_bf16(self, tag, x_b, W, gy, gW, gb, gx=None, xT=None):
+        """y = bf16(x) bf16(W)^T + b on MFMA.  x_b bf16 [M,K]; W fp32 param [N,K]; gy bf16 or fp32 [M,N].
+        gW fp32 [N,K] = gy^T x, gb = colsum(gy), optional gx [M,K] (dtype of the given buffer) = gy W."""
+        M, K = x_b.shape
+        N = W.shape[0]
+        Mp = _rup(M, 64)
+        if gy.dtype == torch.float32:
+            gy_b = self._buf(tag + ".gyb", (M, N), torch.bfloat16)
+            ops.cast_bf16(gy, out=gy_b)
+        else:
+            gy_b = gy
+        gyT = self._buf(tag + ".gyT", (N, Mp), torch.bfloat16)
+        ops.transpose16(gy_b, gyT, M, N, Mp)
+        if xT is None:
+            xT = self._buf(tag + ".xT", (K, Mp), torch.bfloat16)
+            ops.transpose16(x_b, xT, M, K, Mp)
+        ops.gemm_bf16(gyT, xT, out=gW)  # [N, K] fp32
+        if gb is not None:
+            ops.colsum(gy, gb, M, N)
+        if gx is not None:
+            WT = self._buf(tag + ".WT", (K, N), torch.bfloat16)
+            ops.transpose_f32_bf16(W.detach(), WT, N, K, N)
+            ops.gemm_bf16(gy_b, WT, out=gx)
+        return xT
+
+    # ---- TransformerLTSF ----------------------------------------------------------------------
+    def ltsf(self, g_out, x_in):
+        """g_out [B,2,To] = dL/d decoded; returns g_poly_emb [B, D_poly]."""
+        m, G, ws = self.m.ltsf, self.book.g, self.m.ltsf._ws
+        dec, sab = m.decoder, m.attn_block
+        pl = self.pl
+        B, F, T = x_in.shape
+        C, To = m.d_model, m.out_len
+        dev = g_out.device
+        M = B * To
+        H = dec.cross_dim
+        nh = dec.cross_nhead
+        dh = H // nh
+        fwd = lambda name, shape, dt=torch.float32: ws.get("lt." + name, shape, dt, dev)
+        # saved forward activations
+        f2 = fwd("f2", (M, C)); f1 = fwd("f1", (M, C)); fn = fwd("fn", (M, C)); fused = fwd("fused", (M, C))
+        cross = fwd("cross", (M, H), torch.bfloat16); att = fwd("att", (M, H), torch.bfloat16)
+        q = fwd("q", (M, H), torch.bfloat16); proj = fwd("proj", (M, H), torch.bfloat16)
+        dec_tb = fwd("dectb", (M, C), torch.bfloat16)
+        fl = dec.fusion_layer
+
+        # head: out = f2 W_out^T + b (+ last position, no gradient needed)
+        g_f2 = self._buf("g_f2", (M, C))
+        ops.out_head_bwd(g_out, f2, dec.out_proj.weight, g_f2, G[pl + "decoder.out_proj.weight"],
+                         G[pl + "decoder.out_proj.bias"], B, To, C, F)
+        # fusion layer: LN -> Linear -> ReLU -> Linear (no residual)
+        g_f1 = self._buf("g_f1", (M, C))
+        self.lin_bwd_f32(f1, fl[3].weight, g_f2, G[pl + "decoder.fusion_layer.3.weight"],
+                         G[pl + "decoder.fusion_layer.3.bias"], gx=g_f1)
+        ops.relu_bwd(g_f1, f1)
+        g_fn = self._buf("g_fn", (M, C))
+        self.lin_bwd_f32(fn, fl[1].weight, g_f1, G[pl + "decoder.fusion_layer.1.weight"],
+                         G[pl + "decoder.fusion_layer.1.bias"], gx=g_fn)
+        g_dec_t = self._buf("g_dec_t", (M, C))  # gradient w.r.t. fused == first term of g(dec_t)
+        ops.layernorm_bwd(fused, fl[0].weight, g_fn, g_dec_t, G[pl + "decoder.fusion_layer.0.weight"],
+                          G[pl + "decoder.fusion_layer.0.bias"])
+        # fused = cross W_un^T + b_un + dec_t
+        g_cross = self._buf("g_cross", (M, H), torch.bfloat16)
+        self.lin_bwd_bf16("un", cross, dec.dec_unproj.weight, g_dec_t, G[pl + "decoder.dec_unproj.weight"],
+                          G[pl + "decoder.dec_unproj.bias"], gx=g_cross)
+        # cross = att W_co^T + b_co
+        g_att = self._buf("g_att", (M, H), torch.bfloat16)
+        ca = dec.cross_attn
+        self.lin_bwd_bf16("co", att, ca.out_proj.weight, g_cross, G[pl + "decoder.cross_attn.out_proj.weight"],
+                          G[pl + "decoder.cross_attn.out_proj.bias"], gx=g_att)
+        # attention core
+        g_q, g_k, g_v, L = self._xattn_core(g_att, B, To, H, nh, dh)
+        # in-projection (packed [3H, H] weight / [3H] bias)
+        gWin, gbin = G[pl + "decoder.cross_attn.in_proj_weight"], G[pl + "decoder.cross_attn.in_proj_bias"]
+        g_proj = self._buf("g_proj", (M, H), torch.bfloat16)
+        self.lin_bwd_bf16("q", proj, ca.in_proj_weight[:H], g_q, gWin[:H], gbin[:H], gx=g_proj)
+        fh_b = self._fh_b
+        fhT = self.lin_bwd_bf16("k", fh_b[: B * L], ca.in_proj_weight[H:2 * H], g_k[: B * L], gWin[H:2 * H],
+                                gbin[H:2 * H])
+        self.lin_bwd_bf16("v", fh_b[: B * L], ca.in_proj_weight[2 * H:], g_v[: B * L], gWin[2 * H:], gbin[2 * H:],
+                          xT=fhT)
+        # proj = dec_t W_dp^T + b_dp
+        g_dt2 = self._buf("g_dt2", (M, C))
+        self.lin_bwd_bf16("dp", dec_tb, dec.dec_proj.weight, g_proj, G[pl + "decoder.dec_proj.weight"],
+                          G[pl + "decoder.dec_proj.bias"], gx=g_dt2)
+        ops.add_inplace(g_dec_t, g_dt2)
+        # dec_t [B,To,C] -> d1 [B,C,To]
+        g_d1 = self._buf("g_d1", (B, C * To))
+        ops.transpose_ct(g_dec_t, g_d1, None, B, To, C)
+        # post MLP: d1 = relu(d0 W0^T + b0) W3^T + b3
+        d0 = fwd("dec0", (B, C * To))
+        if dec.use_post_mlp:
+            hid = fwd("hid", (B, dec.post_mlp[0].weight.shape[0]))
+            g_hid = self._buf("g_hid", tuple(hid.shape))
+            self.lin_bwd_f32(hid, dec.post_mlp[3].weight, g_d1, G[pl + "decoder.post_mlp.3.weight"],
+                             G[pl + "decoder.post_mlp.3.bias"], gx=g_hid)
+            ops.relu_bwd(g_hid, hid)
+            g_d0 = self._buf("g_d0", (B, C * To))
+            self.lin_bwd_f32(d0, dec.post_mlp[0].weight, g_hid, G[pl + "decoder.post_mlp.0.weight"],
+                             G[pl + "decoder.post_mlp.0.bias"], gx=g_d0)
+        else:
+            g_d0 = g_d1
+        # d0 = NLinear_dec(e) + lane_fc(poly_emb)
+        poly_emb = self._poly_emb
+        g_poly = self._buf("g_poly", tuple(poly_emb.shape))
+        self.lin_bwd_f32(poly_emb, dec.lane_fc.weight, g_d0, G[pl + "decoder.lane_fc.weight"],
+                         G[pl + "decoder.lane_fc.bias"], gx=g_poly)
+        e = sab._ws.get("sab.out", (B * T, C), torch.float32, dev)
+        P = m._prepared()
+        g_dw = self._buf("g_dw", (C, To, T))
+        g_db = self._buf("g_db", (C, To))
+        g_e = self._buf("g_e", (B * T, C))
+        ops.nlinear_bwd(e, P.dec_w, g_d0, (C * To, To, 1), g_dw, g_db, g_e, B, C, T, To)
+        self._scatter_channels(g_dw, g_db, pl + "decoder.decoder_linears.", C)
+        # SelfAttentionBlock
+        g_tok = self._sab(g_e, B, T, C)
+        # front: tok = NLinear_enc(conv(x)) + pos
+        xp = ws.get("lt.xp", (B * T, C), torch.float32, dev)
+        g_ew = self._buf("g_ew", (C, T, T))
+        g_eb = self._buf("g_eb", (C, T))
+        g_xp = self._buf("g_xp", (B * T, C))
+        ops.nlinear_bwd(xp, P.enc_w, g_tok, (T * C, 1, C), g_ew, g_eb, g_xp, B, C, T, T)
+        self._scatter_channels(g_ew, g_eb, pl + "nlinear_encoder.encoder_linears.", C)
+        gpos = G[pl + "pos_encoding"]  # (1, C, seq_len): same reduction as the encoder bias
+        gpos.view(C, -1)[:, :T].copy_(g_eb)
+        ops.conv1x1_bwd(g_xp, x_in, G[pl + "token_proj.weight"].view(C, F), G[pl + "token_proj.bias"], B, C, T, F)
+        return g_poly
+
+    def _scatter_channels(self, gW, gb, prefix, C):
+        """Stacked [C, S, T] / [C, S] gradients -> the C separate nn.Linear gradient views.  The flat
+        book lays these views out contiguously in channel order (weight, bias, weight, bias, ...), so
+        this is two strided device copies (memory plumbing, no arithmetic)."""
+        G = self.book.g
+        o0, _, shape = self.book.offsets[prefix + "0.weight"]
+        S, T = shape
+        stride = self.book.offsets[prefix + "1.weight"][0] - o0 if C > 1 else 0
+        flat = self.book.grads
+        wv = torch.as_strided(flat, (C, S * T), (stride, 1), o0)
+        wv.copy_(gW.view(C, S * T))
+        ob = self.book.offsets[prefix + "0.bias"][0]
+        bv = torch.as_strided(flat, (C, S), (stride, 1), ob)
+        bv.copy_(gb.view(C, S))
+
+    def _sab(self, g_e, B, T, C):
+        m, G = self.m.ltsf.attn_block, self.book.g
+        pl = self.pl + "attn_block."
+        ws, dev = m._ws, g_e.device
+        Mt = B * T
+        f = lambda n, shape: ws.get("sab." + n, shape, torch.float32, dev)
+        tok = self.m.ltsf._ws.get("lt.tok", (Mt, C), torch.float32, dev)
+        xn, qkv, att, res1, rn, ff = f("xn", (Mt, C)), f("qkv", (Mt, 3 * C)), f("att", (Mt, C)), f("res1", (Mt, C)), \
+            f("rn", (Mt, C)), f("f", (Mt, 4 * C))
+        # e = ff W3^T + b3 + rn ; ff = relu(rn W0^T + b0)
+        g_ff = self._buf("sab.g_ff", (Mt, 4 * C))
+        self.lin_bwd_f32(ff, m.ffn[3].weight, g_e, G[pl + "ffn.3.weight"], G[pl + "ffn.3.bias"], gx=g_ff)
+        ops.relu_bwd(g_ff, ff)
+        g_rn = self._buf("sab.g_rn", (Mt, C))
+        self.lin_bwd_f32(rn, m.ffn[0].weight, g_ff, G[pl + "ffn.0.weight"], G[pl + "ffn.0.bias"], gx=g_rn)
+        ops.add_inplace(g_rn, g_e)
+        g_res1 = self._buf("sab.g_res1", (Mt, C))
+        ops.layernorm_bwd(res1, m.norm2.weight, g_rn, g_res1, G[pl + "norm2.weight"], G[pl + "norm2.bias"])
+        # res1 = att Wo^T + bo + xn
+        g_att = self._buf("sab.g_att", (Mt, C))
+        self.lin_bwd_f32(att, m.mha.out_proj.weight, g_res1, G[pl + "mha.out_proj.weight"], G[pl + "mha.out_proj.bias"],
+                         gx=g_att)
+        g_qkv = self._buf("sab.g_qkv", (Mt, 3 * C))
+        dh = C // m.nhead
+        ops.mha_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], g_att, g_qkv[:, :C], g_qkv[:, C:2 * C], g_qkv[:, 2 * C:],
+                    B, T, T, m.nhead, dh, 1.0 / math.sqrt(dh), ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C, ldg=3 * C)
+        g_xn = self._buf("sab.g_xn", (Mt, C))
+        self.lin_bwd_f32(xn, m.mha.in_proj_weight, g_qkv, G[pl + "mha.in_proj_weight"], G[pl + "mha.in_proj_bias"],
+                         gx=g_xn)
+        ops.add_inplace(g_xn, g_res1)
+        g_tok = self._buf("sab.g_tok", (Mt, C))
+        ops.layernorm_bwd(tok, m.norm1.weight, g_xn, g_tok, G[pl + "norm1.weight"], G[pl + "norm1.bias"])
+        return g_tok
+
+    def _xattn_core(self, g_att, B, To, H, nh, dh):
+        """Backward of softmax(q k^T / sqrt(dh)) v per (sample, head) on batched MFMA GEMMs."""
+        ws, dev = self.m.ltsf._ws, g_att.device
+        fh_b = self._fh_b
+        L = self._L
+        Lp = _rup(L, XATTN_PAD)
+        Tp = _rup(To, 64)
+        M = B * To
+        P = self.m.ltsf._prepared()
+        q = ws.get("lt.q", (M, H), torch.bfloat16, dev)
+        kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev)
+        Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
+        scale = 1.0 / math.sqrt(dh)
+        # v (non-transposed, bf16) is recomputed: the forward only kept v^T in fp16
+        v = self._buf("xa.v", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
+        ops.gemm_bf16(fh_b[: B * L], P.w_v, out=v, bias=P.b_v)
+        # dP = dO V^T   [B*nh*To, Lp] fp32 (columns >= L are never read)
+        dP = self._buf("xa.dP", (B * nh * To, Lp))
+        ops.gemm_batched(g_att, v, dP, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                         sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp))
+        dS = self._buf("xa.dS", (B * nh * To, Lp), torch.bfloat16)
+        ops.softmax_bwd_rows(Pm, dP, dS, scale, B * nh * To, L, Lp, Lp, Lp, Lp)
+        # dQ_bh = dS_bh K_bh : contraction over keys -> needs K^T per sample  kT [H, B*Lp]
+        kT = self._buf("xa.kT", (H, B * Lp), torch.bfloat16)
+        ops.transpose16(kx, kT, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
+        g_q = self._buf("xa.g_q", (M, H), torch.bfloat16)
+        ops.gemm_batched(dS, kT, g_q, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                         sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
+        # dK_bh = dS_bh^T Q_bh ; dV_bh = P_bh^T dO_bh : contraction over the To queries (padded to Tp)
+        dST = self._buf("xa.dST", (B * nh * Lp, Tp), torch.bfloat16)
+        ops.transpose16(dS, dST, To, Lp, Tp, ld_in=Lp, ld_out=Tp, batch=B * nh, s_in=To * Lp, s_out=Lp * Tp)
+        Pb = self._buf("xa.Pb", (B * nh * To, Lp), torch.bfloat16)
+        ops.softmax_rows(ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), Pb, B * nh * To, L, Lp, Lp, Lp)
+        PT = self._buf("xa.PT", (B * nh * Lp, Tp), torch.bfloat16)
+        ops.transpose16(Pb, PT, To, Lp, Tp, ld_in=Lp, ld_out=Tp, batch=B * nh, s_in=To * Lp, s_out=Lp * Tp)
+        qT = self._buf("xa.qT", (H, B * Tp), torch.bfloat16)
+        ops.transpose16(q, qT, To, H, Tp, ld_in=H, ld_out=B * Tp, batch=B, s_in=To * H, s_out=Tp)
+        gaT = self._buf("xa.gaT", (H, B * Tp), torch.bfloat16)
+        ops.transpose16(g_att, gaT, To, H, Tp, ld_in=H, ld_out=B * Tp, batch=B, s_in=To * H, s_out=Tp)
+        g_k = self._buf("xa.g_k", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
+        g_v = self._buf("xa.g_v", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
+        ops.gemm_batched(dST, qT, g_k, M=L, N=dh, K=Tp, lda=Tp, ldw=B * Tp, ldc=H, batch=B * nh, inner=nh,
+                         sA=(nh * Lp * Tp, Lp * Tp), sW=(Tp, dh * B * Tp), sC=(L * H, dh))
+        ops.gemm_batched(PT, gaT, g_v, M=L, N=dh, K=Tp, lda=Tp, ldw=B * Tp, ldc=H, batch=B * nh, inner=nh,
+                         sA=(nh * Lp * Tp, Lp * Tp), sW=(Tp, dh * B * Tp), sC=(L * H, dh))
+        return g_q, g_k, g_v, L
+
+    # ---- LanePolygonEncoder -------------------------------------------------------------------
+    def polygon(self, g_emb):
+        enc, G, pp = self.m.lane_polygon_encoder, self.book.g, self.pp
+        sv = enc.saved
+        B, P, D = sv.B, sv.P, enc.d_model
+        M = B * P
+        nh = enc.nhead
+        dh = D // nh
+        g_x = self._buf("po.g_x", (M, D))
+        ops.masked_mean_bwd(g_emb, sv.lens, g_x, B, P, D)
+        for i in reversed(range(len(sv.layers))):
+            s, lyr = sv.layers[i], enc.encoder.layers[i]
+            pre = f"{pp}encoder.layers.{i}."
+            g_y2 = self._buf("po.g_y2", (M, D))
+            ops.layernorm_bwd(s["y2"], lyr.norm2.weight, g_x, g_y2, G[pre + "norm2.weight"], G[pre + "norm2.bias"])
+            ff = lyr.linear1.weight.shape[0]
+            g_f = self._buf("po.g_f", (M, ff))
+            self.lin_bwd_f32(s["f"], lyr.linear2.weight, g_y2, G[pre + "linear2.weight"], G[pre + "linear2.bias"], gx=g_f)
+            ops.relu_bwd(g_f, s["f"])
+            g_x1 = self._buf("po.g_x1", (M, D))
+            self.lin_bwd_f32(s["x1"], lyr.linear1.weight, g_f, G[pre + "linear1.weight"], G[pre + "linear1.bias"], gx=g_x1)
+            ops.add_inplace(g_x1, g_y2)
+            g_y = self._buf("po.g_y", (M, D))
+            ops.layernorm_bwd(s["y"], lyr.norm1.weight, g_x1, g_y, G[pre + "norm1.weight"], G[pre + "norm1.bias"])
+            g_att = self._buf("po.g_att", (M, D))
+            sa = lyr.self_attn
+            self.lin_bwd_f32(s["att"], sa.out_proj.weight, g_y, G[pre + "self_attn.out_proj.weight"],
+                             G[pre + "self_attn.out_proj.bias"], gx=g_att)
+            qkv = s["qkv"]
+            g_qkv = self._buf("po.g_qkv", (M, 3 * D))
+            ops.mha_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], g_att, g_qkv[:, :D], g_qkv[:, D:2 * D],
+                        g_qkv[:, 2 * D:], B, P, P, nh, dh, 1.0 / math.sqrt(dh), key_len=sv.lens, ldq=3 * D, ldk=3 * D,
+                        ldv=3 * D, ldo=D, ldg=3 * D)
+            g_xin = self._buf(f"po.g_xin{i & 1}", (M, D))
+            self.lin_bwd_f32(s["x"], sa.in_proj_weight, g_qkv, G[pre + "self_attn.in_proj_weight"],
+                             G[pre + "self_attn.in_proj_bias"], gx=g_xin)
+            ops.add_inplace(g_xin, g_y)
+            g_x = g_xin
+        gpos = G[pp + "pos_embedding"]
+        ops.poly_embed_bwd(g_x, sv.polygon, G[pp + "input_proj.weight"], G[pp + "input_proj.bias"],
+                           gpos.view(-1, D)[:P], B, P, D)
+
+    # ---- entry ------------------------------------------------------------------------------
+    def run(self, decoded, y, norm_stat, x_in, poly_emb, fh_b, L, after_ltsf=None):
+        """Fills book.grads (must be zeroed by the caller) from the retained forward activations.
+        `after_ltsf` (callable) is invoked once the LTSF gradients are complete (bucket hand-off)."""
+        B, F, To = decoded.shape
+        self._poly_emb, self._fh_b, self._L = poly_emb, fh_b, L
+        g_out = self._buf("g_out", (B, F, To))
+        ops.mse_grad(decoded, y, norm_stat, g_out, B, To)
+        g_poly = self.ltsf(g_out, x_in)
+        if after_ltsf is not None:
+            after_ltsf()
+        self.polygon(g_poly)

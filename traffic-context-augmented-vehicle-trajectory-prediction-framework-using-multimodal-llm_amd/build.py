@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libtcavt_hip.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["core.hip", "gemm_bf16.hip", "attention.hip", "small.hip"]
+SOURCES = ["core.hip", "gemm_bf16.hip", "attention.hip", "small.hip", "backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wall"]
 

@@ -67,7 +67,7 @@ _SIGNATURES = {
                        c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_poly_embed": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_masked_mean": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "tcavt_ltsf_front": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+    "tcavt_ltsf_front": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                          c_int, c_void_p],
     "tcavt_ltsf_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_transpose_ct": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -75,6 +75,28 @@ _SIGNATURES = {
                        c_int, c_void_p],
     "tcavt_traj_metrics": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p],
+    "tcavt_gemm_f32_strided": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                               c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_transpose16": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p],
+    "tcavt_transpose_f32_bf16": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tcavt_colsum": [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_relu_bwd": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
+    "tcavt_add_inplace": [c_void_p, c_void_p, c_int64, c_void_p],
+    "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                      c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "tcavt_softmax_bwd_rows": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_int, c_int,
+                               c_void_p],
+    "tcavt_mse_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_out_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                           c_void_p],
+    "tcavt_nlinear_bwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                          c_int, c_int, c_int, c_void_p],
+    "tcavt_conv1x1_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_poly_embed_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_masked_mean_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                    c_int, c_float, c_void_p],
 }
 _RESTYPES = {"tcavt_last_error": ctypes.c_char_p}
 

@@ -12,8 +12,10 @@ namespace tcavt {
 // 64x64 tile, 16x16 threads, 4x4 outputs per thread, K-tile 16 staged
 // transposed in LDS ([k][row], +1 pad) so the inner loop reads float4 rows.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long lda,
-                                                       const float* __restrict__ W, long ldw,
+// General strides: A[m][k] = A[m*rsA + k*csA], W[n][k] = W[n*rsW + k*csW], so the same kernel
+// serves y = x W^T (forward), gx = gy W and gW = gy^T x (backward) without physical transposes.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long rsA, long csA,
+                                                       const float* __restrict__ W, long rsW, long csW,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ res, long ldr,
                                                        float* __restrict__ C, long ldc, int M, int N,
@@ -35,8 +37,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int e = 0; e < 4; ++e) {
       const int k = k0 + lk + e;
       const int m = m0 + lr, n = n0 + lr;
-      As[lk + e][lr] = (m < M && k < K) ? A[(long)m * lda + k] : 0.f;
-      Ws[lk + e][lr] = (n < N && k < K) ? W[(long)n * ldw + k] : 0.f;
+      As[lk + e][lr] = (m < M && k < K) ? A[(long)m * rsA + (long)k * csA] : 0.f;
+      Ws[lk + e][lr] = (n < N && k < K) ? W[(long)n * rsW + (long)k * csW] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -98,7 +100,7 @@ __global__ void masked_mean_kernel(const float* __restrict__ enc, const int* __r
 __global__ void ltsf_front_kernel(const float* __restrict__ x, const float* __restrict__ cw,
                                   const float* __restrict__ cb, const float* __restrict__ ew,
                                   const float* __restrict__ eb, const float* __restrict__ pos,
-                                  float* __restrict__ tok, int B, int C, int T) {
+                                  float* __restrict__ tok, float* __restrict__ xp_tok, int B, int C, int T) {
   extern __shared__ float xs[];  // [2][T]
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) xs[i] = x[(long)b * 2 * T + i];
@@ -114,6 +116,8 @@ __global__ void ltsf_front_kernel(const float* __restrict__ x, const float* __re
       acc = fmaf(wr[t], xp - last, acc);
     }
     tok[((long)b * T + s) * C + c] = acc + eb[c * T + s] + last + pos[c * T + s];
+    // training: also keep the projected input xp[b][s][c] (token-major) for the backward
+    if (xp_tok) xp_tok[((long)b * T + s) * C + c] = fmaf(w1, xs[T + s], fmaf(w0, xs[s], 0.f)) + bb;
   }
 }
 
@@ -228,9 +232,23 @@ extern "C" int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
   TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32: unsupported flag");
   dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)lda, W,
-                     (long)ldw, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)lda, 1L, W,
+                     (long)ldw, 1L, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
   TCAVT_CHECK_LAUNCH("gemm_f32");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, const float* W, int64_t rsW,
+                                      int64_t csW, const float* bias, const float* residual, int64_t ldr, float* C,
+                                      int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0, "gemm_f32_strided: null pointer or bad shape");
+  TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32_strided: BIAS without bias");
+  TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32_strided: RESIDUAL without residual");
+  TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32_strided: unsupported flag");
+  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)rsA, (long)csA, W,
+                     (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
+  TCAVT_CHECK_LAUNCH("gemm_f32_strided");
   return TCAVT_OK;
 }
 
@@ -255,11 +273,11 @@ extern "C" int tcavt_masked_mean(const float* enc, const int32_t* len, float* em
 
 extern "C" int tcavt_ltsf_front(const float* x, const float* conv_w, const float* conv_b,
                                 const float* enc_w, const float* enc_b, const float* pos,
-                                float* enc_tok, int B, int C, int T, tcavt_stream_t stream) {
+                                float* enc_tok, float* xp_tok, int B, int C, int T, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && conv_w && conv_b && enc_w && enc_b && pos && enc_tok && B > 0 && C > 0 && T > 0,
                   "ltsf_front: bad args");
   hipLaunchKernelGGL(ltsf_front_kernel, dim3(B), dim3(256), 2 * T * sizeof(float),
-                     static_cast<hipStream_t>(stream), x, conv_w, conv_b, enc_w, enc_b, pos, enc_tok, B, C, T);
+                     static_cast<hipStream_t>(stream), x, conv_w, conv_b, enc_w, enc_b, pos, enc_tok, xp_tok, B, C, T);
   TCAVT_CHECK_LAUNCH("ltsf_front");
   return TCAVT_OK;
 }

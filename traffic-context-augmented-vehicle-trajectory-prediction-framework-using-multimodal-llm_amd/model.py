@@ -148,8 +148,11 @@ def _prep_layer(layer, bf16, decoder=False):
 class _TLayerRunner:
     """Runs post-LN layers on token matrices [M, D] (fp32 master copy x, bf16 shadow xb)."""
 
-    def __init__(self, ws, bf16, nhead, tag):
+    def __init__(self, ws, bf16, nhead, tag, record=None):
         self.ws, self.bf16, self.nhead, self.tag = ws, bf16, nhead, tag
+        # training: `record` (a list) receives one dict of retained activations per encoder layer, and
+        # `layer_tag` gives every layer its own buffers instead of recycling them
+        self.record, self.layer_tag = record, ""
 
     def _gemm(self, a, w, **kw):
         if self.bf16:
@@ -158,7 +161,7 @@ class _TLayerRunner:
         return ops.gemm_f32(a, w, **kw)
 
     def _buf(self, name, shape, dtype, dev):
-        return self.ws.get(f"{self.tag}.{name}", shape, dtype, dev)
+        return self.ws.get(f"{self.tag}{self.layer_tag}.{name}", shape, dtype, dev)
 
     def self_attn(self, p, x, xb, B, L, key_len):
         """returns y = x + out_proj(MHA(x)) (fp32 [M, E])"""
@@ -202,7 +205,7 @@ class _TLayerRunner:
         act_dt = torch.bfloat16 if self.bf16 else torch.float32
         f = self._buf("ffh", (M, ff), act_dt, dev)
         self._gemm(xb if self.bf16 else x, p.w1, out=f, bias=p.b1, relu=True, out_dtype=act_dt)
-        y = self._buf("y", (M, x.shape[1]), torch.float32, dev)
+        y = self._buf("y2", (M, x.shape[1]), torch.float32, dev)
         self._gemm(f, p.w2, out=y, bias=p.b2, residual=x, out_dtype=torch.float32)
         return y
 
@@ -210,7 +213,15 @@ class _TLayerRunner:
         y = self.self_attn(p.sa, x, xb, B, L, key_len)
         x1, x1b = self.norm(y, p.n1, f"x1_{slot}")
         y2 = self.ffn(p, x1, x1b)
-        return self.norm(y2, p.n2, f"x2_{slot}")
+        out = self.norm(y2, p.n2, f"x2_{slot}")
+        if self.record is not None:
+            M, E = x.shape
+            dev = x.device
+            self.record.append(dict(
+                x=x, y=y, x1=x1, y2=y2, qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev),
+                att=self._buf("att", (M, E), torch.bfloat16 if self.bf16 else torch.float32, dev),
+                f=self._buf("ffh", (M, p.w1.shape[0]), torch.bfloat16 if self.bf16 else torch.float32, dev)))
+        return out
 
     def decoder_layer(self, p, x, xb, mem, memb, B, Lq, Lk, slot=0):
         y = self.self_attn(p.sa, x, xb, B, Lq, None)
@@ -233,6 +244,8 @@ class LanePolygonEncoder(nn.Module, _Prepared):
         self.pos_embedding = _p(1, max_points, d_model)
         self._ws = _Workspace()
         self._prep = None
+        self.save_for_backward = False  # set by training.Trainer: keep per-layer activations
+        self.saved = None
 
     def _prepare(self):
         return [_prep_layer(l, bf16=False) for l in self.encoder.layers]
@@ -242,15 +255,21 @@ class LanePolygonEncoder(nn.Module, _Prepared):
         dev, D = polygon_batch.device, self.d_model
         lens = poly_len_list if torch.is_tensor(poly_len_list) else torch.tensor(list(poly_len_list), dtype=torch.int32)
         lens = lens.to(device=dev, dtype=torch.int32).contiguous()
-        run = _TLayerRunner(self._ws, bf16=False, nhead=self.nhead, tag="poly")
+        keep = self.save_for_backward
+        run = _TLayerRunner(self._ws, bf16=False, nhead=self.nhead, tag="poly", record=[] if keep else None)
         x = self._ws.get("poly.x0", (B * P, D), torch.float32, dev)
-        ops.poly_embed(polygon_batch.contiguous(), self.input_proj.weight, self.input_proj.bias,
+        polygon_batch = polygon_batch.contiguous()
+        ops.poly_embed(polygon_batch, self.input_proj.weight, self.input_proj.bias,
                        self.pos_embedding[0, :P].contiguous(), x)
         xb = None
         for i, p in enumerate(self._prepared()):
+            if keep:
+                run.layer_tag = f".L{i}"
             x, xb = run.encoder_layer(p, x, xb, B, P, key_len=lens, slot=i & 1)
         emb = torch.empty((B, D), dtype=torch.float32, device=dev)
         ops.masked_mean(x, lens, emb, B, P, D)
+        if keep:
+            self.saved = SimpleNamespace(layers=run.record, lens=lens, polygon=polygon_batch, out=x, B=B, P=P)
         return emb
 
 
@@ -641,6 +660,7 @@ class TransformerLTSF(nn.Module, _Prepared):
                                            cross_nhead, output_feature_dim)
         self._ws = _Workspace()
         self._prep = None
+        self.save_for_backward = False  # set by training.Trainer
 
     def _prepare(self):
         dec, C = self.decoder, self.d_model
@@ -667,7 +687,8 @@ class TransformerLTSF(nn.Module, _Prepared):
         L, H = final_hidden.shape[1], final_hidden.shape[2]
         x = x.contiguous()
         tok = ws.get("lt.tok", (B * T, C), torch.float32, dev)
-        ops.ltsf_front(x, P.conv_w, self.token_proj.bias, P.enc_w, P.enc_b, P.pos, tok, B, C, T)
+        xp_tok = ws.get("lt.xp", (B * T, C), torch.float32, dev) if self.save_for_backward else None
+        ops.ltsf_front(x, P.conv_w, self.token_proj.bias, P.enc_w, P.enc_b, P.pos, tok, B, C, T, xp_tok=xp_tok)
         e = self.attn_block.forward_tokens(tok, B, T)
         lane = ws.get("lt.lane", (B, C * To), torch.float32, dev)
         ops.gemm_f32(lane_polygon_emb.contiguous(), dec.lane_fc.weight, out=lane, bias=dec.lane_fc.bias)

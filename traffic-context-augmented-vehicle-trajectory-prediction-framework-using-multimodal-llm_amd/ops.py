@@ -278,12 +278,13 @@ def masked_mean(enc, lens, out, B, P, D):
     check(lib().tcavt_masked_mean(ptr(enc), ptr(lens), ptr(out), B, P, D, stream_ptr()), "tcavt_masked_mean")
 
 
-def ltsf_front(x, conv_w, conv_b, enc_w, enc_b, pos, out, B, C, T):
+def ltsf_front(x, conv_w, conv_b, enc_w, enc_b, pos, out, B, C, T, xp_tok=None):
+    _need(xp_tok, B * T * C, "ltsf_front.xp_tok")
     for t, n, nm in ((x, B * 2 * T, "x"), (conv_w, C * 2, "conv_w"), (conv_b, C, "conv_b"), (enc_w, C * T * T, "enc_w"),
                      (enc_b, C * T, "enc_b"), (pos, C * T, "pos"), (out, B * T * C, "out")):
         _need(t, n, "ltsf_front." + nm)
-    check(lib().tcavt_ltsf_front(ptr(x), ptr(conv_w), ptr(conv_b), ptr(enc_w), ptr(enc_b), ptr(pos), ptr(out), B, C,
-                                 T, stream_ptr()), "tcavt_ltsf_front")
+    check(lib().tcavt_ltsf_front(ptr(x), ptr(conv_w), ptr(conv_b), ptr(enc_w), ptr(enc_b), ptr(pos), ptr(out),
+                                 ptr(xp_tok), B, C, T, stream_ptr()), "tcavt_ltsf_front")
 
 
 def ltsf_decode(e_tok, dec_w, dec_b, lane_adj, out, B, C, T, To):
@@ -316,3 +317,151 @@ def traj_metrics(pred, gt, norm_stat, sums, argmin, per_sample, B, K, To):
         _need(t, n, "traj_metrics." + nm)
     check(lib().tcavt_traj_metrics(ptr(pred), ptr(gt), ptr(norm_stat), ptr(sums), ptr(argmin), ptr(per_sample), B,
                                    K, To, stream_ptr()), "tcavt_traj_metrics")
+
+
+# ----------------------------------------------------------------------------------------------
+# training-step kernels (include/tcavt.h, second half)
+# ----------------------------------------------------------------------------------------------
+def gemm_f32_strided(a, rsA, csA, w, rsW, csW, out, M, N, K, bias=None, relu=False, residual=None):
+    for t, rs, cs, rows, nm in ((a, rsA, csA, M, "a"), (w, rsW, csW, N, "w")):
+        if _avail(t) < (rows - 1) * rs + (K - 1) * cs + 1:
+            raise capi.TcavtError(f"gemm_f32_strided.{nm}: buffer too small")
+    if _avail(out) < (M - 1) * out.stride(0) + N:
+        raise capi.TcavtError("gemm_f32_strided.out: buffer too small")
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (
+        EPI_RESIDUAL if residual is not None else 0)
+    check(lib().tcavt_gemm_f32_strided(ptr(a), rsA, csA, ptr(w), rsW, csW, ptr(bias), ptr(residual),
+                                       residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), M, N,
+                                       K, flags, stream_ptr()), "tcavt_gemm_f32_strided")
+    return out
+
+
+def transpose16(x, out, rows, cols, rows_pad, ld_in=None, ld_out=None, batch=1, s_in=0, s_out=0):
+    """out[c][r] = x[r][c] (16-bit), zero-filled for r in [rows, rows_pad); batched with strides."""
+    ld_in = ld_in or x.stride(-2)
+    ld_out = ld_out or out.stride(-2)
+    if _avail(x) < (batch - 1) * s_in + (rows - 1) * ld_in + cols or \
+            _avail(out) < (batch - 1) * s_out + (cols - 1) * ld_out + rows_pad:
+        raise capi.TcavtError("transpose16: buffer too small")
+    if x.element_size() != 2 or out.element_size() != 2:
+        raise capi.TcavtError("transpose16: 16-bit tensors only")
+    check(lib().tcavt_transpose16(ptr(x), ld_in, ptr(out), ld_out, rows, cols, rows_pad, batch, s_in, s_out,
+                                  stream_ptr()), "tcavt_transpose16")
+    return out
+
+
+def transpose_f32_bf16(x, out, rows, cols, rows_pad):
+    _req(x, torch.float32, "transpose_f32_bf16.x")
+    if _avail(x) < (rows - 1) * x.stride(0) + cols or _avail(out) < (cols - 1) * out.stride(0) + rows_pad:
+        raise capi.TcavtError("transpose_f32_bf16: buffer too small")
+    check(lib().tcavt_transpose_f32_bf16(ptr(x), x.stride(0), ptr(out), out.stride(0), rows, cols, rows_pad,
+                                         stream_ptr()), "tcavt_transpose_f32_bf16")
+    return out
+
+
+def colsum(g, out, M, N, accumulate=False):
+    _need(out, N, "colsum.out")
+    if _avail(g) < (M - 1) * g.stride(0) + N:
+        raise capi.TcavtError("colsum.g: buffer too small")
+    check(lib().tcavt_colsum(ptr(g), g.stride(0), _DT[g.dtype], ptr(out), M, N, int(accumulate), stream_ptr()),
+          "tcavt_colsum")
+
+
+def relu_bwd(g, y):
+    _req(g, torch.float32, "relu_bwd.g")
+    _need(y, g.numel(), "relu_bwd.y")
+    check(lib().tcavt_relu_bwd(ptr(g), ptr(y), _DT[y.dtype], g.numel(), stream_ptr()), "tcavt_relu_bwd")
+
+
+def add_inplace(a, b):
+    _req(a, torch.float32, "add_inplace.a")
+    _req(b, torch.float32, "add_inplace.b")
+    _need(b, a.numel(), "add_inplace.b")
+    check(lib().tcavt_add_inplace(ptr(a), ptr(b), a.numel(), stream_ptr()), "tcavt_add_inplace")
+
+
+def layernorm_bwd(x, gamma, gy, gx, ggamma, gbeta, eps=1e-5):
+    M, D = x.shape
+    for t, n, nm in ((gamma, D, "gamma"), (gy, M * D, "gy"), (gx, M * D, "gx"), (ggamma, D, "ggamma"), (gbeta, D, "gbeta")):
+        _req(t, torch.float32, "layernorm_bwd." + nm)
+        _need(t, n, "layernorm_bwd." + nm)
+    check(lib().tcavt_layernorm_bwd(ptr(x), ptr(gamma), ptr(gy), eps, ptr(gx), ptr(ggamma), ptr(gbeta), M, D,
+                                    stream_ptr()), "tcavt_layernorm_bwd")
+
+
+def mha_bwd(q, k, v, go, gq, gk, gv, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None,
+            ldg=None):
+    E = nh * dh
+    lq, lk, lv, lo, lg = (ldq or q.stride(-2)), (ldk or k.stride(-2)), (ldv or v.stride(-2)), (ldo or go.stride(-2)), (
+        ldg or gq.stride(-2))
+    for t, rows, ld, nm in ((q, B * Lq, lq, "q"), (k, B * Lk, lk, "k"), (v, B * Lk, lv, "v"), (go, B * Lq, lo, "go"),
+                            (gq, B * Lq, lg, "gq"), (gk, B * Lk, lg, "gk"), (gv, B * Lk, lg, "gv")):
+        if t.dtype != torch.float32 or _avail(t) < (rows - 1) * ld + E:
+            raise capi.TcavtError(f"mha_bwd.{nm}: fp32 buffer with {rows} rows of stride {ld} required")
+    _need(key_len, B, "mha_bwd.key_len")
+    check(lib().tcavt_mha_bwd(ptr(q), lq, ptr(k), lk, ptr(v), lv, ptr(go), lo, ptr(gq), ptr(gk), ptr(gv), lg,
+                              ptr(key_len), B, Lq, Lk, nh, dh, scale, stream_ptr()), "tcavt_mha_bwd")
+
+
+def softmax_bwd_rows(p_f16, dP, dS, scale, rows, n_valid, n_out, ldp, ldd, lds):
+    if p_f16.dtype != torch.float16 or dP.dtype != torch.float32 or dS.dtype != torch.bfloat16:
+        raise capi.TcavtError("softmax_bwd_rows: P fp16, dP fp32, dS bf16 required")
+    if _avail(p_f16) < (rows - 1) * ldp + n_valid or _avail(dP) < (rows - 1) * ldd + n_valid or \
+            _avail(dS) < (rows - 1) * lds + n_out:
+        raise capi.TcavtError("softmax_bwd_rows: buffer too small")
+    check(lib().tcavt_softmax_bwd_rows(ptr(p_f16), ldp, ptr(dP), ldd, ptr(dS), lds, scale, rows, n_valid, n_out,
+                                       stream_ptr()), "tcavt_softmax_bwd_rows")
+
+
+def mse_grad(pred, gt, norm_stat, g, B, To):
+    for t, n, nm in ((pred, B * 2 * To, "pred"), (gt, B * 2 * To, "gt"), (norm_stat, B * 4, "norm_stat"), (g, B * 2 * To, "g")):
+        _req(t, torch.float32, "mse_grad." + nm)
+        _need(t, n, "mse_grad." + nm)
+    check(lib().tcavt_mse_grad(ptr(pred), ptr(gt), ptr(norm_stat), ptr(g), B, To, stream_ptr()), "tcavt_mse_grad")
+
+
+def out_head_bwd(g, fused, w, gf, gw, gb, B, To, C, F):
+    for t, n, nm in ((g, B * F * To, "g"), (fused, B * To * C, "fused"), (w, F * C, "w"), (gf, B * To * C, "gf"),
+                     (gw, F * C, "gw"), (gb, F, "gb")):
+        _need(t, n, "out_head_bwd." + nm)
+    check(lib().tcavt_out_head_bwd(ptr(g), ptr(fused), ptr(w), ptr(gf), ptr(gw), ptr(gb), B, To, C, F, stream_ptr()),
+          "tcavt_out_head_bwd")
+
+
+def nlinear_bwd(in_tok, W, g, g_strides, gW, gbias, gin_tok, B, C, T, S):
+    sb, sc, ss = g_strides
+    for t, n, nm in ((in_tok, B * T * C, "in_tok"), (W, C * S * T, "W"), (gW, C * S * T, "gW"), (gbias, C * S, "gbias"),
+                     (gin_tok, B * T * C, "gin_tok")):
+        _need(t, n, "nlinear_bwd." + nm)
+    if _avail(g) < (B - 1) * sb + (C - 1) * sc + (S - 1) * ss + 1:
+        raise capi.TcavtError("nlinear_bwd.g: buffer too small")
+    check(lib().tcavt_nlinear_bwd(ptr(in_tok), ptr(W), ptr(g), sb, sc, ss, ptr(gW), ptr(gbias), ptr(gin_tok), B, C, T, S,
+                                  stream_ptr()), "tcavt_nlinear_bwd")
+
+
+def conv1x1_bwd(gxp_tok, x, gw, gb, B, C, T, F):
+    for t, n, nm in ((gxp_tok, B * T * C, "gxp_tok"), (x, B * F * T, "x"), (gw, C * F, "gw"), (gb, C, "gb")):
+        _need(t, n, "conv1x1_bwd." + nm)
+    check(lib().tcavt_conv1x1_bwd(ptr(gxp_tok), ptr(x), ptr(gw), ptr(gb), B, C, T, F, stream_ptr()), "tcavt_conv1x1_bwd")
+
+
+def poly_embed_bwd(g, polygon, gw, gb, gpos, B, P, D):
+    for t, n, nm in ((g, B * P * D, "g"), (polygon, B * P * 2, "polygon"), (gw, D * 2, "gw"), (gb, D, "gb"), (gpos, P * D, "gpos")):
+        _need(t, n, "poly_embed_bwd." + nm)
+    check(lib().tcavt_poly_embed_bwd(ptr(g), ptr(polygon), ptr(gw), ptr(gb), ptr(gpos), B, P, D, stream_ptr()),
+          "tcavt_poly_embed_bwd")
+
+
+def masked_mean_bwd(gemb, lens, genc, B, P, D):
+    for t, n, nm in ((gemb, B * D, "gemb"), (lens, B, "lens"), (genc, B * P * D, "genc")):
+        _need(t, n, "masked_mean_bwd." + nm)
+    check(lib().tcavt_masked_mean_bwd(ptr(gemb), ptr(lens), ptr(genc), B, P, D, stream_ptr()), "tcavt_masked_mean_bwd")
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    n = p.numel()
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, "adamw." + nm)
+        _need(t, n, "adamw." + nm)
+    check(lib().tcavt_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, weight_decay, int(step),
+                            grad_scale, stream_ptr()), "tcavt_adamw")

@@ -1,0 +1,99 @@
+"""Training step of scripts/train.py on the HIP path (train.py:1140-1145, 1168-1184).
+
+    zero_grad -> forward (loss) -> backward -> [DDP gradient all-reduce] -> AdamW(lr 5e-4, wd 1e-4)
+
+Trainable set = everything outside ``mllm`` (the MLLM is frozen after the DDP wrap, train.py:1141-1142):
+lane-polygon encoder + TransformerLTSF, 18.1 M parameters at the Llama-3.2-1B shape.  They live in ONE
+flat fp32 vector (backward.GradBook) so that the optimizer is a single fused kernel and the data-parallel
+gradient exchange is a few large all-reduces over RCCL/xGMI on a side stream, launched as soon as a
+contiguous bucket of the flat gradient is complete and overlapped with the rest of the backward
+(reference: DistributedDataParallel's bucketed all-reduce, train.py:1127-1132; DDP averages gradients,
+which is folded into the AdamW kernel as grad_scale = 1/world).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .backward import Backward, GradBook
+
+
+def trainable_named_parameters(model):
+    """Ordered by readiness in the backward: LTSF first (its head and cross-attention gradients are
+    produced first), lane-polygon encoder last."""
+    ltsf = [(n, p) for n, p in model.named_parameters() if n.startswith("ltsf.")]
+    poly = [(n, p) for n, p in model.named_parameters() if n.startswith("lane_polygon_encoder.")]
+    return ltsf + poly
+
+
+class Trainer:
+    def __init__(self, model, lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.model = model
+        dev = next(model.parameters()).device
+        named = trainable_named_parameters(model)
+        for p in model.mllm.parameters():  # train.py:1141-1142
+            p.requires_grad_(False)
+        self.book = GradBook(named, dev)
+        self.n_ltsf = self.book.end_of([n for n, _ in named if n.startswith("ltsf.")][-1])
+        self.m = torch.zeros_like(self.book.params)
+        self.v = torch.zeros_like(self.book.params)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.step_count = 0
+        self.bw = Backward(model, self.book)
+        model.lane_polygon_encoder.save_for_backward = True
+        model.ltsf.save_for_backward = True
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        model.invalidate_prepared()
+
+    # ---- gradient exchange ------------------------------------------------------------------
+    def _allreduce_bucket(self, lo, hi):
+        """SUM all-reduce of grads[lo:hi] on the communication stream (mean folded into AdamW)."""
+        if self.world == 1:
+            return
+        view = self.book.grads[lo:hi]
+        if self.comm_stream is None:  # CPU / gloo rehearsal
+            dist.all_reduce(view, group=self.pg)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        self.comm_stream.wait_event(ready)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(view, group=self.pg)
+
+    def _wait_comm(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    # ---- one optimisation step -----------------------------------------------------------------
+    def forward_backward(self, x, vision_embs, lane_polygon_batch, lane_polygon_len, y, norm_stat, input_ids,
+                         attention_mask, labels=None):
+        """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``."""
+        m = self.model
+        with torch.no_grad():
+            self.book.grads.zero_()  # optimizer.zero_grad()
+            loss, decoded = m(x, vision_embs, None, lane_polygon_batch, lane_polygon_len, y=y, norm_stat=norm_stat,
+                              input_ids=input_ids, attention_mask=attention_mask, labels=labels)
+            ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat])
+            ns = ns.to(device=x.device, dtype=torch.float32).contiguous()
+            B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
+            fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), torch.bfloat16, x.device)
+            self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
+                        after_ltsf=lambda: self._allreduce_bucket(0, self.n_ltsf))
+            self._allreduce_bucket(self.n_ltsf, self.book.total)
+            self._wait_comm()
+        return loss, decoded
+
+    def optimizer_step(self):
+        m = self.model
+        with torch.no_grad():
+            self.step_count += 1
+            ops.adamw(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world)
+            # bf16 shadows / stacked copies of the trainable weights are stale now
+            m.ltsf._invalidate()
+
+    def step(self, *args, **kw):
+        out = self.forward_backward(*args, **kw)
+        self.optimizer_step()
+        return out
