@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--mode", choices=["train", "forward"], default="train",
+                    help="train: zero_grad + forward + backward + grad all-reduce + AdamW (train.py:1168-1183); "
+                         "forward: MultiModalTrajectoryModel.forward incl. loss only (test.py / validation)")
     return ap.parse_args()
 
 
@@ -91,11 +94,22 @@ def cpu_baseline(cfg, args):
     b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True, min_text=128)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
 
+    train = args.mode == "train"
+    if train:  # autograd over exactly the parameters train.py trains (everything outside mllm)
+        for k, v in W.items():
+            if not k.startswith("mllm."):
+                v.requires_grad_(True)
+
     def run(labels):
-        with torch.no_grad():
-            return O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
-                                   t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
-                                   contract="fp32", labels=labels)
+        with torch.set_grad_enabled(train):
+            loss, dec = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
+                                        t["lane_polygon_len"], t["input_ids"], t["attention_mask"], y=t["target_traj"],
+                                        norm_stat=t["norm_stat"], contract="fp32", labels=labels)
+            if train:
+                loss.backward()
+                for k, v in W.items():
+                    v.grad = None
+            return loss
 
     def timed(labels, n):
         run(labels)  # warm
@@ -112,8 +126,9 @@ def cpu_baseline(cfg, args):
     faithful = timed(t["labels"], 2)
     return {
         "value": round(args.cpu_batch / same_work, 4), "unit": "trajectories/sec", "cores": cores, "kind": "port",
-        "sample": f"{args.cpu_batch} samples of the same workload (L={16 + args.text_len}, fp32, torch CPU ops), "
-                  f"median of 3 after 1 warm-up; same work as the GPU path (no lm_head/CE)",
+        "sample": f"{args.cpu_batch} samples of the same workload (L={16 + args.text_len}, fp32, torch CPU ops"
+                  f"{', forward + autograd backward of the trainable part' if train else ''}), "
+                  f"median of 3 after 1 warm-up; same work as the GPU path (no lm_head/CE, no optimizer step)",
         "reference_faithful_value": round(args.cpu_batch / faithful, 4),
         "reference_faithful_note": "adds the lm_head + cross-entropy the reference computes and discards (train.py:547-554)",
     }
@@ -132,7 +147,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from tcavt_amd import capi, config, model, synth
+    from tcavt_amd import capi, config, model, synth, training
     from tcavt_amd.profiling import KernelTimer
     from tcavt_amd.weights import make_weights
 
@@ -155,7 +170,12 @@ def main():
     b = synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank, ragged=True, min_text=128)
     g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
+    trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4) if args.mode == "train" else None
+
     def step():
+        if trainer is not None:
+            return trainer.step(g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"],
+                                g["target_traj"], g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"])
         return m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], y=g["target_traj"],
                  norm_stat=g["norm_stat"], input_ids=g["input_ids"], attention_mask=g["attention_mask"],
                  labels=g["labels"])
@@ -170,7 +190,7 @@ def main():
         log(f"setup + first step done in {setup_s:.1f} s; loss {loss.item():.3f}")
 
         graph = None
-        if not args.no_graph:
+        if not args.no_graph and world == 1:  # multi-rank: RCCL all-reduces are launched eagerly
             # hipGraph capture of the whole step (all launches are stream-ordered, allocation-free
             # after the first call): removes per-launch host cost from the timed loop
             s = torch.cuda.Stream()
@@ -243,8 +263,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": "MultiModalTrajectoryModel.forward incl. loss (train.py:914-964), eval arithmetic; "
-                            "Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head",
+                "workload": ("train.py step (:1168-1183): zero_grad + MultiModalTrajectoryModel.forward incl. loss "
+                             "(:914-964) + backward through the trainable part (LTSF + lane-polygon encoder; MLLM "
+                             "frozen, :1140-1145) + gradient all-reduce + AdamW(lr 5e-4, wd 1e-4)"
+                             if args.mode == "train" else
+                             "MultiModalTrajectoryModel.forward incl. loss (train.py:914-964)")
+                            + "; Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head; dropout off",
+                "mode": args.mode,
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
                 "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",
                 "launch": "eager" if graph is None else "hipGraph replay",

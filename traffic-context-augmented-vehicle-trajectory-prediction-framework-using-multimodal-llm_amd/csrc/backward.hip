@@ -64,19 +64,17 @@ __device__ __forceinline__ float ldv<bf16_t>(const bf16_t* p) { return bf16_to_f
 
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, long ld, float* __restrict__ out,
-                                                     int M, int N, int accumulate) {
+                                                     int M, int N, int rows_per_block) {
   __shared__ float part[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + tx;
+  const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
   float s = 0.f;
   if (n < N)
-    for (int m = ty; m < M; m += 4) s += ldv<T>(g + (long)m * ld + n);
+    for (int m = m_lo + ty; m < m_hi; m += 4) s += ldv<T>(g + (long)m * ld + n);
   part[ty][tx] = s;
   __syncthreads();
-  if (ty == 0 && n < N) {
-    const float t = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
-    out[n] = accumulate ? out[n] + t : t;
-  }
+  if (ty == 0 && n < N) atomicAdd(&out[n], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
 }
 
 // g[i] = y[i] > 0 ? g[i] : 0      (ReLU backward against the saved post-activation)
@@ -267,8 +265,7 @@ __global__ void mse_grad_kernel(const float* __restrict__ pred, const float* __r
 // out_head backward: out[b][f][s] = w[f].fused[b][s] + bias[f] (+x_last)
 //   gf[b][s][c] = sum_f g[b][f][s] w[f][c];  gw[f][c] = sum_{b,s} g[b][f][s] fused[b][s][c];  gb[f] = sum g
 __global__ __launch_bounds__(256) void out_head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ fused,
-                                                           const float* __restrict__ w, float* __restrict__ gf,
-                                                           float* __restrict__ gw, float* __restrict__ gb, int B,
+                                                           const float* __restrict__ w, float* __restrict__ gf, int B,
                                                            int To, int C, int F) {
   const int n = B * To * C;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
@@ -277,20 +274,27 @@ __global__ __launch_bounds__(256) void out_head_bwd_kernel(const float* __restri
     for (int f = 0; f < F; ++f) a = fmaf(g[((long)b * F + f) * To + s], w[f * C + c], a);
     gf[idx] = a;
   }
-  if (blockIdx.x == 0) {
-    for (int fc = threadIdx.x; fc < F * C; fc += blockDim.x) {
-      const int f = fc / C, c = fc % C;
-      float a = 0.f;
-      for (int b = 0; b < B; ++b)
-        for (int s = 0; s < To; ++s) a = fmaf(g[((long)b * F + f) * To + s], fused[((long)b * To + s) * C + c], a);
-      gw[fc] = a;
+}
+
+// one wave per (f, c) for gw, one per f for gb
+__global__ __launch_bounds__(64) void out_head_bwd_w_kernel(const float* __restrict__ g, const float* __restrict__ fused,
+                                                            float* __restrict__ gw, float* __restrict__ gb, int B,
+                                                            int To, int C, int F) {
+  const int id = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f;
+  if (id < F * C) {
+    const int f = id / C, c = id % C;
+    for (int i = lane; i < B * To; i += 64) {
+      const int b = i / To, s = i % To;
+      a = fmaf(g[((long)b * F + f) * To + s], fused[(long)i * C + c], a);
     }
-    for (int f = threadIdx.x; f < F; f += blockDim.x) {
-      float a = 0.f;
-      for (int b = 0; b < B; ++b)
-        for (int s = 0; s < To; ++s) a += g[((long)b * F + f) * To + s];
-      gb[f] = a;
-    }
+    a = wave_sum(a);
+    if (lane == 0) gw[id] = a;
+  } else {
+    const int f = id - F * C;
+    for (int i = lane; i < B * To; i += 64) a += g[((long)(i / To) * F + f) * To + (i % To)];
+    a = wave_sum(a);
+    if (lane == 0) gb[f] = a;
   }
 }
 
@@ -459,13 +463,21 @@ extern "C" int tcavt_transpose_f32_bf16(const float* in, int64_t ld_in, void* ou
 extern "C" int tcavt_colsum(const void* g, int64_t ld, int dtype, float* out, int M, int N, int accumulate,
                             tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(g && out && M > 0 && N > 0 && ld >= N, "colsum: bad args");
-  dim3 grid((N + 63) / 64);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), S_(stream));
+    if (e != hipSuccess) {
+      set_error("colsum: hipMemsetAsync failed: %s", hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+  }
+  const int rpb = 128;  // rows per block: partial sums meet in `out` through float atomics
+  dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
   if (dtype == TCAVT_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, S_(stream), static_cast<const float*>(g), (long)ld, out,
-                       M, N, accumulate);
+                       M, N, rpb);
   else if (dtype == TCAVT_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, S_(stream), static_cast<const bf16_t*>(g), (long)ld,
-                       out, M, N, accumulate);
+                       out, M, N, rpb);
   else {
     set_error("colsum: dtype must be f32 or bf16");
     return TCAVT_ERR_ARG;
@@ -538,8 +550,8 @@ extern "C" int tcavt_out_head_bwd(const float* g, const float* fused, const floa
                                   int B, int To, int C, int F, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(g && fused && w && gf && gw && gb && B > 0 && To > 0 && C > 0 && F > 0, "out_head_bwd: bad args");
   const int n = B * To * C;
-  hipLaunchKernelGGL(out_head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, S_(stream), g, fused, w, gf, gw, gb, B,
-                     To, C, F);
+  hipLaunchKernelGGL(out_head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, S_(stream), g, fused, w, gf, B, To, C, F);
+  hipLaunchKernelGGL(out_head_bwd_w_kernel, dim3(F * C + F), dim3(64), 0, S_(stream), g, fused, gw, gb, B, To, C, F);
   TCAVT_CHECK_LAUNCH("out_head_bwd");
   return TCAVT_OK;
 }

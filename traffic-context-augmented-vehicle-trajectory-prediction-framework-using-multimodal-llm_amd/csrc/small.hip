@@ -8,65 +8,93 @@
 namespace tcavt {
 
 // ---------------------------------------------------------------------------
-// C[M,N] = A[M,K] . W[N,K]^T (+bias)(+relu)(+residual), fp32 FMA in k order.
-// 64x64 tile, 16x16 threads, 4x4 outputs per thread, K-tile 16 staged
-// transposed in LDS ([k][row], +1 pad) so the inner loop reads float4 rows.
+// C[M,N] = A[M,K] . W[N,K]^T (+bias)(+relu)(+residual) in exact fp32 on the matrix cores:
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; bit-for-bit an fmaf chain per output).
+// General element strides: A[m][k] = A[m*rsA + k*csA], W[n][k] = W[n*rsW + k*csW], so the same
+// kernel serves y = x W^T (forward), gx = gy W and gW = gy^T x (backward) without transposes.
+// 64x64 tile, 4 waves (2x2) of 32x32, K-step 16 staged through LDS ([row][k], 17-float rows);
+// global->register prefetch of step s+1 overlaps the MFMAs of step s.  The global read pattern
+// follows the operand's contiguous direction (lanes walk k when csX == 1, rows otherwise).
 // ---------------------------------------------------------------------------
-// General strides: A[m][k] = A[m*rsA + k*csA], W[n][k] = W[n*rsW + k*csW], so the same kernel
-// serves y = x W^T (forward), gx = gy W and gW = gy^T x (backward) without physical transposes.
+__device__ __forceinline__ void gemm_f32_fetch(const float* __restrict__ X, long rs, long cs, int r0, int R, int k0,
+                                               int K, int tid, bool kfast, float (&v)[4], int (&row)[4], int (&kk)[4]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = e * 256 + tid;  // 0..1023 over the 64x16 tile
+    const int r = kfast ? (idx >> 4) : (idx & 63);
+    const int k = kfast ? (idx & 15) : (idx >> 6);
+    row[e] = r;
+    kk[e] = k;
+    const int gr = r0 + r, gk = k0 + k;
+    v[e] = (gr < R && gk < K) ? X[(long)gr * rs + (long)gk * cs] : 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long rsA, long csA,
                                                        const float* __restrict__ W, long rsW, long csW,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ res, long ldr,
                                                        float* __restrict__ C, long ldc, int M, int N,
                                                        int K, int flags) {
-  __shared__ __attribute__((aligned(16))) float As[16][68];
-  __shared__ __attribute__((aligned(16))) float Ws[16][68];
-  const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  __shared__ float As[64][17];
+  __shared__ float Ws[64][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4];
+  const bool akf = csA <= rsA, wkf = csW <= rsW;
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-
-  const int lr = tid >> 2, lk = (tid & 3) * 4;  // row 0..63, k offset 0,4,8,12
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float va[4], vw[4];
+  int ra[4], ka[4], rw[4], kw[4];
+  gemm_f32_fetch(A, rsA, csA, m0, M, 0, K, tid, akf, va, ra, ka);
+  gemm_f32_fetch(W, rsW, csW, n0, N, 0, K, tid, wkf, vw, rw, kw);
+  const int lr = lane & 15, lk = lane >> 4;
   for (int k0 = 0; k0 < K; k0 += 16) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = k0 + lk + e;
-      const int m = m0 + lr, n = n0 + lr;
-      As[lk + e][lr] = (m < M && k < K) ? A[(long)m * rsA + (long)k * csA] : 0.f;
-      Ws[lk + e][lr] = (n < N && k < K) ? W[(long)n * rsW + (long)k * csW] : 0.f;
+      As[ra[e]][ka[e]] = va[e];
+      Ws[rw[e]][kw[e]] = vw[e];
     }
     __syncthreads();
+    if (k0 + 16 < K) {
+      gemm_f32_fetch(A, rsA, csA, m0, M, k0 + 16, K, tid, akf, va, ra, ka);
+      gemm_f32_fetch(W, rsW, csW, n0, N, k0 + 16, K, tid, wkf, vw, rw, kw);
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[k][ty * 4]);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(&Ws[k][tx * 4]);
+    for (int ks = 0; ks < 4; ++ks) {
+      float af[2], wf[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i) af[i] = As[wm * 32 + i * 16 + lr][ks * 4 + lk];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) wf[j] = Ws[wn * 32 + j * 16 + lr][ks * 4 + lk];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], wf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
+  // D layout: column (n) = lane & 15, row (m) = 4 * (lane >> 4) + reg
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + lr;
       if (n >= N) continue;
-      float v = acc[i][j];
-      if (flags & TCAVT_EPI_BIAS) v += bias[n];
-      if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
-      if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
-      C[(long)m * ldc + n] = v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * lk + r;
+        if (m >= M) continue;
+        float v = acc[i][j][r];
+        if (flags & TCAVT_EPI_BIAS) v += bias[n];
+        if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
+        if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
+        C[(long)m * ldc + n] = v;
+      }
     }
-  }
 }
 
 // x[b][p][:] = W_in[:, 0]*px + W_in[:, 1]*py + b_in + pos[p]   (train.py:364-365)
