@@ -1,0 +1,90 @@
+"""Data-parallel path on CPU: 2 ranks over gloo (the N > 1 path of training.Trainer).
+
+Kernels cannot run here, so the C library is stubbed (as in test_host_dryrun.py); what is checked is
+the distributed logic itself: the flat gradient is exchanged in two buckets (LTSF first, lane-polygon
+encoder second) with SUM semantics, every element exactly once, and the optimizer receives
+grad_scale = 1/world (DDP's gradient averaging, reference train.py:1127-1132)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _StubLib:
+    def __init__(self):
+        self.calls = []
+
+    def __getattr__(self, name):
+        if not name.startswith("tcavt_"):
+            raise AttributeError(name)
+
+        def fn(*args):
+            self.calls.append((name, args))
+            return 0
+
+        return fn
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tcavt_amd import config, model, ops, training
+        from tcavt_amd.weights import make_weights
+
+        stub = _StubLib()
+        ops.lib = lambda: stub
+        ops.stream_ptr = lambda: None
+        ops._ALLOW_CPU = True
+        cfg = config.tiny()
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(make_weights(cfg, 0)).eval()
+        tr = training.Trainer(m)
+        assert tr.world == world and tr.comm_stream is None
+        n = tr.book.total
+        base = torch.arange(n, dtype=torch.float32) % 97
+        tr.book.grads.copy_(base * (rank + 1))
+        tr._allreduce_bucket(0, tr.n_ltsf)
+        tr._allreduce_bucket(tr.n_ltsf, n)
+        tr._wait_comm()
+        expect = base * sum(r + 1 for r in range(world))
+        ok_sum = torch.equal(tr.book.grads, expect)
+        tr.optimizer_step()
+        name, args = [c for c in stub.calls if c[0] == "tcavt_adamw"][-1]
+        grad_scale = args[-2]
+        # trainable set == everything outside mllm (train.py:1140-1145), flat order: ltsf then polygon encoder
+        names = tr.book.names
+        ok_names = all(k.startswith("ltsf.") for k in names[: sum(k.startswith("ltsf.") for k in names)]) and \
+            set(names) == {k for k, _ in m.named_parameters() if not k.startswith("mllm.")}
+        q.put((rank, ok_sum, abs(grad_scale - 1.0 / world) < 1e-9, ok_names, 0 < tr.n_ltsf < n))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+        raise
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_exchange_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in results:
+        assert len(r) == 5, r
+        assert all(r[1:]), r

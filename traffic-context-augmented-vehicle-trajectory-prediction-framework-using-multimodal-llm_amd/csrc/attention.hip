@@ -251,6 +251,79 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q
   }
 }
 
+// ---------------------------------------------------------------------------
+// Same contract as mha_small_kernel for the cases whose whole (batch, head) problem fits in LDS
+// (Q, K, V rows padded to dh+1 floats + the score matrix): one global read of q/k/v, everything
+// else out of LDS.  Used for the lane-polygon encoder (64x64, dh 16), the Q-Former (<= 18 keys,
+// dh 96) and the LTSF block (<= 30 tokens, dh 32).
+// ---------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void mha_lds_kernel(const TI* __restrict__ q, long ldq,
+                                                      const TI* __restrict__ k, long ldk,
+                                                      const TI* __restrict__ v, long ldv,
+                                                      TO* __restrict__ out, long ldo,
+                                                      const int* __restrict__ key_len, int Lq, int Lk,
+                                                      int nh, int dh, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ds = dh + 1;
+  float* Qs = reinterpret_cast<float*>(smem);
+  float* Ks = Qs + Lq * ds;
+  float* Vs = Ks + Lk * ds;
+  float* sc = Vs + Lk * ds;  // [Lq][Lk]
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const int klen = key_len ? min(key_len[b], Lk) : Lk;
+  const TI* qb = q + (long)b * Lq * ldq + h * dh;
+  const TI* kb = k + (long)b * Lk * ldk + h * dh;
+  const TI* vb = v + (long)b * Lk * ldv + h * dh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int id = tid; id < Lq * dh; id += 256) {
+    const int i = id / dh, d = id - i * dh;
+    Qs[i * ds + d] = ldf<TI>(qb + (long)i * ldq + d);
+  }
+  for (int id = tid; id < Lk * dh; id += 256) {
+    const int j = id / dh, d = id - j * dh;
+    Ks[j * ds + d] = ldf<TI>(kb + (long)j * ldk + d);
+    Vs[j * ds + d] = ldf<TI>(vb + (long)j * ldv + d);
+  }
+  __syncthreads();
+  for (int ij = tid; ij < Lq * Lk; ij += 256) {
+    const int i = ij / Lk, j = ij - i * Lk;
+    float acc = 0.f;
+    if (j < klen) {
+      const float* qr = Qs + i * ds;
+      const float* kr = Ks + j * ds;
+      for (int d = 0; d < dh; ++d) acc = fmaf(qr[d], kr[d], acc);
+    }
+    sc[ij] = (j < klen) ? acc * scale : -1e30f;
+  }
+  __syncthreads();
+  for (int i = wave; i < Lq; i += 4) {
+    float* row = sc + i * Lk;
+    float m = -1e30f;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, row[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+      const float e = (row[j] > -1e29f) ? __expf(row[j] - m) : 0.f;
+      row[j] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    for (int j = lane; j < Lk; j += 64) row[j] *= inv;
+  }
+  __syncthreads();
+  for (int id = tid; id < Lq * dh; id += 256) {
+    const int i = id / dh, d = id - i * dh;
+    const float* row = sc + i * Lk;
+    float acc = 0.f;
+    for (int j = 0; j < klen; ++j) acc = fmaf(row[j], Vs[j * ds + d], acc);
+    TO* o = out + ((long)b * Lq + i) * ldo + h * dh + d;
+    if constexpr (sizeof(TO) == 2) *o = f32_to_bf16(acc);
+    else *o = acc;
+  }
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -291,6 +364,23 @@ extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk,
   TCAVT_CHECK_ARG(lds <= 64 * 1024, "mha: Lq*Lk*4 = %ld bytes exceeds the 64 KiB score buffer", lds);
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(B * nh), block(256);
+  const long lds_all = ((long)(Lq + 2 * Lk) * (dh + 1) + (long)Lq * Lk) * 4;
+  if (lds_all <= 60 * 1024) {  // whole problem in LDS
+#define TCAVT_MHA_LDS(TI, TO)                                                                                   \
+  hipLaunchKernelGGL((mha_lds_kernel<TI, TO>), grid, block, lds_all, s, (const TI*)q, ldq, (const TI*)k, ldk, \
+                     (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale)
+    if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(float, float);
+    else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16) TCAVT_MHA_LDS(float, bf16_t);
+    else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(bf16_t, float);
+    else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_BF16) TCAVT_MHA_LDS(bf16_t, bf16_t);
+    else {
+      set_error("mha: bad dtype %d/%d", in_dtype, out_dtype);
+      return TCAVT_ERR_ARG;
+    }
+#undef TCAVT_MHA_LDS
+    TCAVT_CHECK_LAUNCH("mha(lds)");
+    return TCAVT_OK;
+  }
   if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32)
     hipLaunchKernelGGL((mha_small_kernel<float, float>), grid, block, lds, s, (const float*)q, ldq,
                        (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale);

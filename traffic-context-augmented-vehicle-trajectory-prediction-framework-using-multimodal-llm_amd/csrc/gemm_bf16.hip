@@ -71,6 +71,85 @@ __device__ __forceinline__ void store_quad(const GemmP& p, int m, int n, f32x4 v
   }
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue shared by both main-loop variants.  acc[i][j] holds, for n-tile i and m-tile j of this
+// wave, features n..n+3 (n = n_base + 16 i + 4 (lane >> 4)) of token m = m_base + 16 j + (lane & 15).
+// ---------------------------------------------------------------------------
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+  // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
+  const int nq = 4 * (lane >> 4);
+  const int ml = lane & 15;
+  if constexpr (EPI == EPI_GENERIC) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m_base + j * 16 + ml;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n_base + i * 16 + nq;
+        if (n >= p.N) continue;
+        f32x4 v = acc[i][j] * p.acc_scale;
+        if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.flags & TCAVT_EPI_BIAS_ROW) {
+          const float bm = p.bias[m];
+          v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+        }
+        if (p.flags & TCAVT_EPI_RELU) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        if (p.flags & TCAVT_EPI_RESIDUAL)
+          v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+        store_quad(p, m, n, v);
+      }
+    }
+  } else if constexpr (EPI == EPI_SILU) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m_base + j * 16 + ml;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; i += 2) {
+        if (n_base + i * 16 >= p.N) continue;  // partial last tile column
+        const int n = ((n_base) >> 1) + (i >> 1) * 16 + nq;
+        const f32x4 g = acc[i][j], u = acc[i + 1][j];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
+        store_quad(p, m, n, v);
+      }
+    }
+  } else {  // EPI_ROPE
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m_base + j * 16 + ml;
+      if (m >= p.M) continue;
+      const int pos = m % p.rope_L;
+#pragma unroll
+      for (int hh = 0; hh < TN / 4; ++hh) {
+        const int nb = n_base + hh * 64;
+        if (nb >= p.N) continue;  // partial last tile column (N % BN != 0)
+        const bool rot = nb < p.rope_cols;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int d = i * 16 + nq;
+          f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
+          if (rot) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
+            const f32x4 s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
+            const f32x4 l2 = lo * c - hi * s;
+            const f32x4 h2 = hi * c + lo * s;
+            lo = l2; hi = h2;
+          }
+          store_quad(p, m, nb + d, lo);
+          store_quad(p, m, nb + 32 + d, hi);
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP p) {
   constexpr int NW = WARPS_M * WARPS_N;
@@ -204,77 +283,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   }
   compute(cur);
 
-  // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
-  const int nq = 4 * (lane >> 4);
-  const int ml = lane & 15;
-  if constexpr (EPI == EPI_GENERIC) {
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * WTM + j * 16 + ml;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int n = n0 + wn * WTN + i * 16 + nq;
-        if (n >= p.N) continue;
-        f32x4 v = acc[i][j] * p.acc_scale;
-        if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.flags & TCAVT_EPI_BIAS_ROW) {
-          const float bm = p.bias[m];
-          v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-        }
-        if (p.flags & TCAVT_EPI_RELU) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-        if (p.flags & TCAVT_EPI_RESIDUAL)
-          v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
-        store_quad(p, m, n, v);
-      }
-    }
-  } else if constexpr (EPI == EPI_SILU) {
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * WTM + j * 16 + ml;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < TN; i += 2) {
-        if (n0 + wn * WTN + i * 16 >= p.N) continue;  // partial last tile column
-        const int n = ((n0 + wn * WTN) >> 1) + (i >> 1) * 16 + nq;
-        const f32x4 g = acc[i][j], u = acc[i + 1][j];
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = g[e] / (1.f + __expf(-g[e])) * u[e];
-        store_quad(p, m, n, v);
-      }
-    }
-  } else {  // EPI_ROPE
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * WTM + j * 16 + ml;
-      if (m >= p.M) continue;
-      const int pos = m % p.rope_L;
-#pragma unroll
-      for (int hh = 0; hh < TN / 4; ++hh) {
-        const int nb = n0 + wn * WTN + hh * 64;
-        if (nb >= p.N) continue;  // partial last tile column (N % BN != 0)
-        const bool rot = nb < p.rope_cols;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int d = i * 16 + nq;
-          f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
-          if (rot) {
-            const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
-            const f32x4 s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
-            const f32x4 l2 = lo * c - hi * s;
-            const f32x4 h2 = hi * c + lo * s;
-            lo = l2; hi = h2;
-          }
-          store_quad(p, m, nb + d, lo);
-          store_quad(p, m, nb + 32 + d, hi);
-        }
-      }
-    }
-  }
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
@@ -300,9 +309,166 @@ static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+// ===========================================================================
+// Main-loop variant 2 ("ring", 256x256 tile only): the K dimension is cut into 32-deep slabs that
+// live in a 4-slot LDS ring (4 x 32 KiB).  Up to three slabs of LDS-DMA stay in flight ACROSS the
+// workgroup barriers: the loop never drains vmcnt to 0 in steady state (counted s_waitcnt vmcnt(8)),
+// uses raw s_barrier (a __syncthreads() would drain the DMA queue), and has one barrier per slab:
+//
+//     wait(slab s landed for my own DMA) ; barrier ; issue DMA for slab s+3 ; ds_read + 32 MFMA on slab s
+//
+// The barrier both publishes slab s (every wave waited for its own pieces before arriving) and
+// proves every wave has finished reading slab s-1, whose slot the new DMA overwrites.
+// An LDS row is a tile row's 64 bytes of the slab; the four 16-byte chunks are XOR-swizzled with
+// F[(row>>2)&3], F = {0,2,3,1}, which makes every ds_read_b128 lane group hit 16 distinct slots of
+// the 256-byte bank row (swizzle on the DMA source address and on the fragment read, never on the
+// DMA destination, which is lane-linear).
+// ===========================================================================
+template <int EPI, bool F16>
+__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
+  constexpr int BM = 256, BN = 256, WARPS_N = 4, NW = 8;
+  constexpr int WTM = 128, WTN = 64, TM = 8, TN = 4;
+  constexpr int SLAB = (BM + BN) * 64;  // bytes per ring slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 4;
+    const int per_group = GM * p.tiles_n;
+    const int g = wgid / per_group, in_g = wgid - g * per_group;
+    const int gsz = min(GM, p.tiles_m - g * GM);
+    tile_m = g * GM + in_g % gsz;
+    tile_n = in_g / gsz;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (gridDim.y > 1) {
+    const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
+    p.A += bo * p.sAo + bi * p.sAi;
+    p.W += bo * p.sWo + bi * p.sWi;
+    const long co = bo * p.sCo + bi * p.sCi;
+    p.C = p.out_kind == TCAVT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + co)
+                                  : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + co);
+  }
+
+  // ---- staging: 4 DMA pieces per thread per slab; piece r of wave w covers rows 16*(8r+w) .. +15
+  const bf16_t* src[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int g = r * NW + wave;
+    const int row = g * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+    if (g * 16 < BM) {
+      const int m = min(m0 + row, p.M - 1);
+      src[r] = p.A + (long)m * p.lda + c * 8;
+    } else {
+      const int n = min(n0 + row - BM, p.N - 1);
+      src[r] = p.W + (long)n * p.ldw + c * 8;
+    }
+  }
+  const int ns1 = p.K >> 5, ns = ns1 + (p.K2 >> 5);
+
+  auto stage = [&](int slot, int s) {
+    char* base = smem + slot * SLAB;
+    if (s < ns1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) glds16(src[r] + s * 32, base + (r * NW + wave) * 1024);
+    } else {
+      const int k0 = (s - ns1) * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = r * NW + wave;
+        const int row = g * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+        const bf16_t* sp;
+        if (g * 16 < BM) {
+          const int m = min(m0 + row, p.M - 1);
+          sp = p.A2 + (long)m * p.lda2 + k0 + c * 8;
+        } else {
+          const int n = min(n0 + row - BM, p.N - 1);
+          sp = p.W2 + (long)n * p.ldw2 + k0 + c * 8;
+        }
+        glds16(sp, base + g * 1024);
+      }
+    }
+  };
+
+  // ---- fragment read addressing inside a slab
+  const int r16 = lane & 15;
+  const int foff = r16 * 64 + ((((lane >> 4)) ^ ((0x78 >> (((r16 >> 2) & 3) * 2)) & 3)) << 4);
+  const int xoff = wm * WTM * 64 + foff;
+  const int woff = (BM + wn * WTN) * 64 + foff;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: three slabs in flight
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+    if (s < ns) stage(s, s);
+
+  for (int s = 0; s < ns; ++s) {
+    const int rem = ns - 1 - s;  // slabs issued after slab s (capped at 2)
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 3 < ns) stage((s + 3) & 3, s + 3);
+    const char* base = smem + (s & 3) * SLAB;
+    bf16x8 wf[TN], xf[TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + woff + i * 1024);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(base + xoff + j * 1024);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        if constexpr (F16)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i]),
+                                                             __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  }
+  gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+template <int EPI, bool F16>
+static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
+  GemmP p = p0;
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  constexpr int lds = 4 * 512 * 64;
+  auto kfn = gemm_bf16_ring_kernel<EPI, F16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      set_error("gemm_bf16(ring): hipFuncSetAttribute(%d B LDS) failed: %s", lds, hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, batch), block(512);
+  hipLaunchKernelGGL(kfn, grid, block, lds, stream, p);
+  TCAVT_CHECK_LAUNCH("gemm_bf16(ring)");
+  return TCAVT_OK;
+}
+
 template <int EPI, bool F16>
 static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream) {
-  if (tile == 256) return launch<256, 256, 2, 4, EPI, F16>(p, batch, stream);
+  if (tile == 256) return launch_ring<EPI, F16>(p, batch, stream);
+  if (tile == 255) return launch<256, 256, 2, 4, EPI, F16>(p, batch, stream);  // 2-buffer loop, kept for A/B
   return launch<128, 128, 2, 2, EPI, F16>(p, batch, stream);
 }
 
@@ -315,6 +481,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   TCAVT_CHECK_ARG(a->A && a->W && a->C, "gemm_bf16: null A/W/C");
   TCAVT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "gemm_bf16: bad M/N/K %d/%d/%d", a->M, a->N, a->K);
   TCAVT_CHECK_ARG(a->K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a->K);
+  TCAVT_CHECK_ARG(a->K < (1 << 26), "gemm_bf16: K too large");
   TCAVT_CHECK_ARG(a->N % 16 == 0, "gemm_bf16: N=%d must be a multiple of 16", a->N);
   TCAVT_CHECK_ARG(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->lda >= a->K && a->ldw >= a->K,
                   "gemm_bf16: lda/ldw must be >= K and multiples of 8");
@@ -358,7 +525,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256, "gemm_bf16: tile must be 0, 128 or 256");
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 255,
+                  "gemm_bf16: tile must be 0 (auto), 128, 256 (ring pipeline) or 255 (256x256 two-buffer loop)");
 
   GemmP p;
   p.A = static_cast<const bf16_t*>(a->A);
@@ -384,9 +552,12 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
 
   int tile = a->tile;
   if (tile == 0) {
-    // 256x256 tiles only when they still fill the chip (>= 256 tiles)
-    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    tile = (t256 >= 256) ? 256 : 128;
+    // 256x256 tiles (two-buffer loop; measured faster than the 32-deep ring on MI355X: 1.24 vs 1.16
+    // PFLOP/s on the gate|up shape) only when whole waves of 256 workgroups stay >= 85 % full;
+    // e.g. the fused q|k|v projection (32 x 12 = 384 tiles = 1.5 waves) runs faster on 128x128 tiles.
+    const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * batch;
+    const long waves = (t256 + 255) / 256;
+    tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.85) ? 255 : 128;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
