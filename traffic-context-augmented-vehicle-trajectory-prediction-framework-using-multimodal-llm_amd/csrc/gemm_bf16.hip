@@ -41,6 +41,7 @@ struct GemmP {
   float acc_scale;
   int batch_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
+  int prio;  // wave-priority experiment: 0 none, 1 static s_setprio(1) for the upper half of the waves, 2 around MFMA clusters
 };
 
 enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2 };
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
 #pragma unroll
       for (int j = 0; j < TM; ++j)
         xf[j] = *reinterpret_cast<const bf16x8*>(base + xrow + j * 2048 + off);
+      if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -268,9 +270,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
                                                                __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
     }
   };
 
+  if (p.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   // ---- main loop: stage t+1 while computing t; one drain+barrier per K-tile
   stage(0, 0);
   __syncthreads();
@@ -468,8 +472,17 @@ static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
 template <int EPI, bool F16>
 static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream) {
   if (tile == 256) return launch_ring<EPI, F16>(p, batch, stream);
-  if (tile == 255) return launch<256, 256, 2, 4, EPI, F16>(p, batch, stream);  // 2-buffer loop, kept for A/B
-  return launch<128, 128, 2, 2, EPI, F16>(p, batch, stream);
+  // 256x256 (8 waves, 2 per SIMD): s_setprio(1) around each MFMA cluster is the default, +3..7 % on
+  // MI355X (the two waves of a SIMD fall into compute/load alternation instead of interleaving MFMA by
+  // MFMA).  128x128 (4 waves, 1 per SIMD per workgroup): the same costs 5..15 %, so it stays off.
+  // Codes 253 / 252 / 127 keep the other arbitration variants reachable for A/B runs.
+  GemmP q = p;
+  if (tile == 255 || tile == 253 || tile == 252) {
+    q.prio = tile == 253 ? 1 : (tile == 252 ? 0 : 2);
+    return launch<256, 256, 2, 4, EPI, F16>(q, batch, stream);
+  }
+  q.prio = tile == 127 ? 2 : 0;
+  return launch<128, 128, 2, 2, EPI, F16>(q, batch, stream);
 }
 
 }  // namespace tcavt
@@ -525,7 +538,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 255,
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 255 || a->tile == 253 || a->tile == 252 || a->tile == 127,
                   "gemm_bf16: tile must be 0 (auto), 128, 256 (ring pipeline) or 255 (256x256 two-buffer loop)");
 
   GemmP p;
@@ -546,6 +559,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.flags = epi;
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
   p.tiles_m = p.tiles_n = 0;
+  p.prio = 0;
   p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale;
   if (epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE))
     TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
