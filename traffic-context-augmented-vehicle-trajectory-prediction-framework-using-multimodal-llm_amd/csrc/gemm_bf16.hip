@@ -21,6 +21,7 @@
 // scripts/train.py:401-406,446-452,493,754-757 and HF modeling_llama.py
 // :174-176,254-256,279-280).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace tcavt {
 
@@ -41,6 +42,7 @@ struct GemmP {
   float acc_scale;
   int batch_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
+  int xcd_gx;  // XCD partition of the tile grid (block_to_tile)
   int prio;  // wave-priority experiment: 0 none, 1 static s_setprio(1) for the upper half of the waves, 2 around MFMA clusters
 };
 
@@ -151,7 +153,40 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
+// ---------------------------------------------------------------------------
+// Workgroup -> output tile.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
+// XCD, each with a private 4 MiB L2), so the grid is cut into gx x gy rectangles of tiles, one per XCD
+// (gx * gy = 8): an XCD then streams 1/gx of the activation rows and 1/gy of the weight rows, and the
+// fabric / Infinity-Cache traffic of the launch is  gy * |A| + gx * |W|.  The host picks (gx, gy) that
+// minimises it (p.xcd_gx; 8 = row bands, the right choice whenever |A| >= |W|).  Inside its rectangle an
+// XCD walks 4-tile-tall super rows so that its 32 CUs work on a 4 x 8 patch at any time.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  constexpr int GM = 4;
+  const int gx = p.xcd_gx;
+  if (gx != 8) {  // 2-D partition; the host guarantees tiles_m % gx == 0 and tiles_n % (8 / gx) == 0
+    const int gy = 8 / gx;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int xi = xcd / gy, xj = xcd - xi * gy;
+    const int sm = p.tiles_m / gx, sn = p.tiles_n / gy;
+    const int per_group = GM * sn;
+    const int g = local / per_group, in_g = local - g * per_group;
+    const int gsz = min(GM, sm - g * GM);
+    tile_m = xi * sm + g * GM + in_g % gsz;
+    tile_n = xj * sn + in_g / gsz;
+    return;
+  }
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int per_group = GM * p.tiles_n;
+  const int g = wgid / per_group, in_g = wgid - g * per_group;
+  const int gsz = min(GM, p.tiles_m - g * GM);
+  tile_m = g * GM + in_g % gsz;
+  tile_n = in_g / gsz;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16, int PIPE>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP p) {
   constexpr int NW = WARPS_M * WARPS_N;
   constexpr int ROWS = BM + BN;
@@ -170,19 +205,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-  // ---- block -> tile: XCD-aware remap (bijective), then 4-tile-tall super rows
+  // ---- block -> tile (XCD-aware; any bijection is correct, this one is for L2 / fabric traffic)
   int tile_m, tile_n;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GM = 4;
-    const int per_group = GM * p.tiles_n;
-    const int g = wgid / per_group, in_g = wgid - g * per_group;
-    const int gsz = min(GM, p.tiles_m - g * GM);
-    tile_m = g * GM + in_g % gsz;
-    tile_n = in_g / gsz;
-  }
+  block_to_tile(p, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (gridDim.y > 1) {  // batched form: product blockIdx.y
     const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
@@ -274,29 +299,140 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
     }
   };
 
+  // Variant (prio == 3): the DMA pieces of tile t+1 are issued one at a time BETWEEN the MFMAs of the
+  // first k-step of tile t instead of in one burst ahead of them (each piece costs the issuing wave
+  // ~60-180 cycles of issue time; spread out, the other wave of the SIMD keeps the matrix pipe busy).
+  auto compute_interleaved = [&](int buf, int nbuf, int tn) {
+    const char* base = smem + buf * TILE_BYTES;
+    char* nbase = smem + nbuf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int off = ks ? off1 : off0;
+      bf16x8 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + wrow + i * 2048 + off);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(base + xrow + j * 2048 + off);
+      if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[i]),
+                                                               __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          constexpr int PER = (TN * TM) / ROUNDS;  // MFMAs per DMA piece
+          const int idx = i * TM + j;
+          if (ks == 0 && (idx % PER) == PER - 1) {
+            const int r = idx / PER;
+            glds16(src[r] + tn * 64, nbase + (r * NW + wave) * 1024);
+          }
+        }
+      if (p.prio == 2) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
   if (p.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   // ---- main loop: stage t+1 while computing t; one drain+barrier per K-tile
   stage(0, 0);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < nt - 1; ++t) {
-    stage(cur ^ 1, t + 1);
-    compute(cur);
-    __syncthreads();
-    cur ^= 1;
+  if constexpr (PIPE == 2) {
+    // PIPE 1 + an L2 warm-up of the weight tile two K-steps ahead.  Inside the model every layer's
+    // weights come from HBM exactly once (1.9 GB per step >> 256 MiB Infinity Cache), so the DMA of
+    // tile t+1 would otherwise eat a full HBM miss per K-step; one 4-byte LDS-DMA per 128-byte line of
+    // W tile t+2 (into a dummy LDS slot, no VGPR involved) pulls those lines into L2 a whole iteration
+    // early.  It is the YOUNGEST memory op of its wave when the iteration ends, so the counted
+    // s_waitcnt vmcnt(1) + raw s_barrier below retire the real DMA but leave the warm-up in flight.
+    static_assert(BN <= NW * 64 / 2, "one lane of the lower half of the waves per W row");
+    char* dummy = smem + 2 * TILE_BYTES + wave * 256;
+    const bool pf_wave = wave < NW / 2;
+    const int pf_row = min(n0 + (int)threadIdx.x, p.N - 1);
+    const bf16_t* pf_src = p.W + (long)pf_row * p.ldw;
+    int t = 0;
+    for (; t + 1 < nt1; ++t) {
+      compute_interleaved(cur, cur ^ 1, t + 1);
+      if (pf_wave && t + 2 < nt1) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_src + (t + 2) * 64),
+                                         (__attribute__((address_space(3))) void*)dummy, 4, 0, 0);
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur ^= 1;
+    }
+    for (; t < nt - 1; ++t) {
+      stage(cur ^ 1, t + 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else if constexpr (PIPE == 1) {
+    int t = 0;
+    for (; t + 1 < nt1; ++t) {
+      compute_interleaved(cur, cur ^ 1, t + 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    for (; t < nt - 1; ++t) {  // second K-source (LoRA): burst staging
+      stage(cur ^ 1, t + 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    for (int t = 0; t < nt - 1; ++t) {
+      stage(cur ^ 1, t + 1);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   compute(cur);
 
   gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16>
+// (gx, gy) minimising gy * |A| + 3 * gx * |W| among the partitions the tile grid divides evenly into
+// whole super rows.  The factor 3 is measured: inside the model the weights W are read from HBM (1.9 GB of
+// weights per step never stay in the 256 MiB Infinity Cache) while the activations A were just written
+// by the previous kernel and are served from the Infinity Cache, so a redundant W read costs about three
+// times a redundant A read (gate|up, cold weights: 467 us with row bands gx=8, 435 us with gx=1; down:
+// 203 us gx=8/4, 242 us gx=1).  TCAVT_GEMM_XCD_GX=<1|2|4|8> forces a partition (A/B runs).
+static int choose_xcd_partition(const GemmP& p) {
+  static const int forced = [] {
+    const char* e = getenv("TCAVT_GEMM_XCD_GX");
+    return e ? atoi(e) : 0;
+  }();
+  const double a_bytes = (double)p.M * p.K, w_bytes = (double)p.N * p.K;
+  int best = 8;
+  constexpr double kColdW = 3.0;
+  double best_cost = 1.0 * a_bytes + kColdW * 8.0 * w_bytes;
+  for (int gx = 1; gx <= 4; gx *= 2) {
+    const int gy = 8 / gx;
+    if (p.tiles_m % gx || p.tiles_n % gy || (p.tiles_m / gx) % 4 || (long)p.tiles_m * p.tiles_n % 8) continue;
+    if (forced == gx) return gx;
+    const double cost = gy * a_bytes + kColdW * gx * w_bytes;
+    if (cost < 0.9 * best_cost) {
+      best_cost = cost;
+      best = gx;
+    }
+  }
+  return forced == 8 ? 8 : best;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16, int PIPE = 0>
 static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   GemmP p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  constexpr int lds = 2 * (BM + BN) * 128;
-  auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI, F16>;
+  p.xcd_gx = choose_xcd_partition(p);
+  constexpr int lds = 2 * (BM + BN) * 128 + (PIPE == 2 ? WARPS_M * WARPS_N * 256 : 0);
+  auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI, F16, PIPE>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -339,17 +475,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   int tile_m, tile_n;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GM = 4;
-    const int per_group = GM * p.tiles_n;
-    const int g = wgid / per_group, in_g = wgid - g * per_group;
-    const int gsz = min(GM, p.tiles_m - g * GM);
-    tile_m = g * GM + in_g % gsz;
-    tile_n = in_g / gsz;
-  }
+  block_to_tile(p, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (gridDim.y > 1) {
     const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
@@ -451,6 +577,7 @@ static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
   GemmP p = p0;
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
+  p.xcd_gx = 8;
   constexpr int lds = 4 * 512 * 64;
   auto kfn = gemm_bf16_ring_kernel<EPI, F16>;
   static bool attr_set = false;
@@ -469,20 +596,28 @@ static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+// tile codes (tcavt_gemm_args.tile): 0 auto | 256, 128 the production variants |
+// A/B variants kept reachable: 255 = 256x256 with burst DMA issue, 253 / 252 = 255 with static / no wave
+// priority, 250 = 256x256 32-deep ring pipeline, 127 = 128x128 with MFMA-cluster priority,
+// 126 = 128x128 with burst DMA issue.
 template <int EPI, bool F16>
 static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream) {
-  if (tile == 256) return launch_ring<EPI, F16>(p, batch, stream);
-  // 256x256 (8 waves, 2 per SIMD): s_setprio(1) around each MFMA cluster is the default, +3..7 % on
-  // MI355X (the two waves of a SIMD fall into compute/load alternation instead of interleaving MFMA by
-  // MFMA).  128x128 (4 waves, 1 per SIMD per workgroup): the same costs 5..15 %, so it stays off.
-  // Codes 253 / 252 / 127 keep the other arbitration variants reachable for A/B runs.
   GemmP q = p;
-  if (tile == 255 || tile == 253 || tile == 252) {
-    q.prio = tile == 253 ? 1 : (tile == 252 ? 0 : 2);
-    return launch<256, 256, 2, 4, EPI, F16>(q, batch, stream);
+  switch (tile) {
+    case 256:  // DMA pieces interleaved with the MFMAs + s_setprio(1) around MFMA clusters (fastest measured)
+      q.prio = 2;
+      return launch<256, 256, 2, 4, EPI, F16, 1>(q, batch, stream);
+    case 255: q.prio = 2; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
+    case 254: q.prio = 2; return launch<256, 256, 2, 4, EPI, F16, 2>(q, batch, stream);
+    case 253: q.prio = 1; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
+    case 252: q.prio = 0; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
+    case 250: return launch_ring<EPI, F16>(q, batch, stream);
+    case 127: q.prio = 2; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
+    case 126: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
+    default:  // 128: interleaved DMA issue, no priority games (4 waves, one per SIMD per workgroup)
+      q.prio = 0;
+      return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
   }
-  q.prio = tile == 127 ? 2 : 0;
-  return launch<128, 128, 2, 2, EPI, F16>(q, batch, stream);
 }
 
 }  // namespace tcavt
@@ -538,8 +673,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || a->tile == 255 || a->tile == 253 || a->tile == 252 || a->tile == 127,
-                  "gemm_bf16: tile must be 0 (auto), 128, 256 (ring pipeline) or 255 (256x256 two-buffer loop)");
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 255 && a->tile != 251) || a->tile == 127 || a->tile == 126,
+                  "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;
   p.A = static_cast<const bf16_t*>(a->A);
@@ -560,18 +695,18 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
   p.tiles_m = p.tiles_n = 0;
   p.prio = 0;
+  p.xcd_gx = 8;
   p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale;
   if (epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE))
     TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
 
   int tile = a->tile;
   if (tile == 0) {
-    // 256x256 tiles (two-buffer loop; measured faster than the 32-deep ring on MI355X: 1.24 vs 1.16
-    // PFLOP/s on the gate|up shape) only when whole waves of 256 workgroups stay >= 85 % full;
-    // e.g. the fused q|k|v projection (32 x 12 = 384 tiles = 1.5 waves) runs faster on 128x128 tiles.
+    // 256x256 tiles when whole waves of 256 workgroups stay >= 75 % full (the fused q|k|v projection,
+    // 32 x 12 = 384 tiles = 1.5 waves, is the boundary case: 111 us on 256x256 vs 114 us on 128x128).
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * batch;
     const long waves = (t256 + 255) / 256;
-    tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.85) ? 255 : 128;
+    tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 128;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
