@@ -255,6 +255,15 @@ def main():
     kernels["attn"] = {"avg_us": round(attn_ms * 1e3, 1), "algorithmic_GBps": round(attn_bytes / (attn_ms * 1e-3) / 1e9, 1),
                        "hbm_frac": round(attn_bytes / (attn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
+    # HBM-side traffic of the dominant kernel: PMC counters cannot be read inside this process, they come
+    # from the committed rocprofv3 --pmc passes of the same kernel / shape (profiles/)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_gateup_gemm_pmc.json")
+    if os.path.exists(pmc_path) and (M, 2 * ll.inter, ll.hidden) == (8192, 16384, 2048):
+        with open(pmc_path) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_gateup_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
+
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
@@ -276,9 +285,10 @@ def main():
             },
             "achieved_model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 1),
             "roofline": {
-                "kernel": "gemm_bf16_kernel<256,256,2,4,SILU> (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
+                "kernel": "gemm_bf16_kernel<256,256,2x4 waves,SILU,PIPE1> (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
                 "bound": "mfma", "achieved": round(gu_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(gu_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(gu_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src, "algorithmic_bytes": int(2 * (M * ll.hidden + 2 * ll.inter * ll.hidden + M * ll.inter)),
                 "launches_timed": ksum["gateup"][0], "avg_launch_us": round(gu_ms * 1e3, 1),
             },
             "kernels": kernels,

@@ -241,3 +241,29 @@ def test_stage_ltsf_head(gpu):
     print(f"[stage ltsf] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
     assert e16 < 1e-3
     assert e32 <= 1.5 * o32 + 1e-3
+
+
+def test_evaluate_model_k_candidates(gpu):
+    """test.py:1301-1382 protocol with dropout off: K identical candidates -> min over K == single pass,
+    and the single-pass ADE/FDE equal the oracle's metrics on the HIP predictions."""
+    from oracle import forward as O
+    from tcavt_amd import evaluate, model
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    g = {k: v.to(dev) for k, v in t.items()}
+    r1 = evaluate.evaluate_model(m, [g], num_candidates=1)
+    r3 = evaluate.evaluate_model(m, [g, g], num_candidates=3)
+    assert r1["n"] == t["traj_emb"].shape[0] and r3["n"] == 2 * r1["n"]
+    for k in ("ADE", "FDE", "RMSE"):
+        assert abs(r1[k] - r3[k]) <= 1e-6 * abs(r1[k])
+    with torch.no_grad():
+        dec = m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], input_ids=g["input_ids"],
+                attention_mask=g["attention_mask"]).cpu()
+    ref = O.traj_metrics(dec, t["target_traj"], t["norm_stat"])
+    n = r1["n"]
+    assert abs(r1["ADE"] - ref["ade_sum"] / n) < 1e-4 * ref["ade_sum"] / n
+    assert abs(r1["FDE"] - ref["fde_sum"] / n) < 1e-4 * ref["fde_sum"] / n
+    assert abs(r1["RMSE"] - ref["rmse_sum"] / n) < 1e-4 * ref["rmse_sum"] / n
