@@ -314,3 +314,26 @@ def test_softmax_rows(gpu):
     ref = torch.softmax(S[:, :L], dim=-1)
     assert (P[:, L:] == 0).all()
     assert (P[:, :L].float() - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 64, 2048), (64, 2048, 2048), (40, 70, 1000)])
+def test_gemm_f32_split_k_and_strided(gpu, M, N, K):
+    """Few output tiles + long K takes the split-K path (float atomics); also the transposed-operand form
+    gW = gy^T x used by the backward."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    out = ops.gemm_f32(a, w, bias=bias, residual=res)
+    ref = (a.double() @ w.double().T + bias.double() + res.double()).float()
+    assert _rel(out, ref) < 1e-6
+    # gW[n][k] = sum_m gy[m][n] x[m][k]
+    gy = torch.randn(K, M, generator=g).to(dev)   # [rows=K (contraction), cols=M]
+    x = torch.randn(K, N, generator=g).to(dev)
+    gw = torch.empty(M, N, device=dev)
+    ops.gemm_f32_strided(gy, 1, gy.stride(0), x, 1, x.stride(0), gw, M, N, K)
+    assert _rel(gw, (gy.double().T @ x.double()).float()) < 1e-6

@@ -339,39 +339,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   stage(0, 0);
   __syncthreads();
   int cur = 0;
-  if constexpr (PIPE == 2) {
-    // PIPE 1 + an L2 warm-up of the weight tile two K-steps ahead.  Inside the model every layer's
-    // weights come from HBM exactly once (1.9 GB per step >> 256 MiB Infinity Cache), so the DMA of
-    // tile t+1 would otherwise eat a full HBM miss per K-step; one 4-byte LDS-DMA per 128-byte line of
-    // W tile t+2 (into a dummy LDS slot, no VGPR involved) pulls those lines into L2 a whole iteration
-    // early.  It is the YOUNGEST memory op of its wave when the iteration ends, so the counted
-    // s_waitcnt vmcnt(1) + raw s_barrier below retire the real DMA but leave the warm-up in flight.
-    static_assert(BN <= NW * 64 / 2, "one lane of the lower half of the waves per W row");
-    char* dummy = smem + 2 * TILE_BYTES + wave * 256;
-    const bool pf_wave = wave < NW / 2;
-    const int pf_row = min(n0 + (int)threadIdx.x, p.N - 1);
-    const bf16_t* pf_src = p.W + (long)pf_row * p.ldw;
-    int t = 0;
-    for (; t + 1 < nt1; ++t) {
-      compute_interleaved(cur, cur ^ 1, t + 1);
-      if (pf_wave && t + 2 < nt1) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_src + (t + 2) * 64),
-                                         (__attribute__((address_space(3))) void*)dummy, 4, 0, 0);
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      cur ^= 1;
-    }
-    for (; t < nt - 1; ++t) {
-      stage(cur ^ 1, t + 1);
-      compute(cur);
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else if constexpr (PIPE == 1) {
+  if constexpr (PIPE == 1) {
     int t = 0;
     for (; t + 1 < nt1; ++t) {
       compute_interleaved(cur, cur ^ 1, t + 1);
@@ -431,7 +399,7 @@ static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.xcd_gx = choose_xcd_partition(p);
-  constexpr int lds = 2 * (BM + BN) * 128 + (PIPE == 2 ? WARPS_M * WARPS_N * 256 : 0);
+  constexpr int lds = 2 * (BM + BN) * 128;
   auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI, F16, PIPE>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
@@ -608,7 +576,6 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
       q.prio = 2;
       return launch<256, 256, 2, 4, EPI, F16, 1>(q, batch, stream);
     case 255: q.prio = 2; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
-    case 254: q.prio = 2; return launch<256, 256, 2, 4, EPI, F16, 2>(q, batch, stream);
     case 253: q.prio = 1; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 252: q.prio = 0; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
@@ -673,7 +640,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 255 && a->tile != 251) || a->tile == 127 || a->tile == 126,
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 255 && a->tile != 251 && a->tile != 254) || a->tile == 127 || a->tile == 126,
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;

@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ res, long ldr,
                                                        float* __restrict__ C, long ldc, int M, int N,
-                                                       int K, int flags) {
+                                                       int K, int flags, int k_chunk) {
+  // split-K: blockIdx.z owns k in [kb, ke); partial sums meet in C (zeroed by the launcher) through float
+  // atomics, split 0 adds bias / residual.  Used when the output has too few tiles to fill the chip.
+  const int kb = blockIdx.z * k_chunk, ke = min(K, kb + k_chunk);
   __shared__ float As[64][17];
   __shared__ float Ws[64][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,19 +52,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float va[4], vw[4];
   int ra[4], ka[4], rw[4], kw[4];
-  gemm_f32_fetch(A, rsA, csA, m0, M, 0, K, tid, akf, va, ra, ka);
-  gemm_f32_fetch(W, rsW, csW, n0, N, 0, K, tid, wkf, vw, rw, kw);
+  gemm_f32_fetch(A, rsA, csA, m0, M, kb, ke, tid, akf, va, ra, ka);
+  gemm_f32_fetch(W, rsW, csW, n0, N, kb, ke, tid, wkf, vw, rw, kw);
   const int lr = lane & 15, lk = lane >> 4;
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = kb; k0 < ke; k0 += 16) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       As[ra[e]][ka[e]] = va[e];
       Ws[rw[e]][kw[e]] = vw[e];
     }
     __syncthreads();
-    if (k0 + 16 < K) {
-      gemm_f32_fetch(A, rsA, csA, m0, M, k0 + 16, K, tid, akf, va, ra, ka);
-      gemm_f32_fetch(W, rsW, csW, n0, N, k0 + 16, K, tid, wkf, vw, rw, kw);
+    if (k0 + 16 < ke) {
+      gemm_f32_fetch(A, rsA, csA, m0, M, k0 + 16, ke, tid, akf, va, ra, ka);
+      gemm_f32_fetch(W, rsW, csW, n0, N, k0 + 16, ke, tid, wkf, vw, rw, kw);
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -89,6 +92,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         const int m = m0 + wm * 32 + i * 16 + 4 * lk + r;
         if (m >= M) continue;
         float v = acc[i][j][r];
+        if (gridDim.z > 1) {
+          if (blockIdx.z == 0) {
+            if (flags & TCAVT_EPI_BIAS) v += bias[n];
+            if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
+          }
+          atomicAdd(&C[(long)m * ldc + n], v);
+          continue;
+        }
         if (flags & TCAVT_EPI_BIAS) v += bias[n];
         if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
         if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
@@ -252,6 +263,40 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const float* __restric
 
 using namespace tcavt;
 
+// Launch with split-K when the 64x64 output tiles cannot fill the chip and K is long (lane-polygon FFN:
+// K = 2048 or a contraction over 2048 tokens with 32 output tiles).  Not with ReLU (needs the full sum),
+// not when C aliases the residual (split 0 would read what other splits already added to).
+static int launch_gemm_f32(const float* A, long rsA, long csA, const float* W, long rsW, long csW, const float* bias,
+                           const float* residual, long ldr, float* C, long ldc, int M, int N, int K, int flags,
+                           hipStream_t stream, const char* what) {
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+  int splits = 1;
+  if (tiles < 128 && K >= 512 && !(flags & TCAVT_EPI_RELU) && residual != C && ldc == N) {
+    splits = K / 256;
+    if (splits > 8) splits = 8;
+    while (splits > 1 && tiles * splits > 512) splits >>= 1;
+  }
+  int k_chunk = K;
+  if (splits > 1) {
+    k_chunk = (((K + splits - 1) / splits) + 15) / 16 * 16;
+    splits = (K + k_chunk - 1) / k_chunk;
+    hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
+    if (e != hipSuccess) {
+      set_error("%s: hipMemsetAsync failed: %s", what, hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+  }
+  dim3 grid((N + 63) / 64, (M + 63) / 64, splits), block(256);
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, stream, A, rsA, csA, W, rsW, csW, bias, residual, ldr, C, ldc, M,
+                     N, K, flags, k_chunk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return TCAVT_ERR_HIP;
+  }
+  return TCAVT_OK;
+}
+
 extern "C" int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
                               const float* bias, const float* residual, int64_t ldr, float* C,
                               int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream) {
@@ -259,11 +304,8 @@ extern "C" int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32: BIAS without bias");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
   TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32: unsupported flag");
-  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)lda, 1L, W,
-                     (long)ldw, 1L, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
-  TCAVT_CHECK_LAUNCH("gemm_f32");
-  return TCAVT_OK;
+  return launch_gemm_f32(A, (long)lda, 1L, W, (long)ldw, 1L, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags,
+                         static_cast<hipStream_t>(stream), "gemm_f32");
 }
 
 extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, const float* W, int64_t rsW,
@@ -273,11 +315,8 @@ extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, 
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32_strided: BIAS without bias");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32_strided: RESIDUAL without residual");
   TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32_strided: unsupported flag");
-  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, static_cast<hipStream_t>(stream), A, (long)rsA, (long)csA, W,
-                     (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags);
-  TCAVT_CHECK_LAUNCH("gemm_f32_strided");
-  return TCAVT_OK;
+  return launch_gemm_f32(A, (long)rsA, (long)csA, W, (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M,
+                         N, K, flags, static_cast<hipStream_t>(stream), "gemm_f32_strided");
 }
 
 extern "C" int tcavt_poly_embed(const float* polygon, const float* w_in, const float* b_in,
