@@ -2,9 +2,10 @@
 //
 // (1) attn_causal_gqa_kernel -- the Llama decoder attention (SURVEY.md row F4;
 //     HF modeling_llama.py:191-213 with the sdpa causal AND key-valid mask).
-//     One workgroup per (sample, kv head); its `group` waves are the query heads
-//     that share that kv head, so K and V are fetched from HBM exactly once per
-//     (sample, kv head) and live in LDS for the whole workgroup:
+//     One workgroup per (sample, kv head); its 2 * `group` waves cover the query heads
+//     that share that kv head (two waves per head, alternating 32-query blocks), so K and V
+//     are fetched from HBM exactly once per (sample, kv head) and live in LDS for the
+//     whole workgroup:
 //       K   [Lp][64]  bf16, 128-byte rows, 16-byte chunks XOR-swizzled by (row>>1)&7
 //       V^T [64][Lp+4] bf16 (transposed while staging so the PV product reads
 //                           k-contiguous 8-byte pieces; +4 pad => conflict-free)
@@ -45,7 +46,7 @@ __device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits
   return static_cast<unsigned int>(ha) | (static_cast<unsigned int>(hb) << 16);
 }
 
-__global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
                                                               bf16_t* __restrict__ out,
                                                               const int* __restrict__ kv_len_p,
                                                               int L, int Lp, int nq, int nkv,
@@ -87,13 +88,17 @@ __global__ __launch_bounds__(512) void attn_causal_gqa_kernel(const bf16_t* __re
   __syncthreads();
 
   const int kv_len = min(kv_len_p[b], L);
-  const int head = kvh * group + wave;
+  // 2 * group waves: wave w serves query head w % group and the 32-query blocks of parity w / group, so every
+  // SIMD holds two waves whose MFMA / softmax / LDS phases interleave (one wave per SIMD left the matrix
+  // pipe idle during every softmax)
+  const int head = kvh * group + (wave % group);
+  const int qb0 = wave / group;
   const int r = lane & 31, hh = lane >> 5;
   const int nqb = (L + 31) >> 5;
   const int kv_tiles = (kv_len + 31) >> 5;
   const int kswz = (r >> 1) & 7;
 
-  for (int qb = 0; qb < nqb; ++qb) {
+  for (int qb = qb0; qb < nqb; qb += 2) {
     const int qi = qb * 32 + r;  // this lane's query row
     const int qrow = min(qi, L - 1);
     bf16x8 qf[4];
@@ -347,7 +352,7 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
     lds_set = 160 * 1024;
   }
   const int group = nq / nkv;
-  hipLaunchKernelGGL(attn_causal_gqa_kernel, dim3(B * nkv), dim3(group * 64), lds,
+  hipLaunchKernelGGL(attn_causal_gqa_kernel, dim3(B * nkv), dim3(2 * group * 64), lds,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
                      static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
   TCAVT_CHECK_LAUNCH("attn_causal_gqa");

@@ -677,19 +677,29 @@ class TransformerLTSF(nn.Module, _Prepared):
             b_k=ca.in_proj_bias.detach()[H:2 * H].contiguous(), b_v=ca.in_proj_bias.detach()[2 * H:].contiguous(),
             w_co=_bf16(ca.out_proj.weight), w_un=_bf16(dec.dec_unproj.weight))
 
-    def forward(self, x, lane_polygon_emb, final_hidden, final_hidden_bf16=None, _fuse_last_residual=False):
+    def front(self, x):
+        """The part of forward() that does not depend on the LLM: token projection, per-channel N-Linear
+        encoder, positional term and the self-attention block (train.py:837-840).  Returns the tokens
+        [B*T, C]; MultiModalTrajectoryModel runs it on a side stream while the decoder stack computes."""
+        B, F, T = x.shape
+        dev, C, ws = x.device, self.d_model, self._ws
+        P = self._prepared()
+        tok = ws.get("lt.tok", (B * T, C), torch.float32, dev)
+        xp_tok = ws.get("lt.xp", (B * T, C), torch.float32, dev) if self.save_for_backward else None
+        ops.ltsf_front(x, P.conv_w, self.token_proj.bias, P.enc_w, P.enc_b, P.pos, tok, B, C, T, xp_tok=xp_tok)
+        return self.attn_block.forward_tokens(tok, B, T)
+
+    def forward(self, x, lane_polygon_emb, final_hidden, final_hidden_bf16=None, _fuse_last_residual=False, _front=None):
         """x (B,2,T) fp32; lane_polygon_emb (B,64); final_hidden (B,L,H) -> (B,2,To), as
         train.py:836-842.  ``_fuse_last_residual`` additionally adds x[:, :, -1:] in the head kernel
-        (the caller's "simple residual", train.py:941-943) instead of a separate pass."""
+        (the caller's "simple residual", train.py:941-943) instead of a separate pass; ``_front`` is the
+        result of front(x) when the caller already computed it."""
         B, F, T = x.shape
         dev, C, To, ws = x.device, self.d_model, self.out_len, self._ws
         dec, P = self.decoder, self._prepared()
         L, H = final_hidden.shape[1], final_hidden.shape[2]
         x = x.contiguous()
-        tok = ws.get("lt.tok", (B * T, C), torch.float32, dev)
-        xp_tok = ws.get("lt.xp", (B * T, C), torch.float32, dev) if self.save_for_backward else None
-        ops.ltsf_front(x, P.conv_w, self.token_proj.bias, P.enc_w, P.enc_b, P.pos, tok, B, C, T, xp_tok=xp_tok)
-        e = self.attn_block.forward_tokens(tok, B, T)
+        e = _front if _front is not None else self.front(x)
         lane = ws.get("lt.lane", (B, C * To), torch.float32, dev)
         ops.gemm_f32(lane_polygon_emb.contiguous(), dec.lane_fc.weight, out=lane, bias=dec.lane_fc.bias)
         d0 = ws.get("lt.dec0", (B, C * To), torch.float32, dev)
@@ -775,6 +785,8 @@ class MultiModalTrajectoryModel(nn.Module):
                                     nhead=ltsf_nhead, dropout_rate=ltsf_dropout, cross_dim=self.llama_hidden_size,
                                     cross_nhead=2, output_feature_dim=feature_size)
         self.feature_size, self.out_len, self.seq_len = feature_size, out_len, seq_len
+        self.overlap_streams = True  # side stream for the LLM-independent small-kernel chains (see forward)
+        self._side = None
 
     @classmethod
     def from_config(cls, cfg: ModelConfig):
@@ -810,10 +822,28 @@ class MultiModalTrajectoryModel(nn.Module):
                 input_ids=None, attention_mask=None, labels=None):
         B = x.size(0)
         dev = x.device
-        poly_emb = self.lane_polygon_encoder(lane_polygon_batch, lane_polygon_len)
+        x = x.contiguous()
+        # The lane-polygon encoder and the LLM-independent half of the LTSF (token projection, N-Linear
+        # encoder, self-attention block) are chains of small launches that leave most CUs idle; they run
+        # on a side stream, concurrently with the Q-Former / decoder stack, and join before the LTSF head.
+        main = torch.cuda.current_stream() if dev.type == "cuda" else None
+        if main is not None and self.overlap_streams:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                poly_emb = self.lane_polygon_encoder(lane_polygon_batch, lane_polygon_len)
+                front = self.ltsf.front(x)
+                poly_emb.record_stream(main)
+        else:
+            poly_emb = self.lane_polygon_encoder(lane_polygon_batch, lane_polygon_len)
+            front = self.ltsf.front(x)
         final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids,
                                              attention_mask=attention_mask, labels=labels, return_bf16=True)
-        decoded = self.ltsf(x, poly_emb, final_hidden, final_hidden_bf16=final_b, _fuse_last_residual=True)
+        if main is not None and self.overlap_streams:
+            main.wait_stream(self._side)
+        decoded = self.ltsf(x, poly_emb, final_hidden, final_hidden_bf16=final_b, _fuse_last_residual=True,
+                            _front=front)
         self.last = SimpleNamespace(poly_emb=poly_emb, final_hidden=final_hidden)
         if y is not None and norm_stat is not None:
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat], dtype=torch.float32)
