@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train: zero_grad + forward + backward + grad all-reduce + AdamW (train.py:1168-1183); "
                          "forward: MultiModalTrajectoryModel.forward incl. loss only (test.py / validation)")
@@ -141,17 +143,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    local_dev = local_rank % ndev  # (gloo rehearsal: several ranks may share a card)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
 
     from tcavt_amd import capi, config, model, synth, training
     from tcavt_amd.profiling import KernelTimer
     from tcavt_amd.weights import make_weights
 
-    capi.init(local_rank)
+    capi.init(local_dev)
     cfg = config.PRESETS[args.preset](seq_len=args.seq_len, out_len=args.out_len, use_lora=not args.no_lora)
     B, L = args.batch, cfg.q_num_query_tokens + args.text_len
 
