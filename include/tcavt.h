@@ -104,6 +104,13 @@ typedef struct tcavt_gemm_args {
    * (scripts/train.py:795-798) are issued: scores = q_bh . k_bh^T and out = p_bh . (v^T_bh)^T. */
   int32_t batch, batch_inner;
   int64_t sAo, sAi, sWo, sWi, sCo, sCi;
+  /* Train-mode dropout fused into the generic epilogue, applied after bias / ReLU and before the residual
+   * (nn.Dropout placement of nn.Transformer*Layer and the LTSF blocks, scripts/train.py:358,402,405,664-671,749):
+   * element (m, n) is kept iff the Philox4x32-10 word of flat index m*N+n at (seed, site) maps to u >= p, and
+   * scaled by 1/(1-p).  dropout_p == 0 disables it.  See csrc/philox.hpp. */
+  float dropout_p;
+  uint32_t dropout_site;
+  uint64_t dropout_seed;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -127,6 +134,11 @@ int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
 int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
                     const float* beta, float eps, float* out_f32, void* out_bf16,
                     int M, int D, tcavt_stream_t stream);
+
+/* Elementwise train-mode dropout: out[i] = x[i] * keep(i) / (1-p), dtype TCAVT_F32 or TCAVT_BF16 (in place
+ * allowed).  Used for the LoRA branch input (lora_dropout, scripts/train.py:433-439). */
+int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
+                  tcavt_stream_t stream);
 
 /* fp32 -> bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */
 int tcavt_cast_f32_bf16(const float* x, void* out_bf16, int64_t n, tcavt_stream_t stream);
@@ -168,11 +180,13 @@ int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int
 
 /* ------------------------------------------------------------------------
  * Row softmax for the batched cross-attention: P[r][c] = softmax_c(S[r][c]) over c < n_valid,
- * P[r][c] = 0 for n_valid <= c < n_out.  S fp32 (ld lds), P fp16 or bf16 (ld ldp).
+ * P[r][c] = 0 for n_valid <= c < n_out.  S fp32 (ld lds), P fp16 or bf16 (ld ldp).  dropout_p > 0 applies
+ * attention-weight dropout to P (flat index r*n_out + c; nn.MultiheadAttention(dropout=...), train.py:754).
  * (nn.MultiheadAttention's softmax, no mask: scripts/train.py:798.)
  * ---------------------------------------------------------------------- */
 int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int out_dtype, int rows,
-                       int n_valid, int n_out, tcavt_stream_t stream);
+                       int n_valid, int n_out, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
+                       tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Generic small multi-head attention, fp32 softmax (nn.MultiheadAttention
@@ -182,22 +196,25 @@ int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int ou
  *   key_len int32 [B] or NULL: keys j >= key_len[b] are masked (src_key_padding_mask)
  *   out [B][Lq][nh*dh], leading dim ldo
  * in_dtype/out_dtype: TCAVT_F32 or TCAVT_BF16 (q,k,v share in_dtype).
- * No causal mask.  Lk <= 544, Lq*Lk*4 bytes must fit 64 KiB.
+ * No causal mask.  Lk <= 544, Lq*Lk*4 bytes must fit 64 KiB.  dropout_p > 0: dropout on the attention
+ * probabilities, flat index ((b*nh + h)*Lq + i)*Lk + j.
  * ---------------------------------------------------------------------- */
 int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
               int64_t ldv, void* out, int64_t ldo, const int32_t* key_len, int B,
               int Lq, int Lk, int nh, int dh, float scale, int in_dtype,
-              int out_dtype, tcavt_stream_t stream);
+              int out_dtype, float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
+              tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * fp32 dense layer  C[M,N] = A[M,K] . W[N,K]^T + bias (+ReLU) (+residual)
  * for the parts of the path that must stay fp32 (raw-pixel lane polygons,
  * LTSF head: scripts/train.py:357-365,741-765).  Any M,N,K; flags = EPI_BIAS |
- * EPI_RELU | EPI_RESIDUAL.
+ * EPI_RELU | EPI_RESIDUAL.  dropout_p > 0: dropout after bias / ReLU, before the residual (flat index m*N+n).
  * ---------------------------------------------------------------------- */
 int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
                    const float* bias, const float* residual, int64_t ldr, float* C,
-                   int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream);
+                   int64_t ldc, int M, int N, int K, int flags, float dropout_p,
+                   uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * LanePolygonEncoder front and back (scripts/train.py:362-383):

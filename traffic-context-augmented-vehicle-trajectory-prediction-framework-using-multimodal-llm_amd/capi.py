@@ -44,6 +44,7 @@ class GemmArgs(ctypes.Structure):
         ("in_dtype", ctypes.c_int32),
         ("batch", ctypes.c_int32), ("batch_inner", ctypes.c_int32),
         ("sAo", c_int64), ("sAi", c_int64), ("sWo", c_int64), ("sWi", c_int64), ("sCo", c_int64), ("sCi", c_int64),
+        ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
     ]
 
 
@@ -58,13 +59,15 @@ _SIGNATURES = {
     "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_void_p, c_void_p],
-    "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,
+                           ctypes.c_uint32, c_void_p],
+    "tcavt_dropout": [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
-                  c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p],
+                  c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_gemm_f32": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                       c_int, c_int, c_int, c_int, c_void_p],
+                       c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_poly_embed": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_masked_mean": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_ltsf_front": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -25,6 +25,7 @@
 //     sequences of the Q-Former, the lane-polygon encoder, the LTSF block and the
 //     head_dim-1024 cross-attention (scripts/train.py:359,403,406,663,754).
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace tcavt {
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q
                                                         const TI* __restrict__ v, long ldv,
                                                         TO* __restrict__ out, long ldo,
                                                         const int* __restrict__ key_len, int Lq,
-                                                        int Lk, int nh, int dh, float scale) {
+                                                        int Lk, int nh, int dh, float scale, DropoutP drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Lq][Lk]
   const int b = blockIdx.x / nh, h = blockIdx.x % nh;
@@ -241,7 +242,12 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q
     }
     s = wave_sum(s);
     const float inv = s > 0.f ? 1.f / s : 0.f;
-    for (int j = lane; j < Lk; j += 64) row[j] *= inv;
+    for (int j = lane; j < Lk; j += 64) {
+      float pj = row[j] * inv;
+      if (drop.p > 0.f)
+        pj *= dropout_one(drop, ((unsigned long long)blockIdx.x * Lq + i) * (unsigned long long)Lk + j);
+      row[j] = pj;
+    }
   }
   __syncthreads();
   // phase 3: out[i][d] = sum_j P[i][j] V[j][d]; consecutive threads -> consecutive d
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void mha_lds_kernel(const TI* __restrict__ q, 
                                                       const TI* __restrict__ v, long ldv,
                                                       TO* __restrict__ out, long ldo,
                                                       const int* __restrict__ key_len, int Lq, int Lk,
-                                                      int nh, int dh, float scale) {
+                                                      int nh, int dh, float scale, DropoutP drop) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ds = dh + 1;
   float* Qs = reinterpret_cast<float*>(smem);
@@ -315,7 +321,12 @@ __global__ __launch_bounds__(256) void mha_lds_kernel(const TI* __restrict__ q, 
     }
     s = wave_sum(s);
     const float inv = s > 0.f ? 1.f / s : 0.f;
-    for (int j = lane; j < Lk; j += 64) row[j] *= inv;
+    for (int j = lane; j < Lk; j += 64) {
+      float pj = row[j] * inv;
+      if (drop.p > 0.f)
+        pj *= dropout_one(drop, ((unsigned long long)blockIdx.x * Lq + i) * (unsigned long long)Lk + j);
+      row[j] = pj;
+    }
   }
   __syncthreads();
   for (int id = tid; id < Lq * dh; id += 256) {
@@ -361,8 +372,10 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
 
 extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                          int64_t ldv, void* out, int64_t ldo, const int32_t* key_len, int B, int Lq,
-                         int Lk, int nh, int dh, float scale, int in_dtype, int out_dtype,
-                         tcavt_stream_t stream) {
+                         int Lk, int nh, int dh, float scale, int in_dtype, int out_dtype, float dropout_p,
+                         uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mha: dropout_p must be in [0, 1)");
+  const DropoutP drop = make_dropout(dropout_p, dropout_seed, dropout_site);
   TCAVT_CHECK_ARG(q && k && v && out, "mha: null pointer");
   TCAVT_CHECK_ARG(B > 0 && Lq > 0 && Lk > 0 && nh > 0 && dh > 0, "mha: bad shape");
   const long lds = (long)Lq * Lk * 4;
@@ -373,7 +386,7 @@ extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk,
   if (lds_all <= 60 * 1024) {  // whole problem in LDS
 #define TCAVT_MHA_LDS(TI, TO)                                                                                   \
   hipLaunchKernelGGL((mha_lds_kernel<TI, TO>), grid, block, lds_all, s, (const TI*)q, ldq, (const TI*)k, ldk, \
-                     (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale)
+                     (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop)
     if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(float, float);
     else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16) TCAVT_MHA_LDS(float, bf16_t);
     else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(bf16_t, float);
@@ -388,16 +401,16 @@ extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk,
   }
   if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32)
     hipLaunchKernelGGL((mha_small_kernel<float, float>), grid, block, lds, s, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+                       (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
   else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16)
     hipLaunchKernelGGL((mha_small_kernel<float, bf16_t>), grid, block, lds, s, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+                       (const float*)k, ldk, (const float*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
   else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32)
     hipLaunchKernelGGL((mha_small_kernel<bf16_t, float>), grid, block, lds, s, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
   else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_BF16)
     hipLaunchKernelGGL((mha_small_kernel<bf16_t, bf16_t>), grid, block, lds, s, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale);
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
   else {
     set_error("mha: bad dtype %d/%d", in_dtype, out_dtype);
     return TCAVT_ERR_ARG;

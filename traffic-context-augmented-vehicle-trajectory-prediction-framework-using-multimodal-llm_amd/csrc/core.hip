@@ -4,6 +4,7 @@
 // wave (H = 2048 fp32 = 8 KiB = 8 float4 per lane) so the only cross-lane
 // traffic is one wave reduction.
 #include "common.hpp"
+#include "philox.hpp"
 #include <string.h>
 
 namespace tcavt {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
 // Row softmax (one wave per row): P = softmax(S[:, :n_valid]), zero-padded to n_out columns.
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long lds,
                                                            bf16_t* __restrict__ P, long ldp, int f16, int rows,
-                                                           int n_valid, int n_out) {
+                                                           int n_valid, int n_out, DropoutP drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -226,8 +227,28 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   const float inv = 1.f / sum;
   bf16_t* o = P + (long)row * ldp;
   for (int c = lane; c < n_out; c += 64) {
-    const float v = c < n_valid ? __expf(s[c] - m) * inv : 0.f;
+    float v = c < n_valid ? __expf(s[c] - m) * inv : 0.f;
+    if (drop.p > 0.f && c < n_valid) v *= dropout_one(drop, (unsigned long long)row * n_out + c);
     o[c] = f16 ? __builtin_bit_cast(unsigned short, static_cast<_Float16>(v)) : f32_to_bf16(v);
+  }
+}
+
+// Elementwise dropout, one Philox call per quad of elements.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long n, DropoutP drop) {
+  const long nq = (n + 3) >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+    float sc[4];
+    dropout_quad(drop, (unsigned long long)q, sc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = 4 * q + e;
+      if (i < n) {
+        if constexpr (sizeof(T) == 2) out[i] = f32_to_bf16(bf16_to_f32(x[i]) * sc[e]);
+        else out[i] = x[i] * sc[e];
+      }
+    }
   }
 }
 
@@ -254,14 +275,33 @@ __global__ __launch_bounds__(64) void mask_to_kvlen_kernel(const int64_t* __rest
 using namespace tcavt;
 
 extern "C" int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int out_dtype, int rows,
-                                  int n_valid, int n_out, tcavt_stream_t stream) {
+                                  int n_valid, int n_out, float dropout_p, uint64_t dropout_seed,
+                                  uint32_t dropout_site, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "softmax_rows: dropout_p must be in [0, 1)");
   TCAVT_CHECK_ARG(S && P && rows > 0 && n_valid > 0 && n_out >= n_valid && lds >= n_valid && ldp >= n_out,
                   "softmax_rows: bad args");
   TCAVT_CHECK_ARG(out_dtype == TCAVT_BF16 || out_dtype == TCAVT_F16, "softmax_rows: out_dtype must be bf16 or fp16");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), S,
                      (long)lds, static_cast<bf16_t*>(P), (long)ldp, out_dtype == TCAVT_F16 ? 1 : 0, rows, n_valid,
-                     n_out);
+                     n_out, make_dropout(dropout_p, dropout_seed, dropout_site));
   TCAVT_CHECK_LAUNCH("softmax_rows");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
+                             tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+  TCAVT_CHECK_ARG(dtype == TCAVT_F32 || dtype == TCAVT_BF16, "dropout: dtype must be f32 or bf16");
+  long blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const DropoutP d = make_dropout(p, seed, site);
+  if (dtype == TCAVT_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(x), static_cast<float*>(out), (long)n, d);
+  else
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d);
+  TCAVT_CHECK_LAUNCH("dropout");
   return TCAVT_OK;
 }
 

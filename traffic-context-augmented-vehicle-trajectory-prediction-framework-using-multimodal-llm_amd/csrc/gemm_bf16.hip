@@ -21,6 +21,7 @@
 // scripts/train.py:401-406,446-452,493,754-757 and HF modeling_llama.py
 // :174-176,254-256,279-280).
 #include "common.hpp"
+#include "philox.hpp"
 #include <stdlib.h>
 
 namespace tcavt {
@@ -43,10 +44,13 @@ struct GemmP {
   int batch_inner;
   long sAo, sAi, sWo, sWi, sCo, sCi;
   int xcd_gx;  // XCD partition of the tile grid (block_to_tile)
+  DropoutP drop;  // epilogue dropout (generic epilogue only)
   int prio;  // wave-priority experiment: 0 none, 1 static s_setprio(1) for the upper half of the waves, 2 around MFMA clusters
 };
 
-enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2 };
+// EPI_DROP = EPI_GENERIC + Philox dropout.  A separate instantiation: with the mask code inside the generic
+// epilogue the 256x256 kernel spilled its accumulators (528 B/lane of scratch, 3x slower).
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -83,7 +87,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
   const int nq = 4 * (lane >> 4);
   const int ml = lane & 15;
-  if constexpr (EPI == EPI_GENERIC) {
+  if constexpr (EPI == EPI_GENERIC || EPI == EPI_DROP) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m_base + j * 16 + ml;
@@ -101,6 +105,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         if (p.flags & TCAVT_EPI_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
           v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        if constexpr (EPI == EPI_DROP) {
+          float sc[4];
+          dropout_quad(p.drop, ((unsigned long long)m * (unsigned long long)p.N + (unsigned long long)n) >> 2, sc);
+          v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
         }
         if (p.flags & TCAVT_EPI_RESIDUAL)
           v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
@@ -663,6 +672,11 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.tiles_m = p.tiles_n = 0;
   p.prio = 0;
   p.xcd_gx = 8;
+  TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "gemm_bf16: dropout_p must be in [0, 1)");
+  if (a->dropout_p > 0.f)
+    TCAVT_CHECK_ARG(!(epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)) && batch == 1 && a->N % 4 == 0,
+                    "gemm_bf16: dropout is supported by the un-batched generic epilogue only");
+  p.drop = make_dropout(a->dropout_p, a->dropout_seed, a->dropout_site);
   p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale;
   if (epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE))
     TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
@@ -678,6 +692,11 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
   if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
+  if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
+    TCAVT_CHECK_ARG(!f16, "gemm_bf16: dropout needs bf16 operands");
+    p.prio = 0;
+    return launch<128, 128, 2, 2, EPI_DROP, false, 1>(p, 1, s);
+  }
   if (f16) return dispatch_tile<EPI_GENERIC, true>(p, tile, batch, s);
   return dispatch_tile<EPI_GENERIC, false>(p, tile, batch, s);
 }

@@ -4,6 +4,7 @@
 // (scripts/train.py:945-962).  All of them are tiny next to the decoder stack, so
 // they are written for clarity and coalesced access, not for MFMA.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace tcavt {
 
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ res, long ldr,
                                                        float* __restrict__ C, long ldc, int M, int N,
-                                                       int K, int flags, int k_chunk) {
+                                                       int K, int flags, int k_chunk, DropoutP drop) {
   // split-K: blockIdx.z owns k in [kb, ke); partial sums meet in C (zeroed by the launcher) through float
   // atomics, split 0 adds bias / residual.  Used when the output has too few tiles to fill the chip.
   const int kb = blockIdx.z * k_chunk, ke = min(K, kb + k_chunk);
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         if (flags & TCAVT_EPI_BIAS) v += bias[n];
         if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
+        if (drop.p > 0.f) v *= dropout_one(drop, (unsigned long long)m * (unsigned long long)N + (unsigned long long)n);
         if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
         C[(long)m * ldc + n] = v;
       }
@@ -266,14 +268,18 @@ using namespace tcavt;
 // Launch with split-K when the 64x64 output tiles cannot fill the chip and K is long (lane-polygon FFN:
 // K = 2048 or a contraction over 2048 tokens with 32 output tiles).  Not with ReLU (needs the full sum),
 // not when C aliases the residual (split 0 would read what other splits already added to).
-static int launch_gemm_f32(const float* A, long rsA, long csA, const float* W, long rsW, long csW, const float* bias,
+// max_splits = 2 keeps the result run-to-run reproducible (0 + a + b == 0 + b + a in IEEE arithmetic; three or
+// more addends are order dependent): the forward entry point uses that, because a 1-ulp difference in the
+// lane-polygon embedding is amplified to ~1e-4 by the bf16 decoder downstream; the backward entry point
+// (gradients, tolerance-checked) uses up to 8.
+static int launch_gemm_f32(int max_splits, const float* A, long rsA, long csA, const float* W, long rsW, long csW, const float* bias,
                            const float* residual, long ldr, float* C, long ldc, int M, int N, int K, int flags,
-                           hipStream_t stream, const char* what) {
+                           DropoutP drop, hipStream_t stream, const char* what) {
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   int splits = 1;
-  if (tiles < 128 && K >= 512 && !(flags & TCAVT_EPI_RELU) && residual != C && ldc == N) {
+  if (tiles < 128 && K >= 512 && !(flags & TCAVT_EPI_RELU) && residual != C && ldc == N && drop.p == 0.f) {
     splits = K / 256;
-    if (splits > 8) splits = 8;
+    if (splits > max_splits) splits = max_splits;
     while (splits > 1 && tiles * splits > 512) splits >>= 1;
   }
   int k_chunk = K;
@@ -288,7 +294,7 @@ static int launch_gemm_f32(const float* A, long rsA, long csA, const float* W, l
   }
   dim3 grid((N + 63) / 64, (M + 63) / 64, splits), block(256);
   hipLaunchKernelGGL(gemm_f32_kernel, grid, block, 0, stream, A, rsA, csA, W, rsW, csW, bias, residual, ldr, C, ldc, M,
-                     N, K, flags, k_chunk);
+                     N, K, flags, k_chunk, drop);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: launch failed: %s", what, hipGetErrorString(e));
@@ -299,13 +305,15 @@ static int launch_gemm_f32(const float* A, long rsA, long csA, const float* W, l
 
 extern "C" int tcavt_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
                               const float* bias, const float* residual, int64_t ldr, float* C,
-                              int64_t ldc, int M, int N, int K, int flags, tcavt_stream_t stream) {
+                              int64_t ldc, int M, int N, int K, int flags, float dropout_p,
+                              uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0, "gemm_f32: null pointer or bad shape");
+  TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "gemm_f32: dropout_p must be in [0, 1)");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32: BIAS without bias");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32: RESIDUAL without residual");
   TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32: unsupported flag");
-  return launch_gemm_f32(A, (long)lda, 1L, W, (long)ldw, 1L, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags,
-                         static_cast<hipStream_t>(stream), "gemm_f32");
+  return launch_gemm_f32(2, A, (long)lda, 1L, W, (long)ldw, 1L, bias, residual, (long)ldr, C, (long)ldc, M, N, K, flags,
+                         make_dropout(dropout_p, dropout_seed, dropout_site), static_cast<hipStream_t>(stream), "gemm_f32");
 }
 
 extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, const float* W, int64_t rsW,
@@ -315,8 +323,8 @@ extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, 
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32_strided: BIAS without bias");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32_strided: RESIDUAL without residual");
   TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32_strided: unsupported flag");
-  return launch_gemm_f32(A, (long)rsA, (long)csA, W, (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M,
-                         N, K, flags, static_cast<hipStream_t>(stream), "gemm_f32_strided");
+  return launch_gemm_f32(8, A, (long)rsA, (long)csA, W, (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M,
+                         N, K, flags, make_dropout(0.f, 0, 0), static_cast<hipStream_t>(stream), "gemm_f32_strided");
 }
 
 extern "C" int tcavt_poly_embed(const float* polygon, const float* w_in, const float* b_in,

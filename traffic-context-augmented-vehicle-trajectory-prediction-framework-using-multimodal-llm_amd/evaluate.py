@@ -89,12 +89,16 @@ def evaluate_cv(tracks, seq_len=6, out_len=30, batch_size=16, stride=6, downsamp
     return tot[0] / n, tot[1] / n, tot[2] / n, n
 
 
-def evaluate_model(model, batches, num_candidates=1, process_group=None):
+def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_dropout=False):
     """Test loop on the HIP path.  `batches` yields dicts in custom_collate_fn layout already on the GPU.
     K = 1: train.py:1274-1326; K > 1: test.py:1301-1382 (K forward passes per batch, min over K).
+    mc_dropout=True runs the passes in train mode under no_grad, as test.py:1308-1309 does: the K candidates then
+    differ through dropout (in-kernel Philox masks, one seed per pass).
     Returns dict(ADE, FDE, RMSE, n) averaged over ALL ranks' samples."""
     from . import ops
 
+    was_training = model.training
+    model.train(bool(mc_dropout))
     dev = next(model.parameters()).device
     sums = torch.zeros(5, dtype=torch.float32, device=dev)
     n = 0
@@ -113,6 +117,7 @@ def evaluate_model(model, batches, num_candidates=1, process_group=None):
             ops.traj_metrics(pred, b["target_traj"].contiguous(), ns, sums, None, None, B, num_candidates,
                              pred.shape[-1])
             n += B
+    model.train(was_training)
     stats = torch.cat([sums[2:5].double(), torch.tensor([float(n)], dtype=torch.float64, device=dev)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.all_reduce(stats, group=process_group)

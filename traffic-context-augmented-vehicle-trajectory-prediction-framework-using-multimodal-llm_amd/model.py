@@ -104,6 +104,26 @@ def _bf16(t):
 XATTN_PAD = 64  # key counts of the head cross-attention are padded to a multiple of this
 
 
+class DropoutCtx:
+    """Train-mode dropout bookkeeping for one forward pass: every dropout site of the reference
+    (nn.Dropout / attention-weight dropout of nn.MultiheadAttention / LoRA dropout) gets its own site id,
+    in call order, under one 64-bit seed; the kernels derive the mask from (seed, site, element index) with
+    Philox4x32-10 (csrc/philox.hpp), so nothing is stored and a pass is reproducible from its seed."""
+
+    def __init__(self, seed):
+        self.seed, self.site = int(seed), 0
+
+    def spec(self, p):
+        if p is None or p <= 0.0:
+            return None
+        self.site += 1
+        return (float(p), self.seed, self.site)
+
+
+def _spec(dctx, p):
+    return dctx.spec(p) if dctx is not None else None
+
+
 class _Prepared:
     """Mixin: lazily (re)build packed / bf16 device buffers derived from the parameters."""
 
@@ -148,8 +168,9 @@ def _prep_layer(layer, bf16, decoder=False):
 class _TLayerRunner:
     """Runs post-LN layers on token matrices [M, D] (fp32 master copy x, bf16 shadow xb)."""
 
-    def __init__(self, ws, bf16, nhead, tag, record=None):
+    def __init__(self, ws, bf16, nhead, tag, record=None, dctx=None, p_drop=0.0):
         self.ws, self.bf16, self.nhead, self.tag = ws, bf16, nhead, tag
+        self.dctx, self.p_drop = dctx, p_drop  # train-mode dropout of nn.Transformer*Layer (default 0.1)
         # training: `record` (a list) receives one dict of retained activations per encoder layer, and
         # `layer_tag` gives every layer its own buffers instead of recycling them
         self.record, self.layer_tag = record, ""
@@ -172,9 +193,10 @@ class _TLayerRunner:
         att = self._buf("att", (M, E), act_dt, dev)
         dh = E // self.nhead
         ops.mha(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], att, B, L, L, self.nhead, dh, 1.0 / math.sqrt(dh),
-                key_len=key_len, ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E)
+                key_len=key_len, ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=_spec(self.dctx, self.p_drop))
         y = self._buf("y", (M, E), torch.float32, dev)
-        self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32)
+        self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32,
+                   dropout=_spec(self.dctx, self.p_drop))
         return y
 
     def cross_attn(self, p, x, xb, mem, memb, B, Lq, Lk):
@@ -187,9 +209,10 @@ class _TLayerRunner:
         att = self._buf("att", (M, E), act_dt, dev)
         dh = E // self.nhead
         ops.mha(q, kv[:, :E], kv[:, E:], att, B, Lq, Lk, self.nhead, dh, 1.0 / math.sqrt(dh), ldq=E, ldk=2 * E,
-                ldv=2 * E, ldo=E)
+                ldv=2 * E, ldo=E, dropout=_spec(self.dctx, self.p_drop))
         y = self._buf("y", (M, E), torch.float32, dev)
-        self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32)
+        self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32,
+                   dropout=_spec(self.dctx, self.p_drop))
         return y
 
     def norm(self, y, n, name):
@@ -204,9 +227,10 @@ class _TLayerRunner:
         ff = p.w1.shape[0]
         act_dt = torch.bfloat16 if self.bf16 else torch.float32
         f = self._buf("ffh", (M, ff), act_dt, dev)
-        self._gemm(xb if self.bf16 else x, p.w1, out=f, bias=p.b1, relu=True, out_dtype=act_dt)
+        self._gemm(xb if self.bf16 else x, p.w1, out=f, bias=p.b1, relu=True, out_dtype=act_dt,
+                   dropout=_spec(self.dctx, self.p_drop))
         y = self._buf("y2", (M, x.shape[1]), torch.float32, dev)
-        self._gemm(f, p.w2, out=y, bias=p.b2, residual=x, out_dtype=torch.float32)
+        self._gemm(f, p.w2, out=y, bias=p.b2, residual=x, out_dtype=torch.float32, dropout=_spec(self.dctx, self.p_drop))
         return y
 
     def encoder_layer(self, p, x, xb, B, L, key_len=None, slot=0):
@@ -246,6 +270,7 @@ class LanePolygonEncoder(nn.Module, _Prepared):
         self._prep = None
         self.save_for_backward = False  # set by training.Trainer: keep per-layer activations
         self.saved = None
+        self.dropout_p, self.dctx = 0.1, None  # nn.TransformerEncoderLayer default; dctx set per forward by the owner
 
     def _prepare(self):
         return [_prep_layer(l, bf16=False) for l in self.encoder.layers]
@@ -256,7 +281,8 @@ class LanePolygonEncoder(nn.Module, _Prepared):
         lens = poly_len_list if torch.is_tensor(poly_len_list) else torch.tensor(list(poly_len_list), dtype=torch.int32)
         lens = lens.to(device=dev, dtype=torch.int32).contiguous()
         keep = self.save_for_backward
-        run = _TLayerRunner(self._ws, bf16=False, nhead=self.nhead, tag="poly", record=[] if keep else None)
+        run = _TLayerRunner(self._ws, bf16=False, nhead=self.nhead, tag="poly", record=[] if keep else None,
+                            dctx=self.dctx, p_drop=self.dropout_p)
         x = self._ws.get("poly.x0", (B * P, D), torch.float32, dev)
         polygon_batch = polygon_batch.contiguous()
         ops.poly_embed(polygon_batch, self.input_proj.weight, self.input_proj.bias,
@@ -287,6 +313,7 @@ class BlipQFormer(nn.Module, _Prepared):
         self.decoder = _LayerStack(num_decoder_layers, hidden_size, dim_feedforward, decoder=True)
         self._ws = _Workspace()
         self._prep = None
+        self.dropout_p, self.dctx = 0.1, None  # nn.Transformer*Layer default dropout
 
     def _prepare(self):
         return SimpleNamespace(
@@ -297,7 +324,7 @@ class BlipQFormer(nn.Module, _Prepared):
         B, Tv, Dv = vision_embs.shape
         dev, E, Nq = vision_embs.device, self.hidden_size, self.num_query_tokens
         P = self._prepared()
-        run = _TLayerRunner(self._ws, bf16=True, nhead=self.nhead, tag="qf")
+        run = _TLayerRunner(self._ws, bf16=True, nhead=self.nhead, tag="qf", dctx=self.dctx, p_drop=self.dropout_p)
         vb = self._ws.get("qf.vb", (B * Tv, Dv), torch.bfloat16, dev)
         ops.cast_bf16(vision_embs.contiguous().view(B * Tv, Dv), out=vb)
         x = self._ws.get("qf.x0", (B * Tv, E), torch.float32, dev)
@@ -396,6 +423,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self.hidden_size = self.shape.hidden
         self.gemm_tile = 0
         self.timer = None  # optional profiling.KernelTimer (bench.py roofline leg)
+        self.dctx = None   # DropoutCtx of the current forward (LoRA dropout on the adapter branch input)
         self._ws = _Workspace()
         self._prep = None
         self._rope = {}
@@ -456,7 +484,12 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         for d in P.layers:
             ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
             if self.use_lora:
-                ops.gemm_bf16(xn, d.a_cat, out=t, acc_scale=self.lora_alpha / self.lora_r, tile=128)
+                xl = xn
+                dspec = _spec(self.dctx, self.lora_dropout)
+                if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
+                    xl = ws.get("ll.xn_drop", (M, H), torch.bfloat16, dev)
+                    ops.dropout(xn, xl, *dspec)
+                ops.gemm_bf16(xl, d.a_cat, out=t, acc_scale=self.lora_alpha / self.lora_r, tile=128)
                 mark("qkv")
                 ops.gemm_bf16(xn, d.w_qkv, out=qkv, a2=t, w2=d.b_ext, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
                 done("qkv")
@@ -579,6 +612,7 @@ class SelfAttentionBlock(nn.Module):
                                   _Linear(embed_dim * 4, embed_dim)])
         self.norm2 = _Norm(embed_dim)
         self._ws = _Workspace()
+        self.dropout_p, self.dctx = dropout_rate, None
 
     def forward_tokens(self, tok, B, T):
         """tok fp32 [B*T, E] (batch-first tokens) -> [B*T, E].  Residuals start from the NORMED
@@ -591,16 +625,18 @@ class SelfAttentionBlock(nn.Module):
         ops.gemm_f32(xn, self.mha.in_proj_weight, out=qkv, bias=self.mha.in_proj_bias)
         att = ws.get("sab.att", (M, E), torch.float32, dev)
         dh = E // self.nhead
+        dc, pd = self.dctx, self.dropout_p
         ops.mha(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], att, B, T, T, self.nhead, dh, 1.0 / math.sqrt(dh),
-                ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E)
+                ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=_spec(dc, pd))
         res1 = ws.get("sab.res1", (M, E), torch.float32, dev)
-        ops.gemm_f32(att, self.mha.out_proj.weight, out=res1, bias=self.mha.out_proj.bias, residual=xn)
+        ops.gemm_f32(att, self.mha.out_proj.weight, out=res1, bias=self.mha.out_proj.bias, residual=xn,
+                     dropout=_spec(dc, pd))
         rn = ws.get("sab.rn", (M, E), torch.float32, dev)
         ops.layernorm(res1, self.norm2.weight, self.norm2.bias, 1e-5, out_f32=rn)
         f = ws.get("sab.f", (M, 4 * E), torch.float32, dev)
-        ops.gemm_f32(rn, self.ffn[0].weight, out=f, bias=self.ffn[0].bias, relu=True)
+        ops.gemm_f32(rn, self.ffn[0].weight, out=f, bias=self.ffn[0].bias, relu=True, dropout=_spec(dc, pd))
         out = ws.get("sab.out", (M, E), torch.float32, dev)
-        ops.gemm_f32(f, self.ffn[3].weight, out=out, bias=self.ffn[3].bias, residual=rn)
+        ops.gemm_f32(f, self.ffn[3].weight, out=out, bias=self.ffn[3].bias, residual=rn, dropout=_spec(dc, pd))
         return out
 
     def forward(self, x):
@@ -661,6 +697,7 @@ class TransformerLTSF(nn.Module, _Prepared):
         self._ws = _Workspace()
         self._prep = None
         self.save_for_backward = False  # set by training.Trainer
+        self.dropout_p, self.dctx = dropout_rate, None
 
     def _prepare(self):
         dec, C = self.decoder, self.d_model
@@ -706,7 +743,8 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.ltsf_decode(e, P.dec_w, P.dec_b, lane, d0, B, C, T, To)
         if dec.use_post_mlp:
             hid = ws.get("lt.hid", (B, dec.post_mlp[0].weight.shape[0]), torch.float32, dev)
-            ops.gemm_f32(d0, dec.post_mlp[0].weight, out=hid, bias=dec.post_mlp[0].bias, relu=True)
+            ops.gemm_f32(d0, dec.post_mlp[0].weight, out=hid, bias=dec.post_mlp[0].bias, relu=True,
+                         dropout=_spec(self.dctx, self.dropout_p))
             d1 = ws.get("lt.dec1", (B, C * To), torch.float32, dev)
             ops.gemm_f32(hid, dec.post_mlp[3].weight, out=d1, bias=dec.post_mlp[3].bias)
         else:
@@ -741,7 +779,7 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
                          sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh))
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
-        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp)
+        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=_spec(self.dctx, self.dropout_p))
         att = ws.get("lt.att", (B * To, H), torch.bfloat16, dev)
         ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
                          sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
@@ -787,6 +825,9 @@ class MultiModalTrajectoryModel(nn.Module):
         self.feature_size, self.out_len, self.seq_len = feature_size, out_len, seq_len
         self.overlap_streams = True  # side stream for the LLM-independent small-kernel chains (see forward)
         self._side = None
+        # Train-mode dropout (the MC-dropout K-candidate protocol, test.py:1301-1342): active when the module
+        # is in .train() mode; every forward uses seed dropout_seed + number of forwards so far.
+        self.dropout_seed, self._fwd_count = 0x5EED, 0
 
     @classmethod
     def from_config(cls, cfg: ModelConfig):
@@ -823,6 +864,12 @@ class MultiModalTrajectoryModel(nn.Module):
         B = x.size(0)
         dev = x.device
         x = x.contiguous()
+        dctx = None
+        if self.training:
+            dctx = DropoutCtx(self.dropout_seed + self._fwd_count)
+            self._fwd_count += 1
+        self.lane_polygon_encoder.dctx = self.mllm.qformer.dctx = self.mllm.llama_wrapper.dctx = dctx
+        self.ltsf.dctx = self.ltsf.attn_block.dctx = dctx
         # The lane-polygon encoder and the LLM-independent half of the LTSF (token projection, N-Linear
         # encoder, self-attention block) are chains of small launches that leave most CUs idle; they run
         # on a side stream, concurrently with the Q-Former / decoder stack, and join before the LTSF head.

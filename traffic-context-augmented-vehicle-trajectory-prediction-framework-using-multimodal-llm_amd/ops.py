@@ -37,8 +37,16 @@ def _need(t, numel, name):
         raise capi.TcavtError(f"{name}: buffer has {t.numel()} elements, kernel needs {numel}")
 
 
+def _drop(d):
+    """dropout spec (p, seed, site) or None -> (p, seed, site) ctypes-ready."""
+    if d is None:
+        return 0.0, 0, 0
+    p, seed, site = d
+    return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFF
+
+
 def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False, residual=None, a2=None,
-              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0):
+              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None):
     """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K] bf16, w [N,K] bf16.
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
@@ -95,6 +103,7 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
     args.epilogue = epi
     args.tile = tile
     args.acc_scale = acc_scale
+    args.dropout_p, args.dropout_seed, args.dropout_site = _drop(dropout)
     check(lib().tcavt_gemm_bf16(ctypes.byref(args), stream_ptr()), "tcavt_gemm_bf16")
     return out
 
@@ -145,14 +154,25 @@ def gemm_batched(a, w, out, *, M, N, K, lda, ldw, ldc, batch, inner, sA, sW, sC,
     return out
 
 
-def softmax_rows(s, p, rows, n_valid, n_out, lds, ldp):
+def softmax_rows(s, p, rows, n_valid, n_out, lds, ldp, dropout=None):
     _req(s, torch.float32, "softmax_rows.s")
     if p.dtype not in (torch.bfloat16, torch.float16):
         raise capi.TcavtError("softmax_rows.p: must be bf16 or fp16")
     if _avail(s) < (rows - 1) * lds + n_valid or _avail(p) < (rows - 1) * ldp + n_out:
         raise capi.TcavtError("softmax_rows: buffer too small")
-    check(lib().tcavt_softmax_rows(ptr(s), lds, ptr(p), ldp, _DT[p.dtype], rows, n_valid, n_out, stream_ptr()),
-          "tcavt_softmax_rows")
+    dp, dseed, dsite = _drop(dropout)
+    check(lib().tcavt_softmax_rows(ptr(s), lds, ptr(p), ldp, _DT[p.dtype], rows, n_valid, n_out, dp, dseed, dsite,
+                                   stream_ptr()), "tcavt_softmax_rows")
+
+
+def dropout(x, out, p, seed, site):
+    """out = x * keep / (1 - p) with the Philox mask of (seed, site); x/out fp32 or bf16, in place allowed."""
+    if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16):
+        raise capi.TcavtError("dropout: x and out must both be fp32 or both bf16")
+    _need(out, x.numel(), "dropout.out")
+    check(lib().tcavt_dropout(ptr(x), ptr(out), x.numel(), _DT[x.dtype], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                              int(site) & 0xFFFFFFFF, stream_ptr()), "tcavt_dropout")
+    return out
 
 
 def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None):
@@ -221,7 +241,7 @@ def attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, scale):
           "tcavt_attn_causal_gqa")
 
 
-def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None):
+def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None, dropout=None):
     """q/k/v may be column slices of wider row-major buffers: pass the slice's data_ptr tensor and ld."""
     in_dt = BF16 if q.dtype == torch.bfloat16 else F32
     out_dt = BF16 if out.dtype == torch.bfloat16 else F32
@@ -238,10 +258,10 @@ def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None
     _need(key_len, B, "mha.key_len")
     check(lib().tcavt_mha(ptr(q), ldq if ldq else q.stride(-2), ptr(k), ldk if ldk else k.stride(-2), ptr(v),
                           ldv if ldv else v.stride(-2), ptr(out), ldo if ldo else out.stride(-2), ptr(key_len), B,
-                          Lq, Lk, nh, dh, scale, in_dt, out_dt, stream_ptr()), "tcavt_mha")
+                          Lq, Lk, nh, dh, scale, in_dt, out_dt, *_drop(dropout), stream_ptr()), "tcavt_mha")
 
 
-def gemm_f32(a, w, out=None, bias=None, relu=False, residual=None):
+def gemm_f32(a, w, out=None, bias=None, relu=False, residual=None, dropout=None):
     _req(a, torch.float32, "gemm_f32.a")
     _req(w, torch.float32, "gemm_f32.w")
     M, K = a.shape
@@ -258,7 +278,7 @@ def gemm_f32(a, w, out=None, bias=None, relu=False, residual=None):
         raise capi.TcavtError("gemm_f32.residual: smaller than (M, N)")
     check(lib().tcavt_gemm_f32(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(residual),
                                residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), M, N, K,
-                               flags, stream_ptr()), "tcavt_gemm_f32")
+                               flags, *_drop(dropout), stream_ptr()), "tcavt_gemm_f32")
     return out
 
 
