@@ -18,7 +18,7 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 384, 256), (300, 208, 128), (1024, 768, 512)])
 def test_gemm_plain(gpu, tile, M, N, K):
     from tcavt_amd import ops
@@ -36,6 +36,34 @@ def test_gemm_plain(gpu, tile, M, N, K):
     assert torch.equal(out16, _bf(out32))  # bf16 output is the RNE rounding of the fp32 result
 
 
+@pytest.mark.parametrize("K", [64, 128, 448])
+def test_gemm_w4_matches_8wave(gpu, K):
+    """The 4-wave 256x256 kernel (tile code 257: whole tiles, one K source) accumulates every output element in the
+    same order as the 8-wave kernel, so the two are bit-identical on every epilogue; odd / tiny K-tile counts exercise
+    the pipeline prologue and tail.  Plain fp32 result also against torch."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator(device="cpu").manual_seed(K)
+    M, N = 512, 768
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    for kw in (dict(), dict(residual=res), dict(bias=bias, relu=True, residual=res), dict(silu_mul=True)):
+        for dt in (torch.float32, torch.bfloat16):
+            r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
+            r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=257, **kw)
+            assert torch.equal(r8, r4), (sorted(kw), dt)
+    out = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257)
+    assert _rel(out, a.float() @ w.float().T) < 2e-6
+    h = res.clone()
+    ops.gemm_bf16(a, w, out=h, residual=h, tile=257)  # in place on the residual stream, as the decoder uses it
+    assert torch.equal(h, ops.gemm_bf16(a, w, out_dtype=torch.float32, residual=res, tile=256))
+    with pytest.raises(Exception):
+        ops.gemm_bf16(a[:300], w, out_dtype=torch.float32, tile=257)  # not whole tiles -> refused, not mis-computed
+
+
 def test_gemm_asymmetric_identity(gpu):
     """A = I against an asymmetric W catches a transposed C write."""
     from tcavt_amd import ops
@@ -48,7 +76,7 @@ def test_gemm_asymmetric_identity(gpu):
     assert torch.equal(out, w.float().T.contiguous())
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256])
 def test_gemm_bias_relu_residual_dual(gpu, tile):
     from tcavt_amd import ops
 
@@ -70,7 +98,7 @@ def test_gemm_bias_relu_residual_dual(gpu, tile):
     assert _rel(h, a.float() @ w.float().T + res) < 2e-6
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256])
 def test_gemm_silu_mul(gpu, tile):
     from tcavt_amd import ops
     from tcavt_amd.layout import interleave_gate_up

@@ -397,6 +397,28 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
     }
   };
 
+  if constexpr (PIPE == 2) {
+    // ---- deep main loop for launches that cannot fill the chip (a few dozen workgroups, each walking its K
+    // range alone): four LDS stages, up to three K-tiles of DMA in flight, so that a K-tile costs its issue
+    // time instead of a full HBM / L2 round trip (the weights of these layers are HBM-cold inside the model).
+    // Counted vmcnt (the wave's own pieces of the NEWER tiles stay in flight) and a raw barrier per K-tile:
+    // the barrier publishes tile t and proves everyone is done with tile t-1, whose stage the next DMA reuses.
+    constexpr int NS = 4;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nt) stage(s, s);
+    for (int t = 0; t < nt; ++t) {
+      const int rem = nt - 1 - t;
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ROUNDS) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUNDS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (t + NS - 1 < nt) stage((t + NS - 1) % NS, t + NS - 1);
+      compute(t % NS);
+    }
+    gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    return;
+  }
   if (p.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   // ---- main loop: stage t+1 while computing t; one drain+barrier per K-tile
   stage(0, 0);
@@ -462,7 +484,7 @@ static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.xcd_gx = choose_xcd_partition(p);
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = (PIPE == 2 ? 4 : 2) * (BM + BN) * 128;
   auto kfn = gemm_bf16_kernel<BM, BN, WARPS_M, WARPS_N, EPI, F16, PIPE>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
@@ -861,9 +883,23 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
       return TCAVT_ERR_ARG;
     case 127: q.prio = 2; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
     case 126: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
-    default:  // 128: interleaved DMA issue, no priority games (4 waves, one per SIMD per workgroup)
+    case 125: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
+    case 124: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
+    default: {  // 128
       q.prio = 0;
+      // grids that leave CUs idle: the 4-stage loop (latency bound, one workgroup per CU is no loss);
+      // fuller grids: interleaved DMA issue, 64 KiB of LDS so that two workgroups share a CU
+      const long wgs = (long)((q.M + 127) / 128) * ((q.N + 127) / 128) * batch;
+      static const bool no_deep = getenv("TCAVT_GEMM_NO_DEEP") != nullptr;  // A/B switches
+      static const bool no_64 = getenv("TCAVT_GEMM_NO_64") != nullptr;
+      if constexpr (EPI != EPI_ROPE) {
+        // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
+        // each K-tile costing a quarter of the DMA issue and MFMA time
+        if ((tile == 64 || (tile == 0 && wgs < 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
+      }
+      if (wgs <= 256 && !no_deep) return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
       return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
+    }
   }
 }
 
@@ -920,7 +956,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 269 && a->tile != 251 && a->tile != 254) || a->tile == 127 || a->tile == 126,
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 269 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;
@@ -958,7 +994,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     // 32 x 12 = 384 tiles = 1.5 waves, is the boundary case: 111 us on 256x256 vs 114 us on 128x128).
     const long t256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * batch;
     const long waves = (t256 + 255) / 256;
-    tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 128;
+    tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 0;  // 0: dispatch_tile picks 128 / 64
     // whole 256x256 tiles, one K source, bf16, no RoPE: the 4-wave kernel (gate|up 406 vs 434 us, down 204 vs 218,
     // o 57.5 vs 60 on the 8-wave kernel)
     if (tile == 256 && !f16 && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && !(epi & TCAVT_EPI_ROPE))
