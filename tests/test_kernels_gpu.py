@@ -55,6 +55,16 @@ def test_gemm_w4_matches_8wave(gpu, K):
             r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
             r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=257, **kw)
             assert torch.equal(r8, r4), (sorted(kw), dt)
+    # fused q|k|v form: RoPE epilogue (bf16 out) with and without the LoRA second K source
+    pos = torch.arange(128, dtype=torch.float32)
+    ang = pos[:, None] * (1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64)))[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    a2 = _bf(torch.randn(M, 64, generator=g)).to(dev)
+    w2 = _bf(torch.randn(N, 64, generator=g) * 0.05).to(dev)
+    for kw in (dict(rope=(cos, sin, 512)), dict(rope=(cos, sin, 512), a2=a2, w2=w2)):
+        r8 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=256, **kw)
+        r4 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=257, **kw)
+        assert torch.equal(r8, r4), sorted(kw)
     out = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257)
     assert _rel(out, a.float() @ w.float().T) < 2e-6
     h = res.clone()

@@ -25,9 +25,13 @@ def check():
     ang = pos[:, None] * inv[None, :]
     cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
     for c in codes:
-        for kw in (dict(), dict(bias=bias, relu=True, residual=res), dict(silu_mul=True), dict(rope=(cos, sin, 512))):
-            r0 = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=256, **kw)
-            r1 = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=c, **kw)
+        a2 = torch.randn(Mc, 64, generator=g).to(torch.bfloat16).to(dev)
+        w2 = (torch.randn(N, 64, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+        for kw in (dict(), dict(bias=bias, relu=True, residual=res), dict(silu_mul=True), dict(rope=(cos, sin, 512)),
+                   dict(rope=(cos, sin, 512), a2=a2, w2=w2)):
+            dt = torch.bfloat16 if "rope" in kw else torch.float32
+            r0 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
+            r1 = ops.gemm_bf16(a, w, out_dtype=dt, tile=c, **kw)
             torch.cuda.synchronize()
             ok = torch.equal(r0, r1)
             print(f"check tile={c} {sorted(kw)}: {'bit-equal' if ok else 'MISMATCH max %.3e' % (r0 - r1).abs().max().item()}", flush=True)
@@ -75,6 +79,12 @@ for name, N, K in (("qkv", 3072, 2048), ("o", 2048, 2048), ("gateup", 16384, 204
     ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(16)]
     out = torch.empty(M, N // 2 if name == "gateup" else N, dtype=torch.bfloat16, device=dev)
     kw = dict(silu_mul=True) if name == "gateup" else {}
+    if name == "qkv":
+        pos = torch.arange(256, dtype=torch.float32)
+        inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64))
+        ang = pos[:, None] * inv[None, :]
+        kw = dict(rope=(ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev), 2560),
+                  a2=torch.randn(M, 64, device=dev).to(torch.bfloat16), w2=(torch.randn(N, 64, device=dev) * 0.02).to(torch.bfloat16))
     line = f"{name:7s}"
     for tile in [256] + codes:
         ms = timeit(lambda i: ops.gemm_bf16(a, ws[i % 16], out=out, tile=tile, **kw))

@@ -89,14 +89,16 @@ __device__ __forceinline__ float silu_mul(float g, float u) {
   return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * u;
 }
 
-template <int TM, int TN, int EPI>
+// WHOLE_ONLY: the caller guarantees whole tiles (the 4-wave kernel); the bounds-checked paths are compiled out where
+// a fast path covers the form.
+template <int TM, int TN, int EPI, bool WHOLE_ONLY = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
   // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
   const int nq = 4 * (lane >> 4);
   const int ml = lane & 15;
   // Fast paths for the forms the decoder launches (whole wave tile inside the matrix): row pointers hoisted,
   // no per-quad flag tests -- the general path below costs ~55 instructions per quad, these ~8.
-  const bool whole = m_base + TM * 16 <= p.M && n_base + TN * 16 <= p.N;  // wave-uniform
+  const bool whole = WHOLE_ONLY || (m_base + TM * 16 <= p.M && n_base + TN * 16 <= p.N);  // wave-uniform
   if constexpr (EPI == EPI_GENERIC) {
     if (whole && p.acc_scale == 1.f && p.out_kind == TCAVT_F32 && p.flags == TCAVT_EPI_RESIDUAL) {
 #pragma unroll
@@ -140,6 +142,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       }
       return;
     }
+  }
+  if constexpr (EPI == EPI_ROPE) {
+    if (whole && p.out_kind == TCAVT_BF16) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int m = m_base + j * 16 + ml;
+        const int pos = m % p.rope_L;
+        const float* crp = p.cosT + pos * 32 + nq;
+        const float* srp = p.sinT + pos * 32 + nq;
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base + nq;
+#pragma unroll
+        for (int hh = 0; hh < TN / 4; ++hh) {
+          const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
+            if (rot) {
+              const f32x4 c = *reinterpret_cast<const f32x4*>(crp + i * 16);
+              const f32x4 s = *reinterpret_cast<const f32x4*>(srp + i * 16);
+              const f32x4 l2 = lo * c - hi * s;
+              const f32x4 h2 = hi * c + lo * s;
+              lo = l2; hi = h2;
+            }
+            *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3])};
+            *reinterpret_cast<u32x2*>(crow + hh * 64 + 32 + i * 16) = u32x2{pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (WHOLE_ONLY && EPI == EPI_ROPE) {
+    return;  // the 4-wave kernel is dispatched for bf16 output only on this epilogue (launch_w4 checks)
   }
   if constexpr (EPI == EPI_GENERIC || EPI == EPI_DROP) {
 #pragma unroll
@@ -674,15 +709,41 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const bf16_t* srcA = p.A + (long)(m0 + wave * 8 + rl) * p.lda + csw * 8;
   const bf16_t* srcW = p.W + (long)(n0 + wave * 8 + rl) * p.ldw + csw * 8;
   const long stepA = 32 * p.lda, stepW = 32 * p.ldw;
-  const int nt = p.K >> 6;
+  // second K source (LoRA: A2 = x.A_cat^T, W2 = B_ext): its 64-deep tiles follow the main ones
+  constexpr bool HASK2 = EPI == EPI_ROPE;  // only the fused q|k|v projection uses it
+  const bf16_t* srcA2 = nullptr;
+  const bf16_t* srcW2 = nullptr;
+  long stepA2 = 0, stepW2 = 0;
+  const int nt1 = p.K >> 6;
+  int nt = nt1;
+  if constexpr (HASK2) {
+    if (p.K2 > 0) {
+      srcA2 = p.A2 + (long)(m0 + wave * 8 + rl) * p.lda2 + csw * 8;
+      srcW2 = p.W2 + (long)(n0 + wave * 8 + rl) * p.ldw2 + csw * 8;
+      stepA2 = 32 * p.lda2;
+      stepW2 = 32 * p.ldw2;
+      nt += p.K2 >> 6;
+    }
+  }
 
-  auto piece = [&](int buf, int t, int r) {
+  struct Src {
+    const bf16_t* a;
+    const bf16_t* w;
+    long sa, sw;
+  };
+  auto tsrc = [&](int t) -> Src {
     t = min(t, nt - 1);  // the last two K-tiles re-fetch the last tile into a free buffer (keeps the loop body uniform)
+    if constexpr (HASK2) {
+      if (t >= nt1) return Src{srcA2 + (t - nt1) * 64, srcW2 + (t - nt1) * 64, stepA2, stepW2};
+    }
+    return Src{srcA + t * 64, srcW + t * 64, stepA, stepW};
+  };
+  auto piece = [&](int buf, const Src& s, int r) {
     char* dst = smem + buf * TILE_BYTES + (r * NW + wave) * 1024;
     if (r < 8)
-      glds16(srcA + r * stepA + t * 64, dst);
+      glds16(s.a + r * s.sa, dst);
     else
-      glds16(srcW + (r - 8) * stepW + t * 64, dst);
+      glds16(s.w + (r - 8) * s.sw, dst);
   };
 
   const int fsw = (lane >> 1) & 7;
@@ -702,12 +763,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   auto ldw = [&](const char* base, int off, int i) { return *reinterpret_cast<const bf16x8*>(base + wrow + i * 2048 + off); };
 
   // ---- prologue: tile 0 (burst), publish, first pieces of tile 1, fragments F0(0)
+  {
+    const Src s0 = tsrc(0);
 #pragma unroll
-  for (int r = 0; r < NP; ++r) piece(0, 0, r);
+    for (int r = 0; r < NP; ++r) piece(0, s0, r);
+  }
   __syncthreads();
+  Src sn1 = tsrc(1);  // source of tile t+1, carried from iteration to iteration (sn1(t+1) = sn2(t))
   if (nt > 1) {
 #pragma unroll
-    for (int r = 0; r < EARLY; ++r) piece(1, 1, r);
+    for (int r = 0; r < EARLY; ++r) piece(1, sn1, r);
   }
 #pragma unroll
   for (int j = 0; j < TM; ++j) x0[j] = ldx(smem, off0, j);
@@ -722,6 +787,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     constexpr bool dma = !(DBG & 1), bar = !(DBG & 2), frd = !(DBG & 4);
     const char* base = smem + cur * TILE_BYTES;
     const char* nbase = smem + (cur ^ 1) * TILE_BYTES;
+    Src sn2;  // source of tile t+2, put together step by step in the shadow of the bare MFMAs of phase B1
+    int koff2 = 0;
+    bool second2 = false;
     // ---- phase A: MFMAs on F0 | load F1 (second 32-deep half of tile t) | rest of the DMA for tile t+1
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -739,9 +807,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           else w1[idx - TM] = ldw(base, off1, idx - TM);
         }
         if (!S1) {
-          if (dma && more && idx % SPREAD == SPREAD - 1 && EARLY + idx / SPREAD < NP) piece(cur ^ 1, t + 1, EARLY + idx / SPREAD);
+          if (dma && more && idx % SPREAD == SPREAD - 1 && EARLY + idx / SPREAD < NP) piece(cur ^ 1, sn1, EARLY + idx / SPREAD);
         } else {
-          if (dma && more && idx >= 16 && (idx & 3) == 3 && EARLY + (idx - 16) / 4 < NP) piece(cur ^ 1, t + 1, EARLY + (idx - 16) / 4);
+          if (dma && more && idx >= 16 && (idx & 3) == 3 && EARLY + (idx - 16) / 4 < NP) piece(cur ^ 1, sn1, EARLY + (idx - 16) / 4);
         }
       }
     }
@@ -749,8 +817,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < TN - B2R; ++i)
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+      for (int j = 0; j < TM; ++j) {
         mfma_agpr(acc[i][j], w1[i], x1[j]);
+        const int idx = i * TM + j;
+        if (idx == 0) {
+          const int tt = min(t + 2, nt - 1);  // clamp: see tsrc
+          second2 = HASK2 && tt >= nt1;
+          koff2 = (second2 ? tt - nt1 : tt) * 64;
+        }
+        if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
+        if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
+        if (idx == 9) {
+          sn2.sa = second2 ? stepA2 : stepA;
+          sn2.sw = second2 ? stepW2 : stepW;
+        }
+      }
     if (more && bar && (DBG & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA wait (timing only)
     else if (more && bar) __syncthreads();  // tile t+1 has landed for everyone; nobody reads tile t any more
     // ---- phase B2: last 16 MFMAs on F1 | load F0 of tile t+1 | first DMA pieces of tile t+2
@@ -768,10 +849,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           if (idx < TM) x0[idx] = ldx(nbase, off0, idx);
           else w0[idx - TM] = ldw(nbase, off0, idx - TM);
         }
-        if (dma && more2 && (idx & 3) == 3 && (idx >> 2) < EARLY) piece(cur, t + 2, idx >> 2);
+        if (dma && more2 && (idx & 3) == 3 && (idx >> 2) < EARLY) piece(cur, sn2, idx >> 2);
       }
     }
     cur ^= 1;
+    sn1 = sn2;
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
@@ -792,7 +874,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-  gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * 128, n0 + wn * 128, lane);
+  gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * 128, n0 + wn * 128, lane);
 }
 
 template <int EPI, int B2R, int DBG = 0>
@@ -860,7 +942,8 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
     case 257: case 258: case 259: case 268: case 269:
       if constexpr (!F16) {
-        if (batch == 1 && q.K2 == 0 && q.M % 256 == 0 && q.N % 256 == 0) {
+        if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
+            (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16)) {
           if (tile == 268) return launch_w4<EPI, 2, 16>(q, stream);
           if (tile == 269) return launch_w4<EPI, 2, 32>(q, stream);
           if (tile == 257) return launch_w4<EPI, 2>(q, stream);
@@ -997,7 +1080,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 0;  // 0: dispatch_tile picks 128 / 64
     // whole 256x256 tiles, one K source, bf16, no RoPE: the 4-wave kernel (gate|up 406 vs 434 us, down 204 vs 218,
     // o 57.5 vs 60 on the 8-wave kernel)
-    if (tile == 256 && !f16 && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && !(epi & TCAVT_EPI_ROPE))
+    if (tile == 256 && !f16 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 &&
+        ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == TCAVT_BF16 : K2 == 0))
       tile = 257;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
