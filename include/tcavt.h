@@ -79,6 +79,8 @@ int tcavt_init(int device, int* num_cus);
 #define TCAVT_EPI_ROPE 16
 #define TCAVT_EPI_BIAS_ROW 32 /* acc += bias[m] (bias per output ROW; used when the roles of
                                  activations and weights are swapped to emit a transposed result) */
+#define TCAVT_EPI_ACCUM 64    /* tcavt_gemm_f32[_strided] only: C already holds a valid partial result (zeros or an
+                                 earlier gradient contribution); the product is ADDED to it and no memset is issued */
 
 typedef struct tcavt_gemm_args {
   const void* A;   int64_t lda;  /* bf16 [M][K]  */

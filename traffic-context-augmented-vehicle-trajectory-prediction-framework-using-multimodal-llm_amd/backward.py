@@ -9,7 +9,9 @@ graph out stage by stage, in reverse, on the activations the forward retained
 Precision: fp32 wherever the forward is fp32; the cross-attention projections run their backward
 contractions in bf16 MFMA with fp32 accumulation (standard mixed precision), writing fp32 gradients.
 """
+import contextlib
 import math
+import os
 
 import torch
 
@@ -50,11 +52,64 @@ class GradBook:
         return o + _rup(sz, 4)
 
 
+class _Fork:
+    """Run the enclosed launches on `stream`, ordered after everything enqueued so far on the current stream."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+
 class Backward:
+    """Stream layout.  The backward of the trainable part is ~200 small launches; most of them are latency bound
+    and leave the chip idle.  Only the activation gradients form a dependency chain: every weight / bias gradient
+    (g_y^T x, column sums, their transposes and memsets) is a LEAF that nothing downstream reads.  The chain stays
+    on the calling stream, the leaves go to a second stream, and the lane-polygon encoder's backward (independent of
+    the LTSF encoder's once d(poly_emb) is known) to a third; everything joins before `run` returns.
+    TCAVT_BW_SERIAL=1 keeps all of it on one stream (A/B, debugging)."""
+
     def __init__(self, model, book: GradBook, prefix_ltsf="ltsf.", prefix_poly="lane_polygon_encoder."):
         self.m, self.book = model, book
         self.pl, self.pp = prefix_ltsf, prefix_poly
         self.ws = model.ltsf._ws  # scratch for gradient activations
+        self._leaf_streams, self._poly_stream, self._leaf_i = None, None, 0
+        self._serial = os.environ.get("TCAVT_BW_SERIAL", "") == "1"
+
+    # ---- streams ---------------------------------------------------------------------------
+    def _multi(self):
+        return (not self._serial) and self.book.grads.device.type == "cuda"
+
+    def _ensure_streams(self):
+        if self._multi() and self._leaf_streams is None:
+            dev = self.book.grads.device
+            n = int(os.environ.get("TCAVT_BW_LEAF_STREAMS", "2"))
+            self._leaf_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n))]
+            self._poly_stream = torch.cuda.Stream(device=dev)
+
+    def _leaf(self, pin=None):
+        """Context for leaf work (weight / bias gradients): a leaf stream, behind the current stream's queue.
+        Leaves are independent of one another and alternate between the streams [1:]; the one chain of leaves that
+        does depend on earlier leaves (cross-attention K/V branch: d(k), d(v) -> their in-projection weight gradients,
+        sharing one transposed copy of the hidden states) is pinned to stream 0."""
+        if not self._multi():
+            return contextlib.nullcontext()
+        self._ensure_streams()
+        cur = torch.cuda.current_stream()
+        if any(cur == s for s in self._leaf_streams):
+            return contextlib.nullcontext()
+        if pin is not None or len(self._leaf_streams) == 1:
+            return _Fork(self._leaf_streams[0])
+        self._leaf_i = self._leaf_i % (len(self._leaf_streams) - 1) + 1
+        return _Fork(self._leaf_streams[self._leaf_i])
 
     # ---- helpers ---------------------------------------------------------------------------
     def _buf(self, name, shape, dtype=torch.float32, zero=False):
@@ -65,14 +120,15 @@ class Backward:
         """y = x W^T + b (fp32).  x [M,K], W [N,K], gy [M,N] -> gW [N,K], gb [N], optional gx [M,K]."""
         M, K = x.shape
         N = W.shape[0]
-        ops.gemm_f32_strided(gy, 1, gy.stride(0), x, 1, x.stride(0), gW, N, K, M)
-        if gb is not None:
-            ops.colsum(gy, gb, M, N)
+        with self._leaf():  # += into the flat gradient (zeroed by zero_grad): no per-launch memsets
+            ops.gemm_f32_strided(gy, 1, gy.stride(0), x, 1, x.stride(0), gW, N, K, M, accumulate=True)
+            if gb is not None:
+                ops.colsum(gy, gb, M, N, accumulate=True)
         if gx is not None:
             ops.gemm_f32_strided(gy, gy.stride(0), 1, W, 1, W.stride(0), gx, M, K, N)
         return gx
 
-    def lin_bwd_bf16(self, tag, x_b, W, gy, gW, gb, gx=None, xT=None):
+    def lin_bwd_bf16(self, tag, x_b, W, gy, gW, gb, gx=None, xT=None, pin=None):
         """y = bf16(x) bf16(W)^T + b on MFMA.  x_b bf16 [M,K]; W fp32 param [N,K]; gy bf16 or fp32 [M,N].
         gW fp32 [N,K] = gy^T x, gb = colsum(gy), optional gx [M,K] (dtype of the given buffer) = gy W."""
         M, K = x_b.shape
@@ -83,14 +139,15 @@ class Backward:
             ops.cast_bf16(gy, out=gy_b)
         else:
             gy_b = gy
-        gyT = self._buf(tag + ".gyT", (N, Mp), torch.bfloat16)
-        ops.transpose16(gy_b, gyT, M, N, Mp)
-        if xT is None:
-            xT = self._buf(tag + ".xT", (K, Mp), torch.bfloat16)
-            ops.transpose16(x_b, xT, M, K, Mp)
-        ops.gemm_bf16(gyT, xT, out=gW)  # [N, K] fp32
-        if gb is not None:
-            ops.colsum(gy, gb, M, N)
+        with self._leaf(pin):
+            gyT = self._buf(tag + ".gyT", (N, Mp), torch.bfloat16)
+            ops.transpose16(gy_b, gyT, M, N, Mp)
+            if xT is None:
+                xT = self._buf(tag + ".xT", (K, Mp), torch.bfloat16)
+                ops.transpose16(x_b, xT, M, K, Mp)
+            ops.gemm_bf16(gyT, xT, out=gW)  # [N, K] fp32
+            if gb is not None:
+                ops.colsum(gy, gb, M, N, accumulate=True)
         if gx is not None:
             WT = self._buf(tag + ".WT", (K, N), torch.bfloat16)
             ops.transpose_f32_bf16(W.detach(), WT, N, K, N)
@@ -98,7 +155,7 @@ class Backward:
         return xT
 
     # ---- TransformerLTSF ----------------------------------------------------------------------
-    def ltsf(self, g_out, x_in):
+    def ltsf(self, g_out, x_in, on_poly_grad=None):
         """g_out [B,2,To] = dL/d decoded; returns g_poly_emb [B, D_poly]."""
         m, G, ws = self.m.ltsf, self.book.g, self.m.ltsf._ws
         dec, sab = m.decoder, m.attn_block
@@ -150,9 +207,9 @@ class Backward:
         self.lin_bwd_bf16("q", proj, ca.in_proj_weight[:H], g_q, gWin[:H], gbin[:H], gx=g_proj)
         fh_b = self._fh_b
         fhT = self.lin_bwd_bf16("k", fh_b[: B * L], ca.in_proj_weight[H:2 * H], g_k[: B * L], gWin[H:2 * H],
-                                gbin[H:2 * H])
+                                gbin[H:2 * H], pin=0)
         self.lin_bwd_bf16("v", fh_b[: B * L], ca.in_proj_weight[2 * H:], g_v[: B * L], gWin[2 * H:], gbin[2 * H:],
-                          xT=fhT)
+                          xT=fhT, pin=0)
         # proj = dec_t W_dp^T + b_dp
         g_dt2 = self._buf("g_dt2", (M, C))
         self.lin_bwd_bf16("dp", dec_tb, dec.dec_proj.weight, g_proj, G[pl + "decoder.dec_proj.weight"],
@@ -179,6 +236,8 @@ class Backward:
         g_poly = self._buf("g_poly", tuple(poly_emb.shape))
         self.lin_bwd_f32(poly_emb, dec.lane_fc.weight, g_d0, G[pl + "decoder.lane_fc.weight"],
                          G[pl + "decoder.lane_fc.bias"], gx=g_poly)
+        if on_poly_grad is not None:
+            on_poly_grad(g_poly)  # the lane-polygon encoder's backward can start here, beside the rest of this one
         e = sab._ws.get("sab.out", (B * T, C), torch.float32, dev)
         P = m._prepared()
         g_dw = self._buf("g_dw", (C, To, T))
@@ -196,7 +255,8 @@ class Backward:
         ops.nlinear_bwd(xp, P.enc_w, g_tok, (T * C, 1, C), g_ew, g_eb, g_xp, B, C, T, T)
         self._scatter_channels(g_ew, g_eb, pl + "nlinear_encoder.encoder_linears.", C)
         gpos = G[pl + "pos_encoding"]  # (1, C, seq_len): same reduction as the encoder bias
-        gpos.view(C, -1)[:, :T].copy_(g_eb)
+        with self._leaf():
+            gpos.view(C, -1)[:, :T].copy_(g_eb)
         ops.conv1x1_bwd(g_xp, x_in, G[pl + "token_proj.weight"].view(C, F), G[pl + "token_proj.bias"], B, C, T, F)
         return g_poly
 
@@ -209,11 +269,12 @@ class Backward:
         S, T = shape
         stride = self.book.offsets[prefix + "1.weight"][0] - o0 if C > 1 else 0
         flat = self.book.grads
-        wv = torch.as_strided(flat, (C, S * T), (stride, 1), o0)
-        wv.copy_(gW.view(C, S * T))
-        ob = self.book.offsets[prefix + "0.bias"][0]
-        bv = torch.as_strided(flat, (C, S), (stride, 1), ob)
-        bv.copy_(gb.view(C, S))
+        with self._leaf():
+            wv = torch.as_strided(flat, (C, S * T), (stride, 1), o0)
+            wv.copy_(gW.view(C, S * T))
+            ob = self.book.offsets[prefix + "0.bias"][0]
+            bv = torch.as_strided(flat, (C, S), (stride, 1), ob)
+            bv.copy_(gb.view(C, S))
 
     def _sab(self, g_e, B, T, C):
         m, G = self.m.ltsf.attn_block, self.book.g
@@ -277,7 +338,15 @@ class Backward:
         g_q = self._buf("xa.g_q", (M, H), torch.bfloat16)
         ops.gemm_batched(dS, kT, g_q, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
                          sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
-        # dK_bh = dS_bh^T Q_bh ; dV_bh = P_bh^T dO_bh : contraction over the To queries (padded to Tp)
+        # dK_bh = dS_bh^T Q_bh ; dV_bh = P_bh^T dO_bh : contraction over the To queries (padded to Tp).
+        # Only the k / v in-projection WEIGHT gradients consume these (the LLM's hidden states are a constant), so
+        # the whole branch is leaf work.
+        with self._leaf(pin=0):
+            g_k, g_v = self._xattn_kv_grads(g_att, dS, q, B, To, H, nh, dh, L, Lp, Tp)
+        return g_q, g_k, g_v, L
+
+    def _xattn_kv_grads(self, g_att, dS, q, B, To, H, nh, dh, L, Lp, Tp):
+        ws, dev = self.m.ltsf._ws, g_att.device
         dST = self._buf("xa.dST", (B * nh * Lp, Tp), torch.bfloat16)
         ops.transpose16(dS, dST, To, Lp, Tp, ld_in=Lp, ld_out=Tp, batch=B * nh, s_in=To * Lp, s_out=Lp * Tp)
         Pb = self._buf("xa.Pb", (B * nh * To, Lp), torch.bfloat16)
@@ -294,7 +363,7 @@ class Backward:
                          sA=(nh * Lp * Tp, Lp * Tp), sW=(Tp, dh * B * Tp), sC=(L * H, dh))
         ops.gemm_batched(PT, gaT, g_v, M=L, N=dh, K=Tp, lda=Tp, ldw=B * Tp, ldc=H, batch=B * nh, inner=nh,
                          sA=(nh * Lp * Tp, Lp * Tp), sW=(Tp, dh * B * Tp), sC=(L * H, dh))
-        return g_q, g_k, g_v, L
+        return g_k, g_v
 
     # ---- LanePolygonEncoder -------------------------------------------------------------------
     def polygon(self, g_emb):
@@ -309,27 +378,27 @@ class Backward:
         for i in reversed(range(len(sv.layers))):
             s, lyr = sv.layers[i], enc.encoder.layers[i]
             pre = f"{pp}encoder.layers.{i}."
-            g_y2 = self._buf("po.g_y2", (M, D))
+            g_y2 = self._buf(f"po.g_y2{i}", (M, D))
             ops.layernorm_bwd(s["y2"], lyr.norm2.weight, g_x, g_y2, G[pre + "norm2.weight"], G[pre + "norm2.bias"])
             ff = lyr.linear1.weight.shape[0]
-            g_f = self._buf("po.g_f", (M, ff))
+            g_f = self._buf(f"po.g_f{i}", (M, ff))
             self.lin_bwd_f32(s["f"], lyr.linear2.weight, g_y2, G[pre + "linear2.weight"], G[pre + "linear2.bias"], gx=g_f)
             ops.relu_bwd(g_f, s["f"])
-            g_x1 = self._buf("po.g_x1", (M, D))
+            g_x1 = self._buf(f"po.g_x1{i}", (M, D))
             self.lin_bwd_f32(s["x1"], lyr.linear1.weight, g_f, G[pre + "linear1.weight"], G[pre + "linear1.bias"], gx=g_x1)
             ops.add_inplace(g_x1, g_y2)
-            g_y = self._buf("po.g_y", (M, D))
+            g_y = self._buf(f"po.g_y{i}", (M, D))
             ops.layernorm_bwd(s["y"], lyr.norm1.weight, g_x1, g_y, G[pre + "norm1.weight"], G[pre + "norm1.bias"])
-            g_att = self._buf("po.g_att", (M, D))
+            g_att = self._buf(f"po.g_att{i}", (M, D))
             sa = lyr.self_attn
             self.lin_bwd_f32(s["att"], sa.out_proj.weight, g_y, G[pre + "self_attn.out_proj.weight"],
                              G[pre + "self_attn.out_proj.bias"], gx=g_att)
             qkv = s["qkv"]
-            g_qkv = self._buf("po.g_qkv", (M, 3 * D))
+            g_qkv = self._buf(f"po.g_qkv{i}", (M, 3 * D))
             ops.mha_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], g_att, g_qkv[:, :D], g_qkv[:, D:2 * D],
                         g_qkv[:, 2 * D:], B, P, P, nh, dh, 1.0 / math.sqrt(dh), key_len=sv.lens, ldq=3 * D, ldk=3 * D,
                         ldv=3 * D, ldo=D, ldg=3 * D)
-            g_xin = self._buf(f"po.g_xin{i & 1}", (M, D))
+            g_xin = self._buf(f"po.g_xin{i}", (M, D))
             self.lin_bwd_f32(s["x"], sa.in_proj_weight, g_qkv, G[pre + "self_attn.in_proj_weight"],
                              G[pre + "self_attn.in_proj_bias"], gx=g_xin)
             ops.add_inplace(g_xin, g_y)
@@ -344,9 +413,29 @@ class Backward:
         `after_ltsf` (callable) is invoked once the LTSF gradients are complete (bucket hand-off)."""
         B, F, To = decoded.shape
         self._poly_emb, self._fh_b, self._L = poly_emb, fh_b, L
+        self._ensure_streams()
         g_out = self._buf("g_out", (B, F, To))
         ops.mse_grad(decoded, y, norm_stat, g_out, B, To)
-        g_poly = self.ltsf(g_out, x_in)
+        if not self._multi():
+            g_poly = self.ltsf(g_out, x_in)
+            if after_ltsf is not None:
+                after_ltsf()
+            self.polygon(g_poly)
+            return
+        main = torch.cuda.current_stream()
+
+        def start_polygon(g_poly):
+            with _Fork(self._poly_stream):
+                self.polygon(g_poly)
+
+        self.ltsf(g_out, x_in, on_poly_grad=start_polygon)
+        # LTSF gradients are complete once the leaf stream has drained what was queued up to here; the bucket
+        # hand-off (all-reduce launch) is issued from the leaf stream so that the chain does not wait for it
         if after_ltsf is not None:
-            after_ltsf()
-        self.polygon(g_poly)
+            for ls in self._leaf_streams[1:]:
+                self._leaf_streams[0].wait_stream(ls)
+            with _Fork(self._leaf_streams[0]):
+                after_ltsf()
+        main.wait_stream(self._poly_stream)
+        for ls in self._leaf_streams:
+            main.wait_stream(ls)

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
           atomicAdd(&C[(long)m * ldc + n], v);
           continue;
         }
+        if (flags & TCAVT_EPI_ACCUM) v += C[(long)m * ldc + n];
         if (flags & TCAVT_EPI_BIAS) v += bias[n];
         if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
         if (drop.p > 0.f) v *= dropout_one(drop, (unsigned long long)m * (unsigned long long)N + (unsigned long long)n);
@@ -286,7 +287,7 @@ static int launch_gemm_f32(int max_splits, const float* A, long rsA, long csA, c
   if (splits > 1) {
     k_chunk = (((K + splits - 1) / splits) + 15) / 16 * 16;
     splits = (K + k_chunk - 1) / k_chunk;
-    hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
+    hipError_t e = (flags & TCAVT_EPI_ACCUM) ? hipSuccess : hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), stream);
     if (e != hipSuccess) {
       set_error("%s: hipMemsetAsync failed: %s", what, hipGetErrorString(e));
       return TCAVT_ERR_HIP;
@@ -322,7 +323,8 @@ extern "C" int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, 
   TCAVT_CHECK_ARG(A && W && C && M > 0 && N > 0 && K > 0, "gemm_f32_strided: null pointer or bad shape");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_BIAS) || bias, "gemm_f32_strided: BIAS without bias");
   TCAVT_CHECK_ARG(!(flags & TCAVT_EPI_RESIDUAL) || residual, "gemm_f32_strided: RESIDUAL without residual");
-  TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL)), "gemm_f32_strided: unsupported flag");
+  TCAVT_CHECK_ARG(!(flags & ~(TCAVT_EPI_BIAS | TCAVT_EPI_RELU | TCAVT_EPI_RESIDUAL | TCAVT_EPI_ACCUM)), "gemm_f32_strided: unsupported flag");
+  TCAVT_CHECK_ARG(!((flags & TCAVT_EPI_ACCUM) && (flags & TCAVT_EPI_RELU)), "gemm_f32_strided: ACCUM excludes RELU");
   return launch_gemm_f32(8, A, (long)rsA, (long)csA, W, (long)rsW, (long)csW, bias, residual, (long)ldr, C, (long)ldc, M,
                          N, K, flags, make_dropout(0.f, 0, 0), static_cast<hipStream_t>(stream), "gemm_f32_strided");
 }

@@ -342,14 +342,14 @@ def traj_metrics(pred, gt, norm_stat, sums, argmin, per_sample, B, K, To):
 # ----------------------------------------------------------------------------------------------
 # training-step kernels (include/tcavt.h, second half)
 # ----------------------------------------------------------------------------------------------
-def gemm_f32_strided(a, rsA, csA, w, rsW, csW, out, M, N, K, bias=None, relu=False, residual=None):
+def gemm_f32_strided(a, rsA, csA, w, rsW, csW, out, M, N, K, bias=None, relu=False, residual=None, accumulate=False):
     for t, rs, cs, rows, nm in ((a, rsA, csA, M, "a"), (w, rsW, csW, N, "w")):
         if _avail(t) < (rows - 1) * rs + (K - 1) * cs + 1:
             raise capi.TcavtError(f"gemm_f32_strided.{nm}: buffer too small")
     if _avail(out) < (M - 1) * out.stride(0) + N:
         raise capi.TcavtError("gemm_f32_strided.out: buffer too small")
     flags = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0) | (
-        EPI_RESIDUAL if residual is not None else 0)
+        EPI_RESIDUAL if residual is not None else 0) | (capi.EPI_ACCUM if accumulate else 0)
     check(lib().tcavt_gemm_f32_strided(ptr(a), rsA, csA, ptr(w), rsW, csW, ptr(bias), ptr(residual),
                                        residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), M, N,
                                        K, flags, stream_ptr()), "tcavt_gemm_f32_strided")
