@@ -267,3 +267,37 @@ def test_evaluate_model_k_candidates(gpu):
     assert abs(r1["ADE"] - ref["ade_sum"] / n) < 1e-4 * ref["ade_sum"] / n
     assert abs(r1["FDE"] - ref["fde_sum"] / n) < 1e-4 * ref["fde_sum"] / n
     assert abs(r1["RMSE"] - ref["rmse_sum"] / n) < 1e-4 * ref["rmse_sum"] / n
+
+
+def test_prefetch_is_transparent(gpu):
+    """model.prefetch(next_vision_embs) (frozen Q-Former of the next batch on a side stream) must not change results:
+    a hit, a miss (different tensor) and a modified tensor (version bump) all give the un-prefetched output."""
+    from tcavt_amd import model
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+
+    def fwd(v):
+        with torch.no_grad():
+            return m(g["traj_emb"], v, None, g["lane_polygon"], g["lane_polygon_len"], input_ids=g["input_ids"],
+                     attention_mask=g["attention_mask"]).clone()
+
+    v = g["vision_emb"]
+    ref = fwd(v)
+    torch.cuda.synchronize()
+    m.prefetch(v)
+    assert torch.equal(fwd(v), ref)            # hit
+    v2 = (v * 0.5).contiguous()
+    ref2 = fwd(v2)
+    m.prefetch(v)
+    assert torch.equal(fwd(v2), ref2)          # miss: another tensor was prefetched
+    m.prefetch(v2)
+    v2.mul_(2.0)                               # modified after the prefetch -> must not be served stale
+    assert torch.equal(fwd(v2), ref)
+    for _ in range(3):                         # steady state: prefetch issued while the previous pass is still in flight
+        out = fwd(v)
+        m.prefetch(v)
+    assert torch.equal(out, ref) and torch.equal(fwd(v), ref)

@@ -1,16 +1,25 @@
-"""Run only the gate|up GEMM (2-buffer 256x256 kernel) a few times: target for rocprofv3 --pmc passes."""
+"""Run only the gate|up GEMM a few times: target for rocprofv3 --pmc passes.
+   argv[1] = tile code for tcavt_gemm_bf16 (0 = auto), or "lib" for the vendor library (torch F.linear -> hipBLASLt,
+   plain GEMM, measurement only)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tcavt_amd import capi, ops
 capi.init(0)
 dev = torch.device("cuda:0")
-M, N, K = 8192, 16384, 2048
-tile = int(sys.argv[1]) if len(sys.argv) > 1 else 255
+which = sys.argv[1] if len(sys.argv) > 1 else "0"
+shape = sys.argv[2] if len(sys.argv) > 2 else "gateup"
+M, N, K = {"gateup": (8192, 16384, 2048), "down": (8192, 2048, 8192), "o": (8192, 2048, 2048)}[shape]
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)
-w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
-out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
-for _ in range(6):
-    ops.gemm_bf16(a, w, out=out, tile=tile, silu_mul=True)
+ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(4)]
+out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev) if shape == "gateup" else torch.randn(M, N, device=dev)
+for i in range(8):
+    if which == "lib":
+        torch.nn.functional.linear(a, ws[i % 4])
+    else:
+        if shape == "gateup":
+            ops.gemm_bf16(a, ws[i % 4], out=out, tile=int(which), silu_mul=True)
+        else:
+            ops.gemm_bf16(a, ws[i % 4], out=out, residual=out, tile=int(which))
 torch.cuda.synchronize()
 print("done")

@@ -683,7 +683,9 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x
 }
 
 // DBG (timing experiments only, results are wrong): 1 = no DMA in the loop, 2 = no barrier, 4 = no fragment loads
-template <int EPI, int B2R, int DBG = 0>
+// BUF: stage with buffer_load ... lds (SGPR resource + one constant per-lane VGPR offset + scalar per-piece offset)
+// instead of global_load ... lds (64-bit per-lane address, two VALU ops per piece).
+template <int EPI, int B2R, int DBG = 0, bool BUF = false>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   constexpr int BM = 256, BN = 256, NW = 4;
   constexpr int TM = 8, TN = 8;
@@ -733,17 +735,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   };
   auto tsrc = [&](int t) -> Src {
     t = min(t, nt - 1);  // the last two K-tiles re-fetch the last tile into a free buffer (keeps the loop body uniform)
+    if constexpr (BUF) return Src{nullptr, nullptr, (long)t * 128, 0};  // only the tile's byte offset along K
     if constexpr (HASK2) {
       if (t >= nt1) return Src{srcA2 + (t - nt1) * 64, srcW2 + (t - nt1) * 64, stepA2, stepW2};
     }
     return Src{srcA + t * 64, srcW + t * 64, stepA, stepW};
   };
+  // buffer form: resources based at the tile's first row, byte offsets in 32 bits (launch_w4 checks the range)
+  __amdgpu_buffer_rsrc_t rsA, rsW;
+  int voffA = 0, voffW = 0, stepAb = 0, stepWb = 0;
+  if constexpr (BUF) {
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long)m0 * p.lda), 0, 0x7ffffffe, 0x00020000);
+    rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W + (long)n0 * p.ldw), 0, 0x7ffffffe, 0x00020000);
+    voffA = ((wave * 8 + rl) * (int)p.lda + csw * 8) * 2;
+    voffW = ((wave * 8 + rl) * (int)p.ldw + csw * 8) * 2;
+    stepAb = 64 * (int)p.lda;  // 32 rows, bytes
+    stepWb = 64 * (int)p.ldw;
+  }
   auto piece = [&](int buf, const Src& s, int r) {
     char* dst = smem + buf * TILE_BYTES + (r * NW + wave) * 1024;
-    if (r < 8)
-      glds16(s.a + r * s.sa, dst);
-    else
-      glds16(s.w + (r - 8) * s.sw, dst);
+    if constexpr (BUF) {
+      auto l = (__attribute__((address_space(3))) void*)dst;
+      if (r < 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, l, 16, voffA, (int)s.sa + r * stepAb, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, l, 16, voffW, (int)s.sa + (r - 8) * stepWb, 0, 0);
+    } else {
+      if (r < 8)
+        glds16(s.a + r * s.sa, dst);
+      else
+        glds16(s.w + (r - 8) * s.sw, dst);
+    }
   };
 
   const int fsw = (lane >> 1) & 7;
@@ -825,11 +847,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           second2 = HASK2 && tt >= nt1;
           koff2 = (second2 ? tt - nt1 : tt) * 64;
         }
-        if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
-        if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
-        if (idx == 9) {
-          sn2.sa = second2 ? stepA2 : stepA;
-          sn2.sw = second2 ? stepW2 : stepW;
+        if constexpr (BUF) {
+          if (idx == 3) sn2 = Src{nullptr, nullptr, (long)koff2 * 2, 0};
+        } else {
+          if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
+          if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
+          if (idx == 9) {
+            sn2.sa = second2 ? stepA2 : stepA;
+            sn2.sw = second2 ? stepW2 : stepW;
+          }
         }
       }
     if (more && bar && (DBG & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA wait (timing only)
@@ -877,14 +903,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * 128, n0 + wn * 128, lane);
 }
 
-template <int EPI, int B2R, int DBG = 0>
+template <int EPI, int B2R, int DBG = 0, bool BUF = false>
 static int launch_w4(const GemmP& p0, hipStream_t stream) {
+  if (BUF && ((long)256 * p0.lda * 2 + (long)p0.K * 2 >= (1L << 31) || (long)256 * p0.ldw * 2 + (long)p0.K * 2 >= (1L << 31))) {
+    set_error("gemm_bf16(w4, buffer loads): a 256-row operand panel must span < 2 GiB");
+    return TCAVT_ERR_ARG;
+  }
   GemmP p = p0;
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / 256;
   p.xcd_gx = choose_xcd_partition(p);
   constexpr int lds = 2 * 512 * 128;
-  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG>;
+  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -940,10 +970,13 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 253: q.prio = 1; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 252: q.prio = 0; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
-    case 257: case 258: case 259: case 268: case 269:
+    case 257: case 258: case 259: case 268: case 269: case 270:
       if constexpr (!F16) {
         if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
             (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16)) {
+          if (tile == 270) {
+            if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 0, true>(q, stream);
+          }
           if (tile == 268) return launch_w4<EPI, 2, 16>(q, stream);
           if (tile == 269) return launch_w4<EPI, 2, 32>(q, stream);
           if (tile == 257) return launch_w4<EPI, 2>(q, stream);
@@ -1039,7 +1072,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 269 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 270 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;

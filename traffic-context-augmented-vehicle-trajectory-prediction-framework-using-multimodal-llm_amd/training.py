@@ -96,6 +96,10 @@ class Trainer:
             # bf16 shadows / stacked copies of the trainable weights are stale now
             m.ltsf._invalidate()
 
+    def prefetch(self, vision_embs, ready=None):
+        """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
+        self.model.prefetch(vision_embs, ready=ready)
+
     def step(self, *args, **kw):
         out = self.forward_backward(*args, **kw)
         self.optimizer_step()
