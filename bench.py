@@ -306,7 +306,7 @@ def main():
             },
             "achieved_model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 1),
             "roofline": {
-                "kernel": "gemm_bf16_kernel<256,256,2x4 waves,SILU,PIPE1> (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
+                "kernel": "gemm_bf16_w4_kernel<SILU> (256x256 tile, 4 waves x 128x128) (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
                 "bound": "mfma", "achieved": round(gu_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(gu_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "algorithmic_bytes": int(2 * (M * ll.hidden + 2 * ll.inter * ll.hidden + M * ll.inter)),
