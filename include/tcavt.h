@@ -312,10 +312,12 @@ int tcavt_add_inplace(float* a, const float* b, int64_t n, tcavt_stream_t stream
 /* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
 int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
                         float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);
-/* backward of tcavt_mha (fp32 operands): gq, gk, gv share leading dimension ldg */
+/* backward of tcavt_mha (fp32 operands): gq, gk, gv share leading dimension ldg; dropout_p > 0 regenerates the
+   attention-weight mask of the forward call with the same (seed, site) */
 int tcavt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                   const float* go, int64_t ldo, float* gq, float* gk, float* gv, int64_t ldg,
                   const int32_t* key_len, int B, int Lq, int Lk, int nh, int dh, float scale,
+                  float dropout_p, uint64_t dropout_seed, uint32_t dropout_site,
                   tcavt_stream_t stream);
 /* backward of tcavt_softmax_rows (+ the 1/sqrt(dh) score scale): dS bf16, zero padded to n_out */
 int tcavt_softmax_bwd_rows(const void* P_f16, int64_t ldp, const float* dP, int64_t ldd, void* dS_bf16,

@@ -45,6 +45,31 @@ def as_torch(weights):
 # --------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------
+class DropTape:
+    """Train-mode dropout for the oracle with the HIP path's masks: every call is the next dropout site (numbered in
+    call order from `first_site`, as tcavt_amd.model.DropoutCtx numbers them) of one 64-bit seed; the keep mask of a
+    site is oracle/philox.py's restatement of csrc/philox.hpp over the tensor's row-major element index.  `cols`
+    (padded row length) reproduces sites whose kernel indexes a padded [rows, cols] matrix (cross-attention)."""
+
+    def __init__(self, seed, p, first_site=1):
+        self.seed, self.p, self.site = int(seed), float(p), int(first_site) - 1
+
+    def __call__(self, x, cols=None):
+        from . import philox
+        self.site += 1
+        if cols is None:
+            keep = philox.keep_mask(x.numel(), self.p, self.seed, self.site).reshape(tuple(x.shape))
+        else:
+            rows = x.numel() // x.shape[-1]
+            keep = philox.keep_mask(rows * cols, self.p, self.seed, self.site).reshape(rows, cols)[:, : x.shape[-1]]
+            keep = keep.reshape(tuple(x.shape))
+        return x * torch.from_numpy(keep.astype("float32")) / (1.0 - self.p)
+
+
+def _ident(x, **kw):
+    return x
+
+
 def linear(x, W, prefix, r, bias=True):
     """nn.Linear with both operands rounded per contract (r = identity in fp32 mode)."""
     y = r(x) @ r(W[prefix + ".weight"]).T
@@ -53,7 +78,7 @@ def linear(x, W, prefix, r, bias=True):
     return y
 
 
-def mha_core(q, k, v, nhead, key_len=None):
+def mha_core(q, k, v, nhead, key_len=None, drop=_ident, drop_cols=None):
     """softmax(q k^T / sqrt(dh)) v per head; q [B,Lq,E], k/v [B,Lk,E]; key_len masks keys >= len
     (nn.MultiheadAttention key_padding_mask semantics, train.py:366-371)."""
     B, Lq, E = q.shape
@@ -67,17 +92,18 @@ def mha_core(q, k, v, nhead, key_len=None):
         j = torch.arange(Lk)
         s = s.masked_fill((j[None, :] >= key_len[:, None])[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
+    p = drop(p, cols=drop_cols) if drop_cols is not None else drop(p)  # attention-weight dropout (train mode)
     return (p @ vh).transpose(1, 2).reshape(B, Lq, E)
 
 
-def mha_module(xq, xkv, W, prefix, nhead, r, key_len=None, r_attn=None):
+def mha_module(xq, xkv, W, prefix, nhead, r, key_len=None, r_attn=None, drop=_ident):
     """nn.MultiheadAttention forward (eval): packed in_proj, heads, out_proj."""
     E = xq.shape[-1]
     Win, bin_ = W[prefix + ".in_proj_weight"], W[prefix + ".in_proj_bias"]
     q = r(xq) @ r(Win[:E]).T + bin_[:E]
     k = r(xkv) @ r(Win[E:2 * E]).T + bin_[E:2 * E]
     v = r(xkv) @ r(Win[2 * E:]).T + bin_[2 * E:]
-    a = mha_core(q, k, v, nhead, key_len)
+    a = mha_core(q, k, v, nhead, key_len, drop=drop)
     a = (r_attn or r)(a)
     return a @ r(W[prefix + ".out_proj.weight"]).T + W[prefix + ".out_proj.bias"]
 
@@ -86,11 +112,12 @@ def layer_norm(x, W, prefix, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), W[prefix + ".weight"], W[prefix + ".bias"], eps)
 
 
-def encoder_layer(x, W, prefix, nhead, r, key_len=None):
-    """nn.TransformerEncoderLayer defaults: post-LN, ReLU, eval (train.py:358,402)."""
-    x = layer_norm(x + mha_module(x, x, W, prefix + ".self_attn", nhead, r, key_len), W, prefix + ".norm1")
-    f = r(torch.relu(linear(x, W, prefix + ".linear1", r)))
-    x = layer_norm(x + linear(f, W, prefix + ".linear2", r), W, prefix + ".norm2")
+def encoder_layer(x, W, prefix, nhead, r, key_len=None, drop=_ident):
+    """nn.TransformerEncoderLayer defaults: post-LN, ReLU (train.py:358,402); `drop` = identity in eval, a DropTape
+    in train mode (sites in the module's call order: attention weights, dropout1, dropout, dropout2)."""
+    x = layer_norm(x + drop(mha_module(x, x, W, prefix + ".self_attn", nhead, r, key_len, drop=drop)), W, prefix + ".norm1")
+    f = r(drop(torch.relu(linear(x, W, prefix + ".linear1", r))))
+    x = layer_norm(x + drop(linear(f, W, prefix + ".linear2", r)), W, prefix + ".norm2")
     return x
 
 
@@ -106,7 +133,7 @@ def decoder_layer(x, mem, W, prefix, nhead, r):
 # --------------------------------------------------------------------------------------
 # A2: LanePolygonEncoder.forward  (train.py:362-383) -- fp32 in both contracts
 # --------------------------------------------------------------------------------------
-def lane_polygon_encoder(W, cfg, polygon, lens):
+def lane_polygon_encoder(W, cfg, polygon, lens, drop=_ident):
     ident = _rounder("fp32")
     P = polygon.shape[1]
     x = polygon @ W["lane_polygon_encoder.input_proj.weight"].T + W["lane_polygon_encoder.input_proj.bias"]
@@ -118,7 +145,7 @@ def lane_polygon_encoder(W, cfg, polygon, lens):
     key_len_safe = torch.where(key_len > 0, key_len, torch.full_like(key_len, P))
     for i in range(cfg.lane_polygon_layers):
         x = encoder_layer(x, W, f"lane_polygon_encoder.encoder.layers.{i}", cfg.lane_polygon_nhead, ident,
-                          key_len_safe)
+                          key_len_safe, drop=drop)
     j = torch.arange(P)
     valid = (j[None, :] < key_len[:, None]).float()
     s = (x * valid[..., None]).sum(1)
@@ -261,7 +288,7 @@ def _stack(W, fmt, n, suffix):
     return torch.stack([W[fmt.format(c) + suffix] for c in range(n)], dim=0)
 
 
-def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r):
+def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r, drop=_ident, xattn_pad=64):
     ident = _rounder("fp32")
     B = x.shape[0]
     C, T, To = cfg.d_model, cfg.seq_len, cfg.out_len
@@ -276,10 +303,10 @@ def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r):
     # SelfAttentionBlock (train.py:674-686): residuals start from the NORMED tensors
     tok = enc.permute(0, 2, 1)  # [B,T,C] (batch-first; attention is order-agnostic)
     xn = layer_norm(tok, W, "ltsf.attn_block.norm1")
-    res1 = xn + mha_module(xn, xn, W, "ltsf.attn_block.mha", cfg.ltsf_nhead, ident)
+    res1 = xn + drop(mha_module(xn, xn, W, "ltsf.attn_block.mha", cfg.ltsf_nhead, ident, drop=drop))
     rn = layer_norm(res1, W, "ltsf.attn_block.norm2")
-    ffn = linear(torch.relu(linear(rn, W, "ltsf.attn_block.ffn.0", ident)), W, "ltsf.attn_block.ffn.3", ident)
-    e = (rn + ffn).permute(0, 2, 1)  # [B,C,T]
+    ffn = linear(drop(torch.relu(linear(rn, W, "ltsf.attn_block.ffn.0", ident))), W, "ltsf.attn_block.ffn.3", ident)
+    e = (rn + drop(ffn)).permute(0, 2, 1)  # [B,C,T]
     # LTSF_NLinearDecoder (train.py:767-806)
     last = e[:, :, -1:]
     Wd = _stack(W, "ltsf.decoder.decoder_linears.{}", C, ".weight")
@@ -287,7 +314,7 @@ def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r):
     dec = torch.einsum("cst,bct->bcs", Wd, e - last) + bd[None] + last
     dec = dec + linear(poly_emb, W, "ltsf.decoder.lane_fc", ident).view(B, C, To)
     if cfg.use_post_mlp:
-        hid = torch.relu(linear(dec.reshape(B, -1), W, "ltsf.decoder.post_mlp.0", ident))
+        hid = drop(torch.relu(linear(dec.reshape(B, -1), W, "ltsf.decoder.post_mlp.0", ident)))
         dec = linear(hid, W, "ltsf.decoder.post_mlp.3", ident).view(B, C, To)
     dec_t = dec.permute(0, 2, 1)  # [B,To,C]
     proj = r(linear(dec_t, W, "ltsf.decoder.dec_proj", r))
@@ -298,7 +325,9 @@ def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r):
     q = r(proj @ r(Win[:H]).T + bin_[:H])
     k = r(fh @ r(Win[H:2 * H]).T + bin_[H:2 * H])
     v = r(fh @ r(Win[2 * H:]).T + bin_[2 * H:])
-    a = r(mha_core(q, k, v, cfg.cross_nhead))
+    # (the HIP kernel draws this site's mask over score rows padded to a multiple of `xattn_pad` keys)
+    Lk = fh.shape[1]
+    a = r(mha_core(q, k, v, cfg.cross_nhead, drop=drop, drop_cols=(Lk + xattn_pad - 1) // xattn_pad * xattn_pad))
     cross = r(a @ r(W["ltsf.decoder.cross_attn.out_proj.weight"]).T + W["ltsf.decoder.cross_attn.out_proj.bias"])
     fused = dec_t + linear(cross, W, "ltsf.decoder.dec_unproj", r)
     f = layer_norm(fused, W, "ltsf.decoder.fusion_layer.0")

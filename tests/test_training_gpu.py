@@ -193,3 +193,147 @@ def test_training_step_reduces_loss(gpu):
     assert losses[-1] < losses[0]
     frozen = m.mllm.q_proj.weight.detach().cpu()
     assert torch.equal(frozen, torch.from_numpy(weights["mllm.q_proj.weight"]))  # MLLM untouched
+
+
+# ---------------------------------------------------------------------------------------------------
+# train-mode dropout: the backward regenerates the forward's Philox masks (seed, site) -> gradients of the
+# SAME stochastic graph; the oracle draws identical masks (oracle.forward.DropTape / oracle.philox)
+# ---------------------------------------------------------------------------------------------------
+def test_mha_bwd_with_attention_dropout(gpu):
+    from oracle import philox
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    B, nh, Lq, Lk, dh, p, seed, site = 3, 2, 10, 12, 8, 0.25, 77, 5
+    g = torch.Generator().manual_seed(3)
+    E = nh * dh
+    q, k, v = (torch.randn(B, L_, E, generator=g).requires_grad_(True) for L_ in (Lq, Lk, Lk))
+    go = torch.randn(B, Lq, E, generator=g)
+    keep = torch.from_numpy(philox.keep_mask(B * nh * Lq * Lk, p, seed, site).reshape(B, nh, Lq, Lk).astype("float32"))
+    qh, kh, vh = (t.view(B, -1, nh, dh).transpose(1, 2) for t in (q, k, v))
+    P = torch.softmax(qh @ kh.transpose(-1, -2) / dh ** 0.5, -1) * keep / (1 - p)
+    ((P @ vh).transpose(1, 2).reshape(B, Lq, E) * go).sum().backward()
+    d = lambda t: t.detach().to(dev).contiguous()
+    gq, gk, gv = (torch.empty_like(d(t)) for t in (q, k, v))
+    ops.mha_bwd(d(q).view(-1, E), d(k).view(-1, E), d(v).view(-1, E), d(go).view(-1, E), gq.view(-1, E), gk.view(-1, E),
+                gv.view(-1, E), B, Lq, Lk, nh, dh, 1.0 / dh ** 0.5, dropout=(p, seed, site))
+    for a, b, nm in ((gq, q.grad, "q"), (gk, k.grad, "k"), (gv, v.grad, "v")):
+        assert rel_err(a.cpu(), b) < 2e-5, nm
+
+
+def test_polygon_encoder_backward_with_dropout(gpu):
+    from oracle import forward as O
+    from tcavt_amd import model, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    W = {k: torch.from_numpy(v).clone() for k, v in weights.items()}
+    names = [k for k in W if k.startswith("lane_polygon_encoder.")]
+    for k in names:
+        W[k].requires_grad_(True)
+    seed = 1234
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    enc = m.lane_polygon_encoder
+    emb = O.lane_polygon_encoder(W, cfg, t["lane_polygon"], t["lane_polygon_len"], drop=O.DropTape(seed, enc.dropout_p))
+    emb_eval = O.lane_polygon_encoder(W, cfg, t["lane_polygon"], t["lane_polygon_len"])
+    assert rel_err(emb.detach(), emb_eval.detach()) > 1e-2  # the masks really bite
+    g_emb = torch.randn(emb.shape, generator=torch.Generator().manual_seed(9))
+    (emb * g_emb).sum().backward()
+    tr = training.Trainer(m)
+    with torch.no_grad():
+        enc.dctx = model.DropoutCtx(seed)
+        out = enc(t["lane_polygon"].to(dev), t["lane_polygon_len"].to(dev))
+        enc.dctx = None
+        tr.book.grads.zero_()
+        tr.bw.polygon(g_emb.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), emb.detach()) < 1e-4  # same stochastic forward
+    for k in names:
+        e = rel_err(tr.book.g[k].cpu(), W[k].grad)
+        assert e < 3e-4, (k, e)
+
+
+def test_ltsf_backward_with_dropout(gpu):
+    from oracle import forward as O
+    from tcavt_amd import model, ops, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    B = t["traj_emb"].shape[0]
+    gen = torch.Generator().manual_seed(10)
+    L, H = 48, cfg.llama.hidden
+    fh = torch.randn(B, L, H, generator=gen)
+    poly = torch.randn(B, cfg.lane_polygon_d_model, generator=gen)
+    W = {k: torch.from_numpy(v).clone() for k, v in weights.items()}
+    names = [k for k in W if k.startswith("ltsf.")]
+    for k in names:
+        W[k].requires_grad_(True)
+    poly_r = poly.clone().requires_grad_(True)
+    seed = 4321
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    out = O.ltsf_forward(W, cfg, t["traj_emb"], poly_r, fh, O._rounder("bf16"),
+                         drop=O.DropTape(seed, m.ltsf.dropout_p)) + t["traj_emb"][:, :, -1:]
+    dp, dg = O.denorm(out, t["norm_stat"]), O.denorm(t["target_traj"], t["norm_stat"])
+    loss = torch.nn.functional.mse_loss(dp[:, 0], dg[:, 0]) + torch.nn.functional.mse_loss(dp[:, 1], dg[:, 1])
+    loss.backward()
+    tr = training.Trainer(m)
+    with torch.no_grad():
+        x = t["traj_emb"].to(dev)
+        fh_b = torch.zeros(B * L + 64, H, dtype=torch.bfloat16, device=dev)
+        ops.cast_bf16(fh.to(dev).view(B * L, H), out=fh_b)
+        m.ltsf.dctx = m.ltsf.attn_block.dctx = model.DropoutCtx(seed)
+        dec = m.ltsf(x, poly.to(dev), fh.to(dev), final_hidden_bf16=fh_b, _fuse_last_residual=True)
+        m.ltsf.dctx = m.ltsf.attn_block.dctx = None
+        tr.book.grads.zero_()
+        tr.bw._poly_emb, tr.bw._fh_b, tr.bw._L = poly.to(dev), fh_b, L
+        g_out = torch.empty_like(dec)
+        ops.mse_grad(dec, t["target_traj"].to(dev), t["norm_stat"].to(dev), g_out, B, cfg.out_len)
+        g_poly = tr.bw.ltsf(g_out, x)
+    torch.cuda.synchronize()
+    assert rel_err(dec.cpu(), out.detach()) < 5e-3  # same masks in both forwards
+    errs = sorted(((rel_err(tr.book.g[k].cpu(), W[k].grad), k) for k in names), reverse=True)
+    e_poly = rel_err(g_poly.cpu(), poly_r.grad)
+    print(f"[ltsf grads, dropout] max {errs[0][0]:.2e} ({errs[0][1]}), median "
+          f"{float(np.median([e for e, _ in errs])):.2e}, g_poly_emb {e_poly:.2e}")
+    for e, k in errs:
+        assert e < 3e-2, (k, e)
+    assert float(np.median([e for e, _ in errs])) < 5e-3 and e_poly < 2e-2
+
+
+def test_training_step_in_train_mode(gpu):
+    """ddp_model.train() semantics (train.py:1160): dropout active in forward AND backward.  Per seed the step is
+    reproducible (bit-equal loss; gradients up to the float-atomic order of the weight-gradient reductions), a different
+    seed gives a different stochastic graph, and optimisation makes progress."""
+    from tcavt_amd import model, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    args = (g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
+            g["input_ids"], g["attention_mask"], g["labels"])
+
+    def first_step(seed):
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).train()
+        m.dropout_seed = seed
+        tr = training.Trainer(m, lr=1e-4)
+        loss, _ = tr.forward_backward(*args)
+        torch.cuda.synchronize()
+        return loss.item(), tr.book.grads.clone(), tr
+
+    la, ga, _ = first_step(11)
+    lb, gb, tr = first_step(11)
+    lc, gc, _ = first_step(12)
+    assert la == lb and rel_err(ga.cpu(), gb.cpu()) < 1e-5          # same seed: same masks in forward and backward
+    assert abs(lc - la) > 1e-3 * abs(la) and rel_err(gc.cpu(), ga.cpu()) > 1e-2  # another seed: another graph
+    m_eval = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    le, _ = training.Trainer(m_eval).forward_backward(*args)
+    assert abs(le.item() - la) > 1e-3 * abs(la)                     # and train mode is not the eval arithmetic
+    losses = [la]
+    tr.optimizer_step()
+    for _ in range(8):
+        loss, _ = tr.step(*args)
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and min(losses[4:]) < losses[0]

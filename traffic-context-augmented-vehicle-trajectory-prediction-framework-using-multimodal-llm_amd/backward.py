@@ -116,6 +116,15 @@ class Backward:
         dev = self.book.grads.device
         return self.ws.get("bw." + name, shape, dtype, dev, zero=zero)
 
+    def _dropped(self, g, spec, name):
+        """Gradient through a dropout site: g o mask / (1 - p) with the forward's (p, seed, site), in a buffer of its own
+        (g itself usually continues along a residual path).  spec None (eval arithmetic): g unchanged."""
+        if spec is None:
+            return g
+        out = self._buf(name, tuple(g.shape), g.dtype)
+        ops.dropout(g, out, *spec)
+        return out
+
     def lin_bwd_f32(self, x, W, gy, gW, gb, gx=None):
         """y = x W^T + b (fp32).  x [M,K], W [N,K], gy [M,N] -> gW [N,K], gb [N], optional gx [M,K]."""
         M, K = x.shape
@@ -225,6 +234,7 @@ class Backward:
             g_hid = self._buf("g_hid", tuple(hid.shape))
             self.lin_bwd_f32(hid, dec.post_mlp[3].weight, g_d1, G[pl + "decoder.post_mlp.3.weight"],
                              G[pl + "decoder.post_mlp.3.bias"], gx=g_hid)
+            ops.dropout_(g_hid, getattr(m, "drop_post", None))  # hid = drop(relu(.)): mask, then the ReLU gate
             ops.relu_bwd(g_hid, hid)
             g_d0 = self._buf("g_d0", (B, C * To))
             self.lin_bwd_f32(d0, dec.post_mlp[0].weight, g_hid, G[pl + "decoder.post_mlp.0.weight"],
@@ -286,8 +296,11 @@ class Backward:
         xn, qkv, att, res1, rn, ff = f("xn", (Mt, C)), f("qkv", (Mt, 3 * C)), f("att", (Mt, C)), f("res1", (Mt, C)), \
             f("rn", (Mt, C)), f("f", (Mt, 4 * C))
         # e = ff W3^T + b3 + rn ; ff = relu(rn W0^T + b0)
+        sp = getattr(m, "drop_specs", None) or [None] * 4  # [attention weights, after out_proj, after ReLU, after ffn.3]
         g_ff = self._buf("sab.g_ff", (Mt, 4 * C))
-        self.lin_bwd_f32(ff, m.ffn[3].weight, g_e, G[pl + "ffn.3.weight"], G[pl + "ffn.3.bias"], gx=g_ff)
+        self.lin_bwd_f32(ff, m.ffn[3].weight, self._dropped(g_e, sp[3], "sab.g_e_d"), G[pl + "ffn.3.weight"],
+                         G[pl + "ffn.3.bias"], gx=g_ff)
+        ops.dropout_(g_ff, sp[2])
         ops.relu_bwd(g_ff, ff)
         g_rn = self._buf("sab.g_rn", (Mt, C))
         self.lin_bwd_f32(rn, m.ffn[0].weight, g_ff, G[pl + "ffn.0.weight"], G[pl + "ffn.0.bias"], gx=g_rn)
@@ -296,12 +309,13 @@ class Backward:
         ops.layernorm_bwd(res1, m.norm2.weight, g_rn, g_res1, G[pl + "norm2.weight"], G[pl + "norm2.bias"])
         # res1 = att Wo^T + bo + xn
         g_att = self._buf("sab.g_att", (Mt, C))
-        self.lin_bwd_f32(att, m.mha.out_proj.weight, g_res1, G[pl + "mha.out_proj.weight"], G[pl + "mha.out_proj.bias"],
-                         gx=g_att)
+        self.lin_bwd_f32(att, m.mha.out_proj.weight, self._dropped(g_res1, sp[1], "sab.g_res1_d"),
+                         G[pl + "mha.out_proj.weight"], G[pl + "mha.out_proj.bias"], gx=g_att)
         g_qkv = self._buf("sab.g_qkv", (Mt, 3 * C))
         dh = C // m.nhead
         ops.mha_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], g_att, g_qkv[:, :C], g_qkv[:, C:2 * C], g_qkv[:, 2 * C:],
-                    B, T, T, m.nhead, dh, 1.0 / math.sqrt(dh), ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C, ldg=3 * C)
+                    B, T, T, m.nhead, dh, 1.0 / math.sqrt(dh), ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C, ldg=3 * C,
+                    dropout=sp[0])
         g_xn = self._buf("sab.g_xn", (Mt, C))
         self.lin_bwd_f32(xn, m.mha.in_proj_weight, g_qkv, G[pl + "mha.in_proj_weight"], G[pl + "mha.in_proj_bias"],
                          gx=g_xn)
@@ -330,8 +344,17 @@ class Backward:
         dP = self._buf("xa.dP", (B * nh * To, Lp))
         ops.gemm_batched(g_att, v, dP, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
                          sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp))
+        # attention-weight dropout (train mode): the forward kept only the dropped probabilities; the softmax
+        # backward needs the un-dropped ones (recomputed from the retained scores) and the masked dP
+        xsp = getattr(self.m.ltsf, "drop_xattn", None)
+        if xsp is not None:
+            ops.dropout_(dP, xsp)
+            Pu = self._buf("xa.Pu", (B * nh * To, Lp), torch.float16)
+            ops.softmax_rows(ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), Pu, B * nh * To, L, Lp, Lp, Lp)
+        else:
+            Pu = Pm
         dS = self._buf("xa.dS", (B * nh * To, Lp), torch.bfloat16)
-        ops.softmax_bwd_rows(Pm, dP, dS, scale, B * nh * To, L, Lp, Lp, Lp, Lp)
+        ops.softmax_bwd_rows(Pu, dP, dS, scale, B * nh * To, L, Lp, Lp, Lp, Lp)
         # dQ_bh = dS_bh K_bh : contraction over keys -> needs K^T per sample  kT [H, B*Lp]
         kT = self._buf("xa.kT", (H, B * Lp), torch.bfloat16)
         ops.transpose16(kx, kT, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
@@ -350,7 +373,8 @@ class Backward:
         dST = self._buf("xa.dST", (B * nh * Lp, Tp), torch.bfloat16)
         ops.transpose16(dS, dST, To, Lp, Tp, ld_in=Lp, ld_out=Tp, batch=B * nh, s_in=To * Lp, s_out=Lp * Tp)
         Pb = self._buf("xa.Pb", (B * nh * To, Lp), torch.bfloat16)
-        ops.softmax_rows(ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), Pb, B * nh * To, L, Lp, Lp, Lp)
+        ops.softmax_rows(ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), Pb, B * nh * To, L, Lp, Lp, Lp,
+                         dropout=getattr(self.m.ltsf, "drop_xattn", None))  # dV uses the probabilities the forward used
         PT = self._buf("xa.PT", (B * nh * Lp, Tp), torch.bfloat16)
         ops.transpose16(Pb, PT, To, Lp, Tp, ld_in=Lp, ld_out=Tp, batch=B * nh, s_in=To * Lp, s_out=Lp * Tp)
         qT = self._buf("xa.qT", (H, B * Tp), torch.bfloat16)
@@ -382,7 +406,10 @@ class Backward:
             ops.layernorm_bwd(s["y2"], lyr.norm2.weight, g_x, g_y2, G[pre + "norm2.weight"], G[pre + "norm2.bias"])
             ff = lyr.linear1.weight.shape[0]
             g_f = self._buf(f"po.g_f{i}", (M, ff))
-            self.lin_bwd_f32(s["f"], lyr.linear2.weight, g_y2, G[pre + "linear2.weight"], G[pre + "linear2.bias"], gx=g_f)
+            sp = s.get("drop") or [None] * 4  # [attention weights, after out_proj, after ReLU, after linear2]
+            self.lin_bwd_f32(s["f"], lyr.linear2.weight, self._dropped(g_y2, sp[3], f"po.g_y2d{i}"),
+                             G[pre + "linear2.weight"], G[pre + "linear2.bias"], gx=g_f)
+            ops.dropout_(g_f, sp[2])
             ops.relu_bwd(g_f, s["f"])
             g_x1 = self._buf(f"po.g_x1{i}", (M, D))
             self.lin_bwd_f32(s["x1"], lyr.linear1.weight, g_f, G[pre + "linear1.weight"], G[pre + "linear1.bias"], gx=g_x1)
@@ -391,13 +418,13 @@ class Backward:
             ops.layernorm_bwd(s["y"], lyr.norm1.weight, g_x1, g_y, G[pre + "norm1.weight"], G[pre + "norm1.bias"])
             g_att = self._buf(f"po.g_att{i}", (M, D))
             sa = lyr.self_attn
-            self.lin_bwd_f32(s["att"], sa.out_proj.weight, g_y, G[pre + "self_attn.out_proj.weight"],
-                             G[pre + "self_attn.out_proj.bias"], gx=g_att)
+            self.lin_bwd_f32(s["att"], sa.out_proj.weight, self._dropped(g_y, sp[1], f"po.g_yd{i}"),
+                             G[pre + "self_attn.out_proj.weight"], G[pre + "self_attn.out_proj.bias"], gx=g_att)
             qkv = s["qkv"]
             g_qkv = self._buf(f"po.g_qkv{i}", (M, 3 * D))
             ops.mha_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], g_att, g_qkv[:, :D], g_qkv[:, D:2 * D],
                         g_qkv[:, 2 * D:], B, P, P, nh, dh, 1.0 / math.sqrt(dh), key_len=sv.lens, ldq=3 * D, ldk=3 * D,
-                        ldv=3 * D, ldo=D, ldg=3 * D)
+                        ldv=3 * D, ldo=D, ldg=3 * D, dropout=sp[0])
             g_xin = self._buf(f"po.g_xin{i}", (M, D))
             self.lin_bwd_f32(s["x"], sa.in_proj_weight, g_qkv, G[pre + "self_attn.in_proj_weight"],
                              G[pre + "self_attn.in_proj_bias"], gx=g_xin)

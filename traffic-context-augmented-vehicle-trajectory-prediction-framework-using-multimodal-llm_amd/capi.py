@@ -87,7 +87,8 @@ _SIGNATURES = {
     "tcavt_add_inplace": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                      c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+                      c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64,
+                      ctypes.c_uint32, c_void_p],
     "tcavt_softmax_bwd_rows": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_float, c_int, c_int, c_int,
                                c_void_p],
     "tcavt_mse_grad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],

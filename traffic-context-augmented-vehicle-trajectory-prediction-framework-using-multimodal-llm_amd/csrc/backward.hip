@@ -8,6 +8,7 @@
 // reductions over the batch, LayerNorm / softmax / small-attention backward, the
 // per-channel N-Linear blocks, the loss gradient.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace tcavt {
 
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
                                                             float* __restrict__ gq, float* __restrict__ gk,
                                                             float* __restrict__ gv, long ldg,
                                                             const int* __restrict__ key_len, int Lq, int Lk, int nh,
-                                                            int dh, float scale) {
+                                                            int dh, float scale, DropoutP drop) {
+  // With attention-weight dropout (train mode): the forward used P' = P o m / (1 - p) in P' V, m drawn from
+  // (seed, site, ((b nh + h) Lq + i) Lk + j) exactly as tcavt_mha does.  Then dV = P'^T dO, dP = (dO V^T) o m / (1 - p),
+  // dS = P o (dP - sum_j P_j dP_j): the softmax backward needs the UN-dropped P, which is recomputed here anyway.
   extern __shared__ float sm[];
   float* P = sm;             // [Lq][Lk]
   float* dS = sm + Lq * Lk;  // [Lq][Lk]
@@ -193,12 +197,17 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
     s = wave_sum(s);
     const float inv = s > 0.f ? 1.f / s : 0.f;
     float dot = 0.f;
+    const unsigned long long base = ((unsigned long long)blockIdx.x * Lq + i) * (unsigned long long)Lk;
     for (int j = lane; j < Lk; j += 64) {
       row[j] *= inv;
+      if (drop.p > 0.f) drow[j] *= dropout_one(drop, base + j);
       dot += row[j] * drow[j];
     }
     dot = wave_sum(dot);
-    for (int j = lane; j < Lk; j += 64) drow[j] = row[j] * (drow[j] - dot) * scale;
+    for (int j = lane; j < Lk; j += 64) {
+      drow[j] = row[j] * (drow[j] - dot) * scale;
+      if (drop.p > 0.f) row[j] *= dropout_one(drop, base + j);  // P' for dV below
+    }
   }
   __syncthreads();
   for (int id = tid; id < Lq * dh; id += 256) {  // dQ
@@ -516,12 +525,14 @@ extern "C" int tcavt_layernorm_bwd(const float* x, const float* gamma, const flo
 extern "C" int tcavt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                              const float* go, int64_t ldo, float* gq, float* gk, float* gv, int64_t ldg,
                              const int32_t* key_len, int B, int Lq, int Lk, int nh, int dh, float scale,
-                             tcavt_stream_t stream) {
+                             float dropout_p, uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(q && k && v && go && gq && gk && gv && B > 0 && Lq > 0 && Lk > 0 && nh > 0 && dh > 0, "mha_bwd: bad args");
+  TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "mha_bwd: dropout_p must be in [0, 1)");
   const long lds = 2L * Lq * Lk * 4;
   TCAVT_CHECK_ARG(lds <= 64 * 1024, "mha_bwd: 2*Lq*Lk*4 = %ld bytes exceeds 64 KiB", lds);
   hipLaunchKernelGGL(mha_small_bwd_kernel, dim3(B * nh), dim3(256), lds, S_(stream), q, (long)ldq, k, (long)ldk, v,
-                     (long)ldv, go, (long)ldo, gq, gk, gv, (long)ldg, key_len, Lq, Lk, nh, dh, scale);
+                     (long)ldv, go, (long)ldo, gq, gk, gv, (long)ldg, key_len, Lq, Lk, nh, dh, scale,
+                     make_dropout(dropout_p, dropout_seed, dropout_site));
   TCAVT_CHECK_LAUNCH("mha_bwd");
   return TCAVT_OK;
 }

