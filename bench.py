@@ -56,6 +56,9 @@ def parse():
                          "GPU, and the side streams of the forward / backward overlap as written.  graph: replay of a "
                          "hipGraph of the step; measured slower (18.85 vs 18.4 ms) because the graph executor maps the "
                          "captured side-stream branches onto its own queues and serialises independent chains")
+    ap.add_argument("--no-dropout", action="store_true",
+                    help="train mode only: run the step with model.eval() arithmetic (dropout = identity) instead of "
+                         "ddp_model.train() (train.py:1152; dropout 0.1 in the lane-polygon encoder, Q-Former, LoRA branch, LTSF)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not start the (frozen) Q-Former of the next batch underneath the step in flight")
     ap.add_argument("--no-graph", action="store_true", help="(kept for old command lines; same as --launch eager)")
@@ -175,7 +178,8 @@ def main():
     W = make_weights(cfg, seed=1, backend="torch", device=dev)
     m.load_weights(W)
     del W
-    m.eval()
+    dropout_on = args.mode == "train" and not args.no_dropout
+    m.train(dropout_on)
     m.mllm.llama_wrapper.gemm_tile = args.tile
     torch.cuda.empty_cache()
 
@@ -296,7 +300,7 @@ def main():
                              "frozen, :1140-1145) + gradient all-reduce + AdamW(lr 5e-4, wd 1e-4)"
                              if args.mode == "train" else
                              "MultiModalTrajectoryModel.forward incl. loss (train.py:914-964)")
-                            + "; Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head; dropout off",
+                            + "; Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head; " + ("dropout on as under ddp_model.train() (in-kernel Philox masks, regenerated in the backward)" if dropout_on else "dropout off (eval arithmetic)"),
                 "mode": args.mode,
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
                 "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",

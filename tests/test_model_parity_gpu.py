@@ -301,3 +301,30 @@ def test_prefetch_is_transparent(gpu):
         out = fwd(v)
         m.prefetch(v)
     assert torch.equal(out, ref) and torch.equal(fwd(v), ref)
+
+
+def test_prefetch_is_transparent_in_train_mode(gpu):
+    """With dropout on, the prefetched Q-Former must draw the masks the next forward would have drawn itself."""
+    from tcavt_amd import model
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).train()
+    v = g["vision_emb"]
+
+    def fwd():
+        with torch.no_grad():
+            return m(g["traj_emb"], v, None, g["lane_polygon"], g["lane_polygon_len"], input_ids=g["input_ids"],
+                     attention_mask=g["attention_mask"]).clone()
+
+    m._fwd_count = 0
+    a0, a1 = fwd(), fwd()
+    assert not torch.equal(a0, a1)           # successive train-mode passes use successive seeds
+    m._fwd_count = 0
+    b0 = fwd()
+    m.prefetch(v)                            # Q-Former of pass 1, with pass 1's masks, on the side stream
+    b1 = fwd()
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    assert m.mllm._pf is None                # consumed (a miss would have recomputed and also passed)

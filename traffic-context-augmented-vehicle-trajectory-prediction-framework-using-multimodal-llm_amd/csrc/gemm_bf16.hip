@@ -955,6 +955,25 @@ static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+// Launches below one wave of 256x256 tiles (tile = 128, 64 or 0 = pick).
+template <int EPI, bool F16>
+static int launch_small(const GemmP& p, int tile, int batch, hipStream_t stream) {
+  GemmP q = p;
+  q.prio = 0;
+  // grids that leave CUs idle: the 4-stage loop (latency bound, one workgroup per CU is no loss);
+  // fuller grids: interleaved DMA issue, 64 KiB of LDS so that two workgroups share a CU
+  const long wgs = (long)((q.M + 127) / 128) * ((q.N + 127) / 128) * batch;
+  static const bool no_deep = getenv("TCAVT_GEMM_NO_DEEP") != nullptr;  // A/B switches
+  static const bool no_64 = getenv("TCAVT_GEMM_NO_64") != nullptr;
+  if constexpr (EPI != EPI_ROPE) {
+    // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
+    // each K-tile costing a quarter of the DMA issue and MFMA time
+    if ((tile == 64 || (tile == 0 && wgs < 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
+  }
+  if (wgs <= 256 && !no_deep) return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
+  return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
+}
+
 // tile codes (tcavt_gemm_args.tile): 0 auto | 256, 128 the production variants |
 // A/B variants kept reachable: 255 = 256x256 with burst DMA issue, 253 / 252 = 255 with static / no wave
 // priority, 250 = 256x256 32-deep ring pipeline, 127 = 128x128 with MFMA-cluster priority,
@@ -1001,21 +1020,7 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 126: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
     case 125: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
     case 124: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
-    default: {  // 128
-      q.prio = 0;
-      // grids that leave CUs idle: the 4-stage loop (latency bound, one workgroup per CU is no loss);
-      // fuller grids: interleaved DMA issue, 64 KiB of LDS so that two workgroups share a CU
-      const long wgs = (long)((q.M + 127) / 128) * ((q.N + 127) / 128) * batch;
-      static const bool no_deep = getenv("TCAVT_GEMM_NO_DEEP") != nullptr;  // A/B switches
-      static const bool no_64 = getenv("TCAVT_GEMM_NO_64") != nullptr;
-      if constexpr (EPI != EPI_ROPE) {
-        // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
-        // each K-tile costing a quarter of the DMA issue and MFMA time
-        if ((tile == 64 || (tile == 0 && wgs < 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
-      }
-      if (wgs <= 256 && !no_deep) return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
-      return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
-    }
+    default: return launch_small<EPI, F16>(q, tile, batch, stream);  // 128 / 64 / 0 (auto)
   }
 }
 
@@ -1122,8 +1127,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
   if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
     TCAVT_CHECK_ARG(!f16, "gemm_bf16: dropout needs bf16 operands");
-    p.prio = 0;
-    return launch<128, 128, 2, 2, EPI_DROP, false, 1>(p, 1, s);
+    return launch_small<EPI_DROP, false>(p, a->tile == 64 || a->tile == 128 ? a->tile : 0, 1, s);
   }
   if (f16) return dispatch_tile<EPI_GENERIC, true>(p, tile, batch, s);
   return dispatch_tile<EPI_GENERIC, false>(p, tile, batch, s);

@@ -110,8 +110,13 @@ class DropoutCtx:
     in call order, under one 64-bit seed; the kernels derive the mask from (seed, site, element index) with
     Philox4x32-10 (csrc/philox.hpp), so nothing is stored and a pass is reproducible from its seed."""
 
-    def __init__(self, seed):
-        self.seed, self.site = int(seed), 0
+    def __init__(self, seed, first_site=0):
+        self.seed, self.site = int(seed), int(first_site)
+
+    def sub(self, block):
+        """Site namespace of one module (block * 65536 + 1, ...): the numbering inside a module then does not depend
+        on the order in which the modules are launched (side streams, Q-Former prefetch)."""
+        return DropoutCtx(self.seed, first_site=block << 16)
 
     def spec(self, p):
         if p is None or p <= 0.0:
@@ -576,7 +581,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
     def _pf_key(t):
         return (t.data_ptr(), tuple(t.shape), t._version)
 
-    def prefetch(self, vision_embs, ready=None):
+    def prefetch(self, vision_embs, ready=None, dctx=None):
         """Software pipelining across calls (optional; results are identical with or without it).  The Q-Former and
         q_proj are frozen and depend on nothing but `vision_embs`, yet they are ~50 small launches that leave the chip
         idle in front of every decoder pass.  `prefetch(next_vision_embs)` enqueues them on a side stream as soon as
@@ -584,8 +589,9 @@ class LlamaMultiModal(nn.Module, _Prepared):
         the next forward() on the same tensor picks the result up instead of recomputing it.
         Contract: `vision_embs` is complete when this is called, or `ready` is a torch.cuda.Event marking its
         completion (the side stream does not wait for the caller's stream, that would serialise it behind the pass
-        in flight).  Ignored in train mode (dropout sites are numbered in call order)."""
-        if self.training or vision_embs.device.type != "cuda":
+        in flight).  In train mode `dctx` carries the dropout seed / site namespace the next forward will use for the
+        Q-Former (MultiModalTrajectoryModel.prefetch supplies it)."""
+        if vision_embs.device.type != "cuda" or (self.training and dctx is None):
             return
         if self._pf_stream is None:
             self._pf_stream = torch.cuda.Stream(device=vision_embs.device)
@@ -594,12 +600,13 @@ class LlamaMultiModal(nn.Module, _Prepared):
             s.wait_event(ready)
         if self._img_consumed is not None:
             s.wait_event(self._img_consumed)  # workspaces / image tokens of the previous pass are free
+        tag = None if dctx is None else (dctx.seed, dctx.site)  # masks are a function of (seed, first site)
         with torch.cuda.stream(s), torch.no_grad():
-            self.qformer.dctx = None
+            self.qformer.dctx = dctx
             self._image_tokens(vision_embs)
             done = torch.cuda.Event()
             done.record(s)
-        self._pf = (self._pf_key(vision_embs), done, vision_embs)
+        self._pf = (self._pf_key(vision_embs), done, vision_embs, tag)
 
     def _prepare(self):
         return SimpleNamespace(w_qp=_bf16(self.q_proj.weight),
@@ -618,7 +625,9 @@ class LlamaMultiModal(nn.Module, _Prepared):
         Nq = self.qformer.num_query_tokens
         L = Nq + Lt
         pf, self._pf = self._pf, None
-        if pf is not None and pf[0] == self._pf_key(vision_embs) and not self.training:
+        want = self.qformer.dctx  # (train mode) the masks this forward must use; a prefetch made for them carries the same
+        if pf is not None and pf[0] == self._pf_key(vision_embs) and \
+                pf[3] == (None if want is None else (want.seed, want.site)):
             torch.cuda.current_stream().wait_event(pf[1])  # prefetched on the side stream (see prefetch)
             img = ws.get("mm.img", (B * Nq, H), torch.float32, dev)
         else:
@@ -921,8 +930,8 @@ class MultiModalTrajectoryModel(nn.Module):
 
     def prefetch(self, vision_embs, ready=None):
         """Start the frozen Q-Former of the NEXT batch underneath the pass in flight (LlamaMultiModal.prefetch)."""
-        if not self.training:
-            self.mllm.prefetch(vision_embs, ready=ready)
+        dctx = DropoutCtx(self.dropout_seed + self._fwd_count).sub(1) if self.training else None  # the next forward's masks
+        self.mllm.prefetch(vision_embs, ready=ready, dctx=dctx)
 
     def forward(self, x, vision_embs, context_str, lane_polygon_batch, lane_polygon_len, y=None, norm_stat=None,
                 input_ids=None, attention_mask=None, labels=None):
@@ -933,8 +942,9 @@ class MultiModalTrajectoryModel(nn.Module):
         if self.training:
             dctx = DropoutCtx(self.dropout_seed + self._fwd_count)
             self._fwd_count += 1
-        self.lane_polygon_encoder.dctx = self.mllm.qformer.dctx = self.mllm.llama_wrapper.dctx = dctx
-        self.ltsf.dctx = self.ltsf.attn_block.dctx = dctx
+        sub = (lambda b: dctx.sub(b)) if dctx is not None else (lambda b: None)
+        self.lane_polygon_encoder.dctx, self.mllm.qformer.dctx, self.mllm.llama_wrapper.dctx = sub(0), sub(1), sub(2)
+        self.ltsf.dctx = self.ltsf.attn_block.dctx = sub(3)
         # The lane-polygon encoder and the LLM-independent half of the LTSF (token projection, N-Linear
         # encoder, self-attention block) are chains of small launches that leave most CUs idle; they run
         # on a side stream, concurrently with the Q-Former / decoder stack, and join before the LTSF head.
