@@ -103,7 +103,7 @@ def cpu_baseline(cfg, args):
     log(f"cpu_baseline: generating fp32 weights on the host ({cores} threads)")
     W = make_weights(cfg, seed=1, backend="torch", device="cpu")
     log("cpu_baseline: timing the oracle")
-    b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True, min_text=min(128, max(1, args.text_len // 2)))
+    b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True, min_text=128 if args.text_len > 128 else max(1, args.text_len // 2))
     t = {k: torch.from_numpy(v) for k, v in b.items()}
 
     train = args.mode == "train"
@@ -184,7 +184,7 @@ def main():
     torch.cuda.empty_cache()
 
     # rank r works on its own shard of the global batch (seeded by rank): weak scaling
-    b = synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank, ragged=True, min_text=min(128, max(1, args.text_len // 2)))
+    b = synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank, ragged=True, min_text=128 if args.text_len > 128 else max(1, args.text_len // 2))
     g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
     trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4) if args.mode == "train" else None
