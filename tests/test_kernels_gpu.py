@@ -53,8 +53,9 @@ def test_gemm_w4_matches_8wave(gpu, K):
     for kw in (dict(), dict(residual=res), dict(bias=bias, relu=True, residual=res), dict(silu_mul=True)):
         for dt in (torch.float32, torch.bfloat16):
             r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
-            r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=257, **kw)
-            assert torch.equal(r8, r4), (sorted(kw), dt)
+            for code in (257, 271):  # 256x256 (2x2 waves) and 256x192 (4x1 waves; N = 768 = 4 x 192) forms
+                r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=code, **kw)
+                assert torch.equal(r8, r4), (code, sorted(kw), dt)
     # fused q|k|v form: RoPE epilogue (bf16 out) with and without the LoRA second K source
     pos = torch.arange(128, dtype=torch.float32)
     ang = pos[:, None] * (1.0 / (10000.0 ** (torch.arange(0, 64, 2, dtype=torch.float32) / 64)))[None, :]
@@ -63,8 +64,9 @@ def test_gemm_w4_matches_8wave(gpu, K):
     w2 = _bf(torch.randn(N, 64, generator=g) * 0.05).to(dev)
     for kw in (dict(rope=(cos, sin, 512)), dict(rope=(cos, sin, 512), a2=a2, w2=w2)):
         r8 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=256, **kw)
-        r4 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=257, **kw)
-        assert torch.equal(r8, r4), sorted(kw)
+        for code in (257, 271):
+            r4 = ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, tile=code, **kw)
+            assert torch.equal(r8, r4), (code, sorted(kw))
     out = ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257)
     assert _rel(out, a.float() @ w.float().T) < 2e-6
     h = res.clone()

@@ -685,21 +685,25 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x
 // DBG (timing experiments only, results are wrong): 1 = no DMA in the loop, 2 = no barrier, 4 = no fragment loads
 // BUF: stage with buffer_load ... lds (SGPR resource + one constant per-lane VGPR offset + scalar per-piece offset)
 // instead of global_load ... lds (64-bit per-lane address, two VALU ops per piece).
-template <int EPI, int B2R, int DBG = 0, bool BUF = false>
+// BN = 256: 2 x 2 waves of 128 x 128.  BN = 192: 4 x 1 waves of 64 x 192 (4 x 12 MFMA tiles, 192 accumulator
+// registers) for N = 3072 (fused q|k|v): 512 tiles = two full waves of 256 CUs instead of 384 = one and a half.
+template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
-  constexpr int BM = 256, BN = 256, NW = 4;
-  constexpr int TM = 8, TN = 8;
+  constexpr int BM = 256, NW = 4;
+  constexpr int WN_ = BN == 256 ? 2 : 1, WM_ = NW / WN_;
+  constexpr int TM = BM / WM_ / 16, TN = BN / WN_ / 16;
+  static_assert(TM + TN == 16, "the fragment pipeline assumes 16 fragment loads per 32-deep K-step");
   constexpr int TILE_BYTES = (BM + BN) * 128;
-  constexpr int NP = 16;    // DMA pieces (8 rows x 128 B per wave-instruction) per thread and K-tile
+  constexpr int NP = (BM + BN) / 32;  // DMA pieces (8 rows x 128 B per wave-instruction) per thread and K-tile
   constexpr int NB2 = B2R * TM;     // MFMAs after the barrier (phase B2)
   constexpr bool S1 = DBG & 16, S2 = DBG & 32;  // schedule variants (valid results)
   constexpr int EARLY = S2 ? 0 : NB2 / 4;    // pieces of tile t+2 issued in phase B2 of tile t
-  constexpr int SPREAD = 64 / (NP - EARLY);  // phase A: one DMA piece per SPREAD MFMAs
+  constexpr int SPREAD = (TM * TN) / (NP - EARLY);  // phase A: one DMA piece per SPREAD MFMAs
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN_, wn = wave % WN_;
   int tile_m, tile_n;
   block_to_tile(p, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -771,8 +775,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const int fsw = (lane >> 1) & 7;
   const int off0 = ((lane >> 4) ^ fsw) * 16;
   const int off1 = ((4 + (lane >> 4)) ^ fsw) * 16;
-  const int xrow = (wm * 128 + (lane & 15)) * 128;
-  const int wrow = (BM + wn * 128 + (lane & 15)) * 128;
+  const int xrow = (wm * TM * 16 + (lane & 15)) * 128;
+  const int wrow = (BM + wn * TN * 16 + (lane & 15)) * 128;
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -867,11 +871,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
       for (int j = 0; j < TM; ++j) {
         mfma_agpr(acc[i][j], w1[i], x1[j]);
         const int idx = (i - (TN - B2R)) * TM + j;  // 0..NB2-1
-        if (frd && more && !S2 && idx < TM) {  // the 16 fragment loads go first, two per MFMA
+        if (frd && more && !S2 && TM == TN && idx < TM) {  // the 16 fragment loads go first, two per MFMA
           x0[idx] = ldx(nbase, off0, idx);
           w0[idx] = ldw(nbase, off0, idx);
         }
-        if (frd && more && S2 && idx < 16) {  // S2: one per MFMA
+        if (frd && more && (S2 || TM != TN) && idx < 16) {  // S2 / unequal fragment counts: one per MFMA
           if (idx < TM) x0[idx] = ldx(nbase, off0, idx);
           else w0[idx - TM] = ldw(nbase, off0, idx - TM);
         }
@@ -900,10 +904,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-  gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * 128, n0 + wn * 128, lane);
+  gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
 }
 
-template <int EPI, int B2R, int DBG = 0, bool BUF = false>
+template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256>
 static int launch_w4(const GemmP& p0, hipStream_t stream) {
   if (BUF && ((long)256 * p0.lda * 2 + (long)p0.K * 2 >= (1L << 31) || (long)256 * p0.ldw * 2 + (long)p0.K * 2 >= (1L << 31))) {
     set_error("gemm_bf16(w4, buffer loads): a 256-row operand panel must span < 2 GiB");
@@ -911,10 +915,10 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   }
   GemmP p = p0;
   p.tiles_m = p.M / 256;
-  p.tiles_n = p.N / 256;
+  p.tiles_n = p.N / BN;
   p.xcd_gx = choose_xcd_partition(p);
-  constexpr int lds = 2 * 512 * 128;
-  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF>;
+  constexpr int lds = 2 * (256 + BN) * 128;
+  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF, BN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -989,6 +993,14 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 253: q.prio = 1; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 252: q.prio = 0; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
+    case 271:  // 256 x 192 tiles (N % 192 == 0)
+      if constexpr (!F16) {
+        if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 192 == 0 &&
+            (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16))
+          return launch_w4<EPI, 4, 0, false, 192>(q, stream);
+      }
+      set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs bf16 operands, M %% 256 == 0, N %% 192 == 0, no batch");
+      return TCAVT_ERR_ARG;
     case 257: case 258: case 259: case 268: case 269: case 270:
       if constexpr (!F16) {
         if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
@@ -1077,7 +1089,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 270 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 271 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;
@@ -1119,8 +1131,15 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     // whole 256x256 tiles, one K source, bf16, no RoPE: the 4-wave kernel (gate|up 406 vs 434 us, down 204 vs 218,
     // o 57.5 vs 60 on the 8-wave kernel)
     if (tile == 256 && !f16 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 &&
-        ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == TCAVT_BF16 : K2 == 0))
+        ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == TCAVT_BF16 : K2 == 0)) {
       tile = 257;
+      // 256 x 192 tiles where they fill whole waves of 256 CUs and 256 x 256 tiles do not (q|k|v: N = 3072)
+      if (a->N % 192 == 0) {
+        const long t192 = (long)(a->M / 256) * (a->N / 192);
+        const double f256 = (double)t256 / (double)(waves * 256), f192 = (double)t192 / (double)((t192 + 255) / 256 * 256);
+        if (f192 > f256 + 0.1) tile = 271;
+      }
+    }
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
