@@ -53,7 +53,7 @@ def test_gemm_w4_matches_8wave(gpu, K):
     for kw in (dict(), dict(residual=res), dict(bias=bias, relu=True, residual=res), dict(silu_mul=True)):
         for dt in (torch.float32, torch.bfloat16):
             r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
-            for code in (257, 271):  # 256x256 (2x2 waves) and 256x192 (4x1 waves; N = 768 = 4 x 192) forms
+            for code in (257, 271, 272):  # 256x256 (2x2 waves), 256x192 (4x1 waves; N = 768 = 4 x 192), two-barrier deep-prefetch form
                 r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=code, **kw)
                 assert torch.equal(r8, r4), (code, sorted(kw), dt)
     # fused q|k|v form: RoPE epilogue (bf16 out) with and without the LoRA second K source

@@ -697,6 +697,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   constexpr int NP = (BM + BN) / 32;  // DMA pieces (8 rows x 128 B per wave-instruction) per thread and K-tile
   constexpr int NB2 = B2R * TM;     // MFMAs after the barrier (phase B2)
   constexpr bool S1 = DBG & 16, S2 = DBG & 32;  // schedule variants (valid results)
+  // DEEP (DBG & 64, valid results): a second barrier in the middle of phase A, where every wave holds all
+  // fragments of tile t in registers, frees tile t's LDS buffer a whole K-tile earlier; the 16 pieces of tile t+2 are
+  // issued behind it (one per 4 MFMAs over the rest of phase A and phase B1) and stay in flight ACROSS the end-of-B1
+  // barrier, which waits with a counted vmcnt(NP) for the older tile t+1 only.  Every piece gets >= one full K-tile
+  // (2048 MFMA cycles) to land instead of 0.4-1.2.
+  constexpr bool DEEP = DBG & 64;
+  static_assert(!DEEP || (TM == 8 && TN == 8), "DEEP is laid out for the 2x2-wave form");
   constexpr int EARLY = S2 ? 0 : NB2 / 4;    // pieces of tile t+2 issued in phase B2 of tile t
   constexpr int SPREAD = (TM * TN) / (NP - EARLY);  // phase A: one DMA piece per SPREAD MFMAs
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -796,7 +803,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   }
   __syncthreads();
   Src sn1 = tsrc(1);  // source of tile t+1, carried from iteration to iteration (sn1(t+1) = sn2(t))
-  if (nt > 1) {
+  if constexpr (DEEP) {
+#pragma unroll
+    for (int r = 0; r < NP; ++r) piece(1, sn1, r);  // all of tile 1 (tsrc clamps when there is none: harmless re-fetch)
+  } else if (nt > 1) {
 #pragma unroll
     for (int r = 0; r < EARLY; ++r) piece(1, sn1, r);
   }
@@ -832,7 +842,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           if (idx < TM) x1[idx] = ldx(base, off1, idx);
           else w1[idx - TM] = ldw(base, off1, idx - TM);
         }
-        if (!S1) {
+        if constexpr (DEEP) {
+          if (idx == 0) {
+            const int tt = min(t + 2, nt - 1);
+            second2 = HASK2 && tt >= nt1;
+            koff2 = (second2 ? tt - nt1 : tt) * 64;
+          }
+          if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
+          if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
+          if (idx == 9) {
+            sn2.sa = second2 ? stepA2 : stepA;
+            sn2.sw = second2 ? stepW2 : stepW;
+          }
+          if (idx == 39 && bar) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile t is in registers everywhere
+          if (dma && idx >= 43 && (idx & 3) == 3) piece(cur, sn2, (idx - 43) / 4);  // pieces 0..5 of tile t+2
+        } else if (!S1) {
           if (dma && more && idx % SPREAD == SPREAD - 1 && EARLY + idx / SPREAD < NP) piece(cur ^ 1, sn1, EARLY + idx / SPREAD);
         } else {
           if (dma && more && idx >= 16 && (idx & 3) == 3 && EARLY + (idx - 16) / 4 < NP) piece(cur ^ 1, sn1, EARLY + (idx - 16) / 4);
@@ -846,6 +870,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
       for (int j = 0; j < TM; ++j) {
         mfma_agpr(acc[i][j], w1[i], x1[j]);
         const int idx = i * TM + j;
+        if constexpr (DEEP) {
+          if (dma && (idx & 3) == 3 && 6 + idx / 4 < NP) piece(cur, sn2, 6 + idx / 4);  // pieces 6..15 of tile t+2
+          continue;
+        }
         if (idx == 0) {
           const int tt = min(t + 2, nt - 1);  // clamp: see tsrc
           second2 = HASK2 && tt >= nt1;
@@ -862,7 +890,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           }
         }
       }
-    if (more && bar && (DBG & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA wait (timing only)
+    if (DEEP && bar) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NP) : "memory");  // tile t+1 landed; t+2 in flight
+    else if (more && bar && (DBG & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // no DMA wait (timing only)
     else if (more && bar) __syncthreads();  // tile t+1 has landed for everyone; nobody reads tile t any more
     // ---- phase B2: last 16 MFMAs on F1 | load F0 of tile t+1 | first DMA pieces of tile t+2
 #pragma unroll
@@ -879,7 +908,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           if (idx < TM) x0[idx] = ldx(nbase, off0, idx);
           else w0[idx - TM] = ldw(nbase, off0, idx - TM);
         }
-        if (dma && more2 && (idx & 3) == 3 && (idx >> 2) < EARLY) piece(cur, sn2, idx >> 2);
+        if (!DEEP && dma && more2 && (idx & 3) == 3 && (idx >> 2) < EARLY) piece(cur, sn2, idx >> 2);
       }
     }
     cur ^= 1;
@@ -896,6 +925,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   for (int t = 0; t < nt; ++t) ktile(T_{}, T_{}, t);
 #endif
   // the accumulators are read by VALU next: cover the MFMA write latency the compiler cannot see behind the asm
+  if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   // ... and pin every accumulator read behind those nops: an empty volatile asm that redefines the register is
   // ordered after the s_nop asm, and the epilogue's v_accvgpr_read depends on it (without this the scheduler is
@@ -1001,10 +1031,13 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
       }
       set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs bf16 operands, M %% 256 == 0, N %% 192 == 0, no batch");
       return TCAVT_ERR_ARG;
-    case 257: case 258: case 259: case 268: case 269: case 270:
+    case 257: case 258: case 259: case 268: case 269: case 270: case 272:
       if constexpr (!F16) {
         if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
             (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16)) {
+          if (tile == 272) {
+            if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 64>(q, stream);
+          }
           if (tile == 270) {
             if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 0, true>(q, stream);
           }
@@ -1089,7 +1122,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 271 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 272 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 
   GemmP p;
@@ -1139,6 +1172,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
         const double f256 = (double)t256 / (double)(waves * 256), f192 = (double)t192 / (double)((t192 + 255) / 256 * 256);
         if (f192 > f256 + 0.1) tile = 271;
       }
+      // long K (down projection, K = 8192): the two-barrier form with a whole K-tile of DMA in flight (190 vs 200 us);
+      // neutral to slightly worse at K = 2048
+      if (tile == 257 && !(epi & TCAVT_EPI_ROPE) && a->K >= 4096) tile = 272;
     }
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
