@@ -122,9 +122,13 @@ int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
  * (modeling_llama.py:62-67; F1/F7 of SURVEY.md section 8a).
  * out_f32 (optional) receives the un-rounded fp32 result (final norm ->
  * hidden_states[-1], scripts/train.py:553).  H % 8 == 0, H <= 8192.
+ * out_drop_bf16 (optional, train mode) additionally receives dropout(out_bf16) with the Philox mask of
+ * (dropout_seed, dropout_site, element m * H + n) -- the LoRA branch input (PEFT lora_dropout on x,
+ * scripts/train.py:433-440); identical to tcavt_dropout applied to out_bf16.
  * ---------------------------------------------------------------------- */
 int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
-                  float* out_f32, int M, int H, tcavt_stream_t stream);
+                  float* out_f32, int M, int H, void* out_drop_bf16, float dropout_p,
+                  uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * nn.LayerNorm over the last dim with optional fused residual add:

@@ -115,3 +115,24 @@ def test_mc_dropout_candidates(gpu):
     r1 = evaluate.evaluate_model(m, [g], num_candidates=1)
     r5 = evaluate.evaluate_model(m, [g], num_candidates=5, mc_dropout=True)
     assert not m.training and r5["n"] == r1["n"] and all(math.isfinite(r5[k]) for k in ("ADE", "FDE", "RMSE"))
+
+
+def test_rmsnorm_fused_dropout_matches_two_pass(gpu):
+    """tcavt_rmsnorm's optional dropped output (LoRA branch input) is bit-identical to tcavt_dropout on its bf16 output."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(2)
+    for M, H in ((37, 2048), (64, 384)):  # exact-template width and the generic two-pass width
+        x = torch.randn(M, H, generator=g).to(dev)
+        gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+        spec = (0.1, 99, 7)
+        xn = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+        xd = torch.empty_like(xn)
+        ops.rmsnorm(x, gamma, 1e-5, out_bf16=xn, out_drop=xd, dropout=spec)
+        xn2 = torch.empty_like(xn)
+        ops.rmsnorm(x, gamma, 1e-5, out_bf16=xn2)
+        ref = torch.empty_like(xn)
+        ops.dropout(xn2, ref, *spec)
+        assert torch.equal(xn, xn2) and torch.equal(xd, ref)
+        assert 0.05 < (xd == 0).float().mean().item() < 0.15

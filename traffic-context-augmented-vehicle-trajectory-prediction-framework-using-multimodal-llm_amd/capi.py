@@ -54,7 +54,8 @@ _SIGNATURES = {
     "tcavt_last_error": [],
     "tcavt_init": [c_int, ctypes.POINTER(c_int)],
     "tcavt_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
-    "tcavt_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, ctypes.c_uint64,
+                      ctypes.c_uint32, c_void_p],
     "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -28,10 +28,22 @@ template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ gamma, float eps,
                                                       bf16_t* __restrict__ out_bf16,
-                                                      float* __restrict__ out_f32, int M, int H) {
+                                                      float* __restrict__ out_f32, int M, int H,
+                                                      bf16_t* __restrict__ out_drop, DropoutP drop) {
+  // out_drop (optional): dropout(out_bf16) with the mask of (seed, site, row * H + column) -- bit-identical to running
+  // tcavt_dropout on out_bf16 afterwards (the LoRA branch input, train.py:433-440), without re-reading it
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  auto store_drop = [&](const f32x4& y, int idx) {
+    float sc[4];
+    dropout_quad(drop, ((unsigned long long)row * (unsigned long long)H + 4ull * idx) >> 2, sc);
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = bf16_to_f32(f32_to_bf16(y[e])) * sc[e];
+    u32x2 o = {pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3])};
+    *reinterpret_cast<u32x2*>(out_drop + (long)row * H + idx * 4) = o;
+  };
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * H);
   const f32x4* gr = reinterpret_cast<const f32x4*>(gamma);
   if constexpr (NV > 0) {
@@ -56,6 +68,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
       }
       if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
+      if (out_drop) store_drop(y, idx);
     }
   } else {
     const int nvec = H >> 2;
@@ -77,6 +90,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
       }
       if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
+      if (out_drop) store_drop(y, idx);
     }
   }
 }
@@ -340,14 +354,19 @@ extern "C" int tcavt_init(int device, int* num_cus) {
 }
 
 extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
-                             float* out_f32, int M, int H, tcavt_stream_t stream) {
+                             float* out_f32, int M, int H, void* out_drop_bf16, float dropout_p,
+                             uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "rmsnorm: null pointer");
+  TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (!out_drop_bf16 || dropout_p > 0.f),
+                  "rmsnorm: out_drop needs 0 < dropout_p < 1");
+  bf16_t* od = static_cast<bf16_t*>(out_drop_bf16);
+  const DropoutP drop = make_dropout(dropout_p, dropout_seed, dropout_site);
   TCAVT_CHECK_ARG(M > 0 && H > 0 && H % 8 == 0, "rmsnorm: H=%d must be a multiple of 8", H);
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma), "rmsnorm: unaligned input");
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((M + 3) / 4), block(256);
   bf16_t* ob = static_cast<bf16_t*>(out_bf16);
-#define TCAVT_RMS(NV) hipLaunchKernelGGL(rmsnorm_kernel<NV>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H)
+#define TCAVT_RMS(NV) hipLaunchKernelGGL(rmsnorm_kernel<NV>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H, od, drop)
   switch (H % 256 == 0 ? H / 256 : 0) {
     case 1: TCAVT_RMS(1); break;
     case 2: TCAVT_RMS(2); break;

@@ -496,13 +496,14 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         mark = (lambda n: tm.start(n)) if tm else (lambda n: None)
         done = (lambda n: tm.stop(n)) if tm else (lambda n: None)
         for d in P.layers:
-            ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
+            xl = xn
+            dspec = _spec(self.dctx, self.lora_dropout) if self.use_lora else None
+            if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
+                xl = ws.get("ll.xn_drop", (M, H), torch.bfloat16, dev)
+                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xl, dropout=dspec)  # both from one pass over h
+            else:
+                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
             if self.use_lora:
-                xl = xn
-                dspec = _spec(self.dctx, self.lora_dropout)
-                if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
-                    xl = ws.get("ll.xn_drop", (M, H), torch.bfloat16, dev)
-                    ops.dropout(xn, xl, *dspec)
                 ops.gemm_bf16(xl, d.a_cat, out=t, acc_scale=self.lora_alpha / self.lora_r, tile=128)
                 mark("qkv")
                 ops.gemm_bf16(xn, d.w_qkv, out=qkv, a2=t, w2=d.b_ext, rope=(cos, sin, (nq + nkv) * hd), tile=tile)

@@ -183,15 +183,21 @@ def dropout(x, out, p, seed, site):
     return out
 
 
-def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None):
+def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None, out_drop=None, dropout=None):
+    """out_drop (bf16, with dropout=(p, seed, site)): dropout(out_bf16) from the same pass (LoRA branch input)."""
     _req(x, torch.float32, "rmsnorm.x")
     _req(gamma, torch.float32, "rmsnorm.gamma")
     M, H = x.shape
     _need(gamma, H, "rmsnorm.gamma")
     _need(out_bf16, M * H, "rmsnorm.out_bf16")
     _need(out_f32, M * H, "rmsnorm.out_f32")
-    check(lib().tcavt_rmsnorm(ptr(x), ptr(gamma), eps, ptr(out_bf16), ptr(out_f32), M, H, stream_ptr()),
-          "tcavt_rmsnorm")
+    if (out_drop is None) != (dropout is None):
+        raise capi.TcavtError("rmsnorm: out_drop and dropout go together")
+    if out_drop is not None:
+        _req(out_drop, torch.bfloat16, "rmsnorm.out_drop")
+        _need(out_drop, M * H, "rmsnorm.out_drop")
+    check(lib().tcavt_rmsnorm(ptr(x), ptr(gamma), eps, ptr(out_bf16), ptr(out_f32), M, H, ptr(out_drop),
+                              *_drop(dropout), stream_ptr()), "tcavt_rmsnorm")
 
 
 def layernorm(x, gamma, beta, eps=1e-5, residual=None, out_f32=None, out_bf16=None):
