@@ -16,6 +16,7 @@ Differences from the reference that are deliberate and documented in DESIGN.md:
     tokenizer that does not exist offline and raises ``NotImplementedError``;
   * eval-mode arithmetic only (dropout = identity) in this round.
 """
+import contextlib
 import math
 from types import SimpleNamespace
 
@@ -766,6 +767,7 @@ class TransformerLTSF(nn.Module, _Prepared):
         self._prep = None
         self.save_for_backward = False  # set by training.Trainer
         self.dropout_p, self.dctx = dropout_rate, None
+        self._kv_stream = None
 
     def _prepare(self):
         dec, C = self.decoder, self.d_model
@@ -804,6 +806,35 @@ class TransformerLTSF(nn.Module, _Prepared):
         dec, P = self.decoder, self._prepared()
         L, H = final_hidden.shape[1], final_hidden.shape[2]
         x = x.contiguous()
+        nh = dec.cross_nhead
+        dh = H // nh
+        Lp = (L + XATTN_PAD - 1) // XATTN_PAD * XATTN_PAD
+        if final_hidden_bf16 is None:
+            final_hidden_bf16 = ws.get("lt.fhb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
+            ops.cast_bf16(final_hidden.contiguous().view(B * L, H), out=final_hidden_bf16)
+        elif final_hidden_bf16.shape[0] < (B - 1) * L + Lp:
+            raise ValueError("final_hidden_bf16 needs XATTN_PAD zeroed tail rows")
+        # The cross-attention K / V projections (two chip-filling GEMMs over the LLM's final hidden states) do not depend
+        # on the decoder chain below (lane_fc -> N-Linear decoder -> post-MLP -> dec_proj -> q projection: one-workgroup
+        # launches): they go to a side stream and join before the scores.
+        main = torch.cuda.current_stream() if dev.type == "cuda" else None
+        if main is not None:
+            if self._kv_stream is None:
+                self._kv_stream = torch.cuda.Stream(device=dev)
+            self._kv_stream.wait_stream(main)
+            kv_ctx = torch.cuda.stream(self._kv_stream)
+        else:
+            kv_ctx = contextlib.nullcontext()
+        with kv_ctx:
+            # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
+            kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
+            ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
+            # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
+            # (roles of weights and activations swapped, batched over samples), so that P.V is again
+            # a K-contiguous A.W^T product
+            vT = ws.get("lt.vT", (H, B * Lp), torch.float16, dev)
+            ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
+                             sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
         e = _front if _front is not None else self.front(x)
         lane = ws.get("lt.lane", (B, C * To), torch.float32, dev)
         ops.gemm_f32(lane_polygon_emb.contiguous(), dec.lane_fc.weight, out=lane, bias=dec.lane_fc.bias)
@@ -826,23 +857,8 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.gemm_bf16(dec_tb, P.w_dp, out=proj, bias=dec.dec_proj.bias)
         q = ws.get("lt.q", (B * To, H), torch.bfloat16, dev)
         ops.gemm_bf16(proj, P.w_q, out=q, bias=P.b_q)
-        nh = dec.cross_nhead
-        dh = H // nh
-        Lp = (L + XATTN_PAD - 1) // XATTN_PAD * XATTN_PAD
-        if final_hidden_bf16 is None:
-            final_hidden_bf16 = ws.get("lt.fhb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
-            ops.cast_bf16(final_hidden.contiguous().view(B * L, H), out=final_hidden_bf16)
-        elif final_hidden_bf16.shape[0] < (B - 1) * L + Lp:
-            raise ValueError("final_hidden_bf16 needs XATTN_PAD zeroed tail rows")
-        # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
-        kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
-        ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
-        # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
-        # (roles of weights and activations swapped, batched over samples), so that P.V is again
-        # a K-contiguous A.W^T product
-        vT = ws.get("lt.vT", (H, B * Lp), torch.float16, dev)
-        ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
-                         sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
+        if main is not None:
+            main.wait_stream(self._kv_stream)
         # scores[b,h] = q_bh . k_bh^T / sqrt(dh)  (fp32), softmax -> fp16 probabilities (zero beyond L)
         S = ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev)
         ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
