@@ -377,3 +377,24 @@ def test_gemm_f32_split_k_and_strided(gpu, M, N, K):
     gw = torch.empty(M, N, device=dev)
     ops.gemm_f32_strided(gy, 1, gy.stride(0), x, 1, x.stride(0), gw, M, N, K)
     assert _rel(gw, (gy.double().T @ x.double()).float()) < 1e-6
+
+
+def test_gemm_w4_persistent_stream(gpu):
+    """More 256x256 tiles than CUs: the 4-wave kernel runs one persistent workgroup per CU that walks its tiles as one
+    K-tile stream (look-ahead continues into the next output tile).  288 tiles, uneven tiles per workgroup, 1..3 K-tiles:
+    bit-identical to the one-workgroup-per-tile 8-wave kernel."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    M, N = 4096, 4608
+    for K in (64, 192):
+        g = torch.Generator(device="cpu").manual_seed(K)
+        a = _bf(torch.randn(M, K, generator=g)).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev)
+        for kw, dt in ((dict(), torch.bfloat16), (dict(residual=res), torch.float32), (dict(silu_mul=True), torch.bfloat16)):
+            r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
+            r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=257, **kw)
+            assert torch.equal(r8, r4), (K, sorted(kw))
+        ref = a.float() @ w.float().T
+        assert _rel(ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257), ref) < 2e-6

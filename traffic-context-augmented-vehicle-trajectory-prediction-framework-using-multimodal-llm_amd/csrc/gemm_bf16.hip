@@ -46,6 +46,7 @@ struct GemmP {
   long sAo, sAi, sWo, sWi, sCo, sCi;
   int xcd_gx;  // XCD partition of the tile grid (block_to_tile)
   DropoutP drop;  // epilogue dropout (generic epilogue only)
+  int pers_tiles;  // > 0: persistent launch of the 4-wave kernel, workgroup w runs tiles w, w + gridDim.x, ... < pers_tiles
   int prio;  // wave-priority experiment: 0 none, 1 static s_setprio(1) for the upper half of the waves, 2 around MFMA clusters
 };
 
@@ -259,8 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 // minimises it (p.xcd_gx; 8 = row bands, the right choice whenever |A| >= |W|).  Inside its rectangle an
 // XCD walks 4-tile-tall super rows so that its 32 CUs work on a 4 x 8 patch at any time.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n) {
-  const int nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n, int bid, int nwg) {
   constexpr int GM = 4;
   const int gx = p.xcd_gx;
   if (gx != 8) {  // 2-D partition; the host guarantees tiles_m % gx == 0 and tiles_n % (8 / gx) == 0
@@ -282,6 +282,10 @@ __device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& 
   const int gsz = min(GM, p.tiles_m - g * GM);
   tile_m = g * GM + in_g % gsz;
   tile_n = in_g / gsz;
+}
+
+__device__ __forceinline__ void block_to_tile(const GemmP& p, int& tile_m, int& tile_n) {
+  block_to_tile(p, tile_m, tile_n, blockIdx.x, gridDim.x);
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI, bool F16, int PIPE>
@@ -711,9 +715,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
+  // Persistent form (p.pers_tiles > 0): this workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... as ONE stream of
+  // K-tiles -- the look-ahead of the pipeline (fragments of the next K-tile, DMA of the next two) simply continues into
+  // the next output tile, so its first operands arrive while this tile's epilogue runs (no per-tile prologue).
+  constexpr bool PERS_OK = !BUF && !DEEP && EPI != EPI_ROPE;  // (the RoPE instantiation fell apart into scratch with it)
+  const bool pers = PERS_OK && p.pers_tiles > 0;
+  const int total_tiles = pers ? p.pers_tiles : (int)gridDim.x;
+  int vb = blockIdx.x;
   int tile_m, tile_n;
-  block_to_tile(p, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  block_to_tile(p, tile_m, tile_n, vb, total_tiles);
+  int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // DMA sources: piece r of a K-tile is the 8-row group g = 4 r + wave (r < 8: activation rows, r >= 8:
   // weight rows).  The swizzle term of a lane does not depend on r (32-row steps), so one base per operand.
@@ -721,6 +732,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const int csw = (lane & 7) ^ (((wave & 1) * 4 + (rl >> 1)) & 7);
   const bf16_t* srcA = p.A + (long)(m0 + wave * 8 + rl) * p.lda + csw * 8;
   const bf16_t* srcW = p.W + (long)(n0 + wave * 8 + rl) * p.ldw + csw * 8;
+  // next output tile of this workgroup (persistent form): where the look-ahead continues
+  bool has_next = pers && vb + (int)gridDim.x < total_tiles;
+  int nm0 = m0, nn0 = n0;
+  const bf16_t* nxtA = srcA;
+  const bf16_t* nxtW = srcW;
+  auto locate_next = [&]() {
+    if (has_next) {
+      int tm, tn;
+      block_to_tile(p, tm, tn, vb + (int)gridDim.x, total_tiles);
+      nm0 = tm * BM;
+      nn0 = tn * BN;
+      nxtA = p.A + (long)(nm0 + wave * 8 + rl) * p.lda + csw * 8;
+      nxtW = p.W + (long)(nn0 + wave * 8 + rl) * p.ldw + csw * 8;
+    }
+  };
+  locate_next();
   const long stepA = 32 * p.lda, stepW = 32 * p.ldw;
   // second K source (LoRA: A2 = x.A_cat^T, W2 = B_ext): its 64-deep tiles follow the main ones
   constexpr bool HASK2 = EPI == EPI_ROPE;  // only the fused q|k|v projection uses it
@@ -729,15 +756,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   long stepA2 = 0, stepW2 = 0;
   const int nt1 = p.K >> 6;
   int nt = nt1;
+  auto locate_k2 = [&]() {
+    if constexpr (HASK2) {
+      if (p.K2 > 0) {
+        srcA2 = p.A2 + (long)(m0 + wave * 8 + rl) * p.lda2 + csw * 8;
+        srcW2 = p.W2 + (long)(n0 + wave * 8 + rl) * p.ldw2 + csw * 8;
+      }
+    }
+  };
   if constexpr (HASK2) {
     if (p.K2 > 0) {
-      srcA2 = p.A2 + (long)(m0 + wave * 8 + rl) * p.lda2 + csw * 8;
-      srcW2 = p.W2 + (long)(n0 + wave * 8 + rl) * p.ldw2 + csw * 8;
       stepA2 = 32 * p.lda2;
       stepW2 = 32 * p.ldw2;
       nt += p.K2 >> 6;
     }
   }
+  locate_k2();
 
   struct Src {
     const bf16_t* a;
@@ -745,6 +779,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     long sa, sw;
   };
   auto tsrc = [&](int t) -> Src {
+    if constexpr (PERS_OK) {
+      if (t >= nt && has_next) return Src{nxtA + (t - nt) * 64, nxtW + (t - nt) * 64, stepA, stepW};  // next tile's first K-tiles
+    }
     t = min(t, nt - 1);  // the last two K-tiles re-fetch the last tile into a free buffer (keeps the loop body uniform)
     if constexpr (BUF) return Src{nullptr, nullptr, (long)t * 128, 0};  // only the tile's byte offset along K
     if constexpr (HASK2) {
@@ -825,7 +862,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     const char* nbase = smem + (cur ^ 1) * TILE_BYTES;
     Src sn2;  // source of tile t+2, put together step by step in the shadow of the bare MFMAs of phase B1
     int koff2 = 0;
-    bool second2 = false;
+    bool second2 = false, into_next2 = false;
     // ---- phase A: MFMAs on F0 | load F1 (second 32-deep half of tile t) | rest of the DMA for tile t+1
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
@@ -875,15 +912,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           continue;
         }
         if (idx == 0) {
-          const int tt = min(t + 2, nt - 1);  // clamp: see tsrc
-          second2 = HASK2 && tt >= nt1;
+          into_next2 = PERS_OK && has_next && t + 2 >= nt;   // the look-ahead crosses into the next output tile
+          const int tt = into_next2 ? t + 2 - nt : min(t + 2, nt - 1);  // clamp: see tsrc
+          second2 = HASK2 && !into_next2 && tt >= nt1;
           koff2 = (second2 ? tt - nt1 : tt) * 64;
         }
         if constexpr (BUF) {
           if (idx == 3) sn2 = Src{nullptr, nullptr, (long)koff2 * 2, 0};
         } else {
-          if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
-          if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
+          if (idx == 3) sn2.a = (into_next2 ? nxtA : second2 ? srcA2 : srcA) + koff2;
+          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + koff2;
           if (idx == 9) {
             sn2.sa = second2 ? stepA2 : stepA;
             sn2.sw = second2 ? stepW2 : stepW;
@@ -922,19 +960,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   if (t + 1 < nt) { ktile(T_{}, F_{}, t); ++t; }
   ktile(F_{}, F_{}, t);
 #else
-  for (int t = 0; t < nt; ++t) ktile(T_{}, T_{}, t);
+  for (;;) {
+    for (int t = 0; t < nt; ++t) ktile(T_{}, T_{}, t);
+    // the accumulators are read by VALU next: cover the MFMA write latency the compiler cannot see behind the asm
+    if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // ... and pin every accumulator read behind those nops: an empty volatile asm that redefines the register is
+    // ordered after the s_nop asm, and the epilogue's v_accvgpr_read depends on it (without this the scheduler is
+    // free to hoist the reads above the nops -- one instantiation did, and read stale values)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
+    gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
+    if (!PERS_OK || !has_next) break;  // (uniform) non-persistent launches leave here
+    // ---- next output tile: F0 already holds its first fragments, its second K-tile is in flight
+    vb += gridDim.x;
+    m0 = nm0;
+    n0 = nn0;
+    srcA = nxtA;
+    srcW = nxtW;
+    locate_k2();
+    has_next = vb + (int)gridDim.x < total_tiles;
+    locate_next();
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(acc[i][j]));  // the zeroing stays in front of ...
+      }
+    asm volatile("s_nop 7" ::: "memory");    // ... the wait states a VALU write needs before an MFMA reads it as SrcC
+  }
 #endif
-  // the accumulators are read by VALU next: cover the MFMA write latency the compiler cannot see behind the asm
-  if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  // ... and pin every accumulator read behind those nops: an empty volatile asm that redefines the register is
-  // ordered after the s_nop asm, and the epilogue's v_accvgpr_read depends on it (without this the scheduler is
-  // free to hoist the reads above the nops -- one instantiation did, and read stale values)
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-  gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
 }
 
 template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256>
@@ -959,7 +1017,23 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
     }
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  // more tiles than CUs: one persistent workgroup per CU walking its tiles as one K-tile stream (multiple of 8 so that
+  // tile ids keep their XCD); TCAVT_GEMM_NO_PERSIST=1 launches one workgroup per tile (A/B)
+  const int tiles = p.tiles_m * p.tiles_n;
+  static const bool no_pers = getenv("TCAVT_GEMM_NO_PERSIST") != nullptr;
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n / 8 * 8;
+  }();
+  int wgs = tiles;
+  p.pers_tiles = 0;
+  // (the two-K-tile look-ahead may reach into the NEXT output tile only: at least two K-tiles per tile)
+  if (!BUF && !(DBG & 64) && EPI != EPI_ROPE && !no_pers && n_cu >= 8 && tiles > n_cu && p.K + p.K2 >= 128) {
+    p.pers_tiles = tiles;
+    wgs = n_cu;
+  }
+  dim3 grid(wgs), block(256);
   hipLaunchKernelGGL(kfn, grid, block, lds, stream, p);
   TCAVT_CHECK_LAUNCH("gemm_bf16(w4)");
   return TCAVT_OK;
@@ -1144,6 +1218,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;
   p.tiles_m = p.tiles_n = 0;
   p.prio = 0;
+  p.pers_tiles = 0;
   p.xcd_gx = 8;
   TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "gemm_bf16: dropout_p must be in [0, 1)");
   if (a->dropout_p > 0.f)
