@@ -99,7 +99,14 @@ __global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __r
   const int kv_tiles = (kv_len + 31) >> 5;
   const int kswz = (r >> 1) & 7;
 
-  for (int qb = qb0; qb < nqb; qb += 2) {
+  // Query blocks are dealt to the two waves of a head in PAIRS (k, nqb-1-k): a short causal block with a long one,
+  // every pair costs nqb + 1 key tiles, wave parity p takes pairs p, p + 2, ...  (8 blocks: {0,7,2,5} and {1,6,3,4},
+  // 18 key tiles each, instead of 16 / 20 with alternating blocks).
+  const int npair = (nqb + 1) >> 1;
+  for (int pr = qb0; pr < npair; pr += 2)
+  for (int mem = 0; mem < 2; ++mem) {
+    const int qb = mem ? nqb - 1 - pr : pr;
+    if (mem && qb == pr) break;  // odd block count: the middle block is its own pair
     const int qi = qb * 32 + r;  // this lane's query row
     const int qrow = min(qi, L - 1);
     bf16x8 qf[4];
@@ -123,30 +130,52 @@ __global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __r
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + hh) ^ kswz) << 4));
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
       }
-      // scale + mask + tile max
+      // scale + mask + tile max.  Only the diagonal tile and a tile that straddles kv_len need per-element masks
+      // (wave-uniform test); every other tile is all-valid for all 32 queries of the block.
       float p[16];
       float tmax = -1e30f;
+      const bool full = (kt < qb) && (kt * 32 + 32 <= kv_len);
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int kk = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const bool ok = (kk <= qi) && (kk < kv_len);
-        p[i] = ok ? sacc[i] * scale_log2e : -1e30f;
-        tmax = fmaxf(tmax, p[i]);
+        for (int i = 0; i < 16; ++i) {
+          p[i] = sacc[i] * scale_log2e;
+          tmax = fmaxf(tmax, p[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kk = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          const bool ok = (kk <= qi) && (kk < kv_len);
+          p[i] = ok ? sacc[i] * scale_log2e : -1e30f;
+          tmax = fmaxf(tmax, p[i]);
+        }
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float mnew = fmaxf(mrun, tmax);
       const float alpha = exp2f(mrun - mnew);
       float psum = 0.f;
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        p[i] = (p[i] > -1e29f) ? exp2f(p[i] - mnew) : 0.f;
-        psum += p[i];
+        for (int i = 0; i < 16; ++i) {
+          p[i] = exp2f(p[i] - mnew);
+          psum += p[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          p[i] = (p[i] > -1e29f) ? exp2f(p[i] - mnew) : 0.f;
+          psum += p[i];
+        }
       }
       psum += __shfl_xor(psum, 32, 64);
       lrun = lrun * alpha + psum;
       mrun = mnew;
+      // rescale the running output only when some query's maximum moved (wave-uniform; x 1.0f is exact, so skipping
+      // it changes nothing): after the first tiles of a block the maxima rarely move
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+      }
       // O^T += V^T . P^T  (two 16-key k-steps; P registers 8*s2.. are the B operand)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
