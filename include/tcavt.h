@@ -96,7 +96,13 @@ typedef struct tcavt_gemm_args {
   int32_t out_dtype;             /* TCAVT_F32 | TCAVT_BF16 */
   int32_t epilogue;              /* TCAVT_EPI_* flags */
   int32_t rope_L, rope_cols;
-  int32_t tile;                  /* 0 = auto, 128 or 256 = force square tile */
+  int32_t tile;                  /* 0 = auto (recommended).  Forcing a kernel form (all forms give bit-identical results):
+                                    64 / 128 = small-launch kernels (4-stage pipeline), 256 = 8-wave 256x256,
+                                    257 = 4-wave 256x256 (whole tiles only), 271 = 4-wave 256x192 (N % 192 == 0),
+                                    272 = 4-wave two-barrier deep-prefetch form (long K); other codes in [124,127] and
+                                    [250,270] are measured-and-rejected variants kept for A/B runs (csrc/gemm_bf16.hip);
+                                    261-267 are timing-only experiments and are refused unless
+                                    TCAVT_GEMM_TIMING_EXPERIMENTS is set */
   float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */
   int32_t in_dtype;              /* operand type of A/W/A2/W2: 0 or TCAVT_BF16, or TCAVT_F16 (generic epilogue only) */
   /* Batched form (generic epilogue only): batch > 1 runs `batch` independent products; product i uses

@@ -1,5 +1,6 @@
 """Timing-only elimination experiments on the 4-wave gate|up GEMM (codes 261-267 give wrong results by design)."""
 import os, sys
+os.environ["TCAVT_GEMM_TIMING_EXPERIMENTS"] = "1"  # codes 261-267 refuse to run without it
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tcavt_amd import capi, ops

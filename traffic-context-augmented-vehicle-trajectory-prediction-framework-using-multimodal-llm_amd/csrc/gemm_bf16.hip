@@ -1124,7 +1124,17 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
       }
       set_error("gemm_bf16: tile %d (4-wave kernel) needs bf16 operands, whole 256x256 tiles, one K source, no batch", tile);
       return TCAVT_ERR_ARG;
-    case 261: case 262: case 263: case 264: case 265: case 267:  // timing experiments (wrong results)
+    case 261: case 262: case 263: case 264: case 265: case 267: {  // timing experiments (wrong results)
+      static const bool allow = getenv("TCAVT_GEMM_TIMING_EXPERIMENTS") != nullptr;
+      if (!allow) {
+        set_error("gemm_bf16: tile codes 261-267 are timing-only elimination experiments that compute WRONG results; "
+                  "set TCAVT_GEMM_TIMING_EXPERIMENTS=1 to run them (tools/ab_w4_dbg.py)");
+        return TCAVT_ERR_ARG;
+      }
+      if (!(q.M % 256 == 0 && q.N % 256 == 0 && batch == 1 && q.K2 == 0)) {
+        set_error("gemm_bf16: timing experiments need whole 256x256 tiles");
+        return TCAVT_ERR_ARG;
+      }
       if constexpr (!F16 && EPI == EPI_SILU) {
         if (tile == 261) return launch_w4<EPI, 2, 1>(q, stream);
         if (tile == 262) return launch_w4<EPI, 2, 2>(q, stream);
@@ -1133,8 +1143,9 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
         if (tile == 265) return launch_w4<EPI, 2, 8>(q, stream);
         return launch_w4<EPI, 2, 7>(q, stream);
       }
-      set_error("gemm_bf16: tile 257 (4-wave kernel) needs bf16 operands, whole 256x256 tiles, one K source, no batch");
+      set_error("gemm_bf16: the timing experiments exist for the SiLU epilogue only");
       return TCAVT_ERR_ARG;
+    }
     case 127: q.prio = 2; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
     case 126: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
     case 125: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
