@@ -178,7 +178,8 @@ def main():
     W = make_weights(cfg, seed=1, backend="torch", device=dev)
     m.load_weights(W)
     del W
-    dropout_on = args.mode == "train" and not args.no_dropout
+    # (a captured graph would replay ONE set of dropout masks: seeds are kernel arguments -> graph mode runs eval arithmetic)
+    dropout_on = args.mode == "train" and not args.no_dropout and args.launch != "graph"
     m.train(dropout_on)
     m.mllm.llama_wrapper.gemm_tile = args.tile
     torch.cuda.empty_cache()
