@@ -328,3 +328,40 @@ def test_prefetch_is_transparent_in_train_mode(gpu):
     b1 = fwd()
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
     assert m.mllm._pf is None                # consumed (a miss would have recomputed and also passed)
+
+
+@pytest.mark.parametrize("case", ["b1", "one_token", "all_padding", "no_polygons", "max_polygon"])
+def test_edge_case_batches_match_oracle(gpu, case):
+    """Degenerate batches the reference's collate can produce (train.py:301-347): a single sample, a one-token prompt,
+    text that is padding only (the 16 image tokens are then the only keys), polygons that are all empty (zero embedding,
+    train.py:378-380) or all at the maximum of 64 points.  HIP path vs the oracle on the same inputs."""
+    from oracle import forward as O
+    from tcavt_amd import synth
+
+    cfg, weights, _ = load_case("tiny_6_12_lora_ragged")
+    B, Lt = (1, 24) if case == "b1" else (3, 1) if case == "one_token" else (3, 24)
+    b = synth.make_batch(cfg, B, text_len=Lt, seed=7, ragged=(case not in ("one_token",)), min_text=1)
+    if case == "all_padding":
+        b["attention_mask"][:] = 0
+    if case == "no_polygons":
+        b["lane_polygon_len"][:] = 0
+    if case == "max_polygon":
+        b["lane_polygon_len"][:] = b["lane_polygon"].shape[1]
+    t = {k: torch.from_numpy(v) for k, v in b.items()}
+    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"])
+    ex = {}
+    with torch.no_grad():
+        loss_o, dec_o = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
+                                        t["lane_polygon_len"], t["input_ids"], t["attention_mask"], y=t["target_traj"],
+                                        norm_stat=t["norm_stat"], contract="bf16", extras=ex)
+        _, dec_f = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
+                                   t["lane_polygon_len"], t["input_ids"], t["attention_mask"], y=t["target_traj"],
+                                   norm_stat=t["norm_stat"], contract="fp32")
+    assert torch.isfinite(decoded).all() and torch.isfinite(loss)
+    assert rel_err(m.last.poly_emb.cpu(), ex["poly_emb"]) < 1e-4
+    if case == "no_polygons":
+        assert (m.last.poly_emb == 0).all()
+    o_dec = rel_err(dec_o, dec_f)  # the bf16 contract's own distance from fp32
+    assert rel_err(decoded.cpu(), dec_f) <= 1.5 * o_dec + 1e-3
+    assert rel_err(decoded.cpu(), dec_o) <= 1.5 * o_dec + 1e-3
+    assert abs(loss.item() - loss_o.item()) <= 1e-2 * abs(loss_o.item())
