@@ -190,10 +190,11 @@ def main():
 
     trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4) if args.mode == "train" else None
 
-    def step():
+    def step(next_vision=None):
         if trainer is not None:
             return trainer.step(g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"],
-                                g["target_traj"], g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"])
+                                g["target_traj"], g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"],
+                                next_vision_embs=next_vision)
         return m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], y=g["target_traj"],
                  norm_stat=g["norm_stat"], input_ids=g["input_ids"], attention_mask=g["attention_mask"],
                  labels=g["labels"])
@@ -226,9 +227,12 @@ def main():
             if graph is not None:
                 graph.replay()
             else:
-                step()
-                if prefetch:  # batch i+1's Q-Former goes to a side stream and runs under step i's decoder
-                    m.prefetch(g["vision_emb"])
+                if trainer is not None:  # batch i+1's Q-Former goes to a side stream and runs under step i's decoder
+                    step(g["vision_emb"] if prefetch else None)
+                else:
+                    step()
+                    if prefetch:
+                        m.prefetch(g["vision_emb"])
 
         log("graph captured" if graph is not None else "eager mode")
         for _ in range(args.warmup):

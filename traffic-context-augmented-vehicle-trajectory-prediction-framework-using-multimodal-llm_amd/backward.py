@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import ops
+from . import ops, streams
 from .model import XATTN_PAD
 
 
@@ -91,9 +91,9 @@ class Backward:
     def _ensure_streams(self):
         if self._multi() and self._leaf_streams is None:
             dev = self.book.grads.device
-            n = int(os.environ.get("TCAVT_BW_LEAF_STREAMS", "2"))
-            self._leaf_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n))]
-            self._poly_stream = torch.cuda.Stream(device=dev)
+            # shared pool (streams.py): more streams than hardware queues would serialise behind one another
+            self._leaf_streams = [streams.side_stream(dev, 4), streams.side_stream(dev, 5)]  # = slots 1, 2 of a pool of 3
+            self._poly_stream = streams.side_stream(dev, 3)  # = slot 0
 
     def _leaf(self, pin=None):
         """Context for leaf work (weight / bias gradients): a leaf stream, behind the current stream's queue.

@@ -23,7 +23,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .config import LlamaShape, ModelConfig
 from .layout import interleave_gate_up
 from .rope import rope_tables
@@ -596,7 +596,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         if vision_embs.device.type != "cuda" or (self.training and dctx is None):
             return
         if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=vision_embs.device)
+            self._pf_stream = streams.side_stream(vision_embs.device, 2)
         s = self._pf_stream
         if ready is not None:
             s.wait_event(ready)
@@ -820,7 +820,7 @@ class TransformerLTSF(nn.Module, _Prepared):
         main = torch.cuda.current_stream() if dev.type == "cuda" else None
         if main is not None:
             if self._kv_stream is None:
-                self._kv_stream = torch.cuda.Stream(device=dev)
+                self._kv_stream = streams.side_stream(dev, 1)
             self._kv_stream.wait_stream(main)
             kv_ctx = torch.cuda.stream(self._kv_stream)
         else:
@@ -968,7 +968,7 @@ class MultiModalTrajectoryModel(nn.Module):
         main = torch.cuda.current_stream() if dev.type == "cuda" else None
         if main is not None and self.overlap_streams:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
+                self._side = streams.side_stream(dev, 0)
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 poly_emb = self.lane_polygon_encoder(lane_polygon_batch, lane_polygon_len)

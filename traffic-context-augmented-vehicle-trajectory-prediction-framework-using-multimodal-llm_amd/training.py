@@ -67,8 +67,11 @@ class Trainer:
 
     # ---- one optimisation step -----------------------------------------------------------------
     def forward_backward(self, x, vision_embs, lane_polygon_batch, lane_polygon_len, y, norm_stat, input_ids,
-                         attention_mask, labels=None):
-        """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``."""
+                         attention_mask, labels=None, next_vision_embs=None):
+        """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``.
+        next_vision_embs (optional): the next batch's vision embeddings, already resident -- its frozen Q-Former is
+        enqueued on a side stream between this step's forward and backward (model.prefetch) and runs under this step's
+        decoder; results are identical with or without it."""
         m = self.model
         with torch.no_grad():
             self.book.grads.zero_()  # optimizer.zero_grad()
@@ -76,6 +79,8 @@ class Trainer:
                               input_ids=input_ids, attention_mask=attention_mask, labels=labels)
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat])
             ns = ns.to(device=x.device, dtype=torch.float32).contiguous()
+            if next_vision_embs is not None:
+                m.prefetch(next_vision_embs)  # before the backward: its leaf work shares the prefetch stream's queue
             B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
             fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), torch.bfloat16, x.device)
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
