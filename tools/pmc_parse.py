@@ -13,10 +13,10 @@ for d in sorted(glob.glob(sys.argv[1]+"/*/")):
     q=f"select s.kernel_name, i.name, avg(e.value), count(*) from {pc[0]} e join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id join {pi[0]} i on e.pmc_id=i.id group by s.kernel_name, i.name"
     try:
         for kn, dur, n in c.execute(f"select s.kernel_name, avg(d.end-d.start), count(*) from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name"):
-            if "gemm" in kn or "Cijk" in kn:
+            if "gemm" in kn or "Cijk" in kn or "attn" in kn:
                 res.setdefault(kn[:60],{}).setdefault("_avg_us_under_pmc", []).append(round(dur/1e3,1))
         for kn,cn,v,n in c.execute(q):
-            if "gemm" in kn or "Cijk" in kn:
+            if "gemm" in kn or "Cijk" in kn or "attn" in kn:
                 res.setdefault(kn[:60],{})[cn]=v
     except Exception as ex:
         print("ERR",d,ex)
