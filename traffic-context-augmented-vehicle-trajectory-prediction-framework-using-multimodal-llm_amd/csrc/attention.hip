@@ -136,10 +136,27 @@ __global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __r
       float tmax = -1e30f;
       const bool full = (kt < qb) && (kt * 32 + 32 <= kv_len);
       if (full) {
+        // all 32 x 32 scores valid: running maximum over the RAW scores (the scale is positive), scale folded into the
+        // exponent's fma -> max3 / fma / exp2 / add per score instead of mul / max / sub / exp2 / add
+        float rmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) rmax = fmaxf(fmaxf(rmax, sacc[i]), sacc[i + 1]);
+        rmax = fmaxf(rmax, sacc[15]);
+        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+        const float mnew = fmaxf(mrun, rmax * scale_log2e);
+        const float alpha = exp2f(mrun - mnew);
+        float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          p[i] = sacc[i] * scale_log2e;
-          tmax = fmaxf(tmax, p[i]);
+          p[i] = exp2f(fmaf(sacc[i], scale_log2e, -mnew));
+          psum += p[i];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
         }
       } else {
 #pragma unroll
@@ -150,31 +167,24 @@ __global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __r
           tmax = fmaxf(tmax, p[i]);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mnew = fmaxf(mrun, tmax);
-      const float alpha = exp2f(mrun - mnew);
-      float psum = 0.f;
-      if (full) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          p[i] = exp2f(p[i] - mnew);
-          psum += p[i];
-        }
-      } else {
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = exp2f(mrun - mnew);
+        float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           p[i] = (p[i] > -1e29f) ? exp2f(p[i] - mnew) : 0.f;
           psum += p[i];
         }
-      }
-      psum += __shfl_xor(psum, 32, 64);
-      lrun = lrun * alpha + psum;
-      mrun = mnew;
-      // rescale the running output only when some query's maximum moved (wave-uniform; x 1.0f is exact, so skipping
-      // it changes nothing): after the first tiles of a block the maxima rarely move
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+        // rescale the running output only when some query's maximum moved (wave-uniform; x 1.0f is exact, so
+        // skipping it changes nothing): after the first tiles of a block the maxima rarely move
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
       }
       // O^T += V^T . P^T  (two 16-key k-steps; P registers 8*s2.. are the B operand)
 #pragma unroll
