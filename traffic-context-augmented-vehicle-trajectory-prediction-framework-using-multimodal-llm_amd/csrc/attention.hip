@@ -47,7 +47,10 @@ __device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits
   return static_cast<unsigned int>(ha) | (static_cast<unsigned int>(hb) << 16);
 }
 
-__global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
+// MAXT = launch bound: 512 threads (GQA groups up to 4, the Llama-3.2-1B case) leaves the compiler 256 VGPRs per
+// lane -- with the 1024-thread bound (groups up to 8) the kernel is held to 128 and spills.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
                                                               bf16_t* __restrict__ out,
                                                               const int* __restrict__ kv_len_p,
                                                               int L, int Lp, int nq, int nkv,
@@ -166,7 +169,6 @@ __global__ __launch_bounds__(1024) void attn_causal_gqa_kernel(const bf16_t* __r
           p[i] = ok ? sacc[i] * scale_log2e : -1e30f;
           tmax = fmaxf(tmax, p[i]);
         }
-      }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = exp2f(mrun - mnew);
@@ -391,20 +393,27 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
   TCAVT_CHECK_ARG(aligned16(qkv) && aligned16(out), "attn_causal_gqa: unaligned pointer");
   const int Lp = (L + 31) & ~31;
   const int lds = Lp * 128 + 64 * (Lp + 4) * 2;
-  static int lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_causal_gqa_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  const int group = nq / nkv;
+  const bool small = 2 * group * 64 <= 512;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[small]) {
+    const void* fn = small ? reinterpret_cast<const void*>(attn_causal_gqa_kernel<512>)
+                           : reinterpret_cast<const void*>(attn_causal_gqa_kernel<1024>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (e != hipSuccess) {
       set_error("attn_causal_gqa: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return TCAVT_ERR_HIP;
     }
-    lds_set = 160 * 1024;
+    attr_set[small] = true;
   }
-  const int group = nq / nkv;
-  hipLaunchKernelGGL(attn_causal_gqa_kernel, dim3(B * nkv), dim3(2 * group * 64), lds,
-                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
-                     static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
+  if (small)
+    hipLaunchKernelGGL(attn_causal_gqa_kernel<512>, dim3(B * nkv), dim3(2 * group * 64), lds,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
+                       static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
+  else
+    hipLaunchKernelGGL(attn_causal_gqa_kernel<1024>, dim3(B * nkv), dim3(2 * group * 64), lds,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
+                       static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
   TCAVT_CHECK_LAUNCH("attn_causal_gqa");
   return TCAVT_OK;
 }

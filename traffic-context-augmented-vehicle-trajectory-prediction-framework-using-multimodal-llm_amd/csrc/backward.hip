@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
                                                             float* __restrict__ gq, float* __restrict__ gk,
                                                             float* __restrict__ gv, long ldg,
                                                             const int* __restrict__ key_len, int Lq, int Lk, int nh,
-                                                            int dh, float scale, DropoutP drop, int staged) {
+                                                            int dh, float scale, DropoutP drop) {
   // With attention-weight dropout (train mode): the forward used P' = P o m / (1 - p) in P' V, m drawn from
   // (seed, site, ((b nh + h) Lq + i) Lk + j) exactly as tcavt_mha does.  Then dV = P'^T dO, dP = (dO V^T) o m / (1 - p),
   // dS = P o (dP - sum_j P_j dP_j): the softmax backward needs the UN-dropped P, which is recomputed here anyway.
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
   float* dS = sm + Lq * Lk;  // [Lq][Lk]
   const int b = blockIdx.x / nh, h = blockIdx.x % nh;
   const int klen = key_len ? min(key_len[b], Lk) : Lk;
-  const float* qb = q + (long)b * Lq * ldq + h * dh;  // (re-pointed at the LDS copies when staged)
+  const float* qb = q + (long)b * Lq * ldq + h * dh;
   const float* kb = k + (long)b * Lk * ldk + h * dh;
   const float* vb = v + (long)b * Lk * ldv_ + h * dh;
   const float* gob = go + (long)b * Lq * ldo + h * dh;
@@ -168,29 +168,6 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
   float* gkb = gk + (long)b * Lk * ldg + h * dh;
   float* gvb = gv + (long)b * Lk * ldg + h * dh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // staged != 0: q, k, v, dO of this (sample, head) are copied to LDS first (rows padded to dh + 1 floats); every
-  // element is re-read Lq or Lk times below, and from global memory those loops were pure load latency
-  // (64 x 64 x 16 lane-polygon heads: 75 us -> ~15 us)
-  if (staged) {
-    const int ldp = dh + 1;
-    float* qs = sm + 2 * Lq * Lk;
-    float* ks = qs + Lq * ldp;
-    float* vs = ks + Lk * ldp;
-    float* gs = vs + Lk * ldp;
-    for (int id = tid; id < Lq * dh; id += 256) {
-      const int i = id / dh, e = id - i * dh;
-      qs[i * ldp + e] = qb[(long)i * ldq + e];
-      gs[i * ldp + e] = gob[(long)i * ldo + e];
-    }
-    for (int id = tid; id < Lk * dh; id += 256) {
-      const int j = id / dh, e = id - j * dh;
-      ks[j * ldp + e] = kb[(long)j * ldk + e];
-      vs[j * ldp + e] = vb[(long)j * ldv_ + e];
-    }
-    __syncthreads();
-    qb = qs; kb = ks; vb = vs; gob = gs;
-    ldq = ldk = ldv_ = ldo = ldp;
-  }
   // scores and dP
   for (int ij = tid; ij < Lq * Lk; ij += 256) {
     const int i = ij / Lk, j = ij - i * Lk;
@@ -246,6 +223,116 @@ __global__ __launch_bounds__(256) void mha_small_bwd_kernel(const float* __restr
       for (int i = 0; i < Lq; ++i) {
         a = fmaf(dS[i * Lk + j], qb[(long)i * ldq + e], a);
         c = fmaf(P[i * Lk + j], gob[(long)i * ldo + e], c);
+      }
+    }
+    gkb[(long)j * ldg + e] = a;
+    gvb[(long)j * ldg + e] = c;
+  }
+}
+
+// Same computation with q, k, v, dO of the (sample, head) staged in LDS (rows padded to dh + 1 floats) and the inner
+// products unrolled so that their LDS loads are issued in batches: one workgroup of 4 waves runs alone on its CU, and
+// with one load in flight at a time the global-memory version above spent ~75 us of pure latency on a 64 x 64 x 16
+// lane-polygon head.
+__global__ __launch_bounds__(256) void mha_small_bwd_lds_kernel(const float* __restrict__ q, long ldq,
+                                                                const float* __restrict__ k, long ldk,
+                                                                const float* __restrict__ v, long ldv_,
+                                                                const float* __restrict__ go, long ldo,
+                                                                float* __restrict__ gq, float* __restrict__ gk,
+                                                                float* __restrict__ gv, long ldg,
+                                                                const int* __restrict__ key_len, int Lq, int Lk, int nh,
+                                                                int dh, float scale, DropoutP drop) {
+  extern __shared__ float sm[];
+  const int ldp = dh + 1;
+  float* P = sm;                  // [Lq][Lk]
+  float* dS = P + Lq * Lk;        // [Lq][Lk]
+  float* qs = dS + Lq * Lk;       // [Lq][ldp]
+  float* ks = qs + Lq * ldp;      // [Lk][ldp]
+  float* vs = ks + Lk * ldp;      // [Lk][ldp]
+  float* gs = vs + Lk * ldp;      // [Lq][ldp]
+  const int b = blockIdx.x / nh, h = blockIdx.x % nh;
+  const int klen = key_len ? min(key_len[b], Lk) : Lk;
+  const float* qb = q + (long)b * Lq * ldq + h * dh;
+  const float* kb = k + (long)b * Lk * ldk + h * dh;
+  const float* vb = v + (long)b * Lk * ldv_ + h * dh;
+  const float* gob = go + (long)b * Lq * ldo + h * dh;
+  float* gqb = gq + (long)b * Lq * ldg + h * dh;
+  float* gkb = gk + (long)b * Lk * ldg + h * dh;
+  float* gvb = gv + (long)b * Lk * ldg + h * dh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int id = tid; id < Lq * dh; id += 256) {
+    const int i = id / dh, e = id - i * dh;
+    qs[i * ldp + e] = qb[(long)i * ldq + e];
+    gs[i * ldp + e] = gob[(long)i * ldo + e];
+  }
+  for (int id = tid; id < Lk * dh; id += 256) {
+    const int j = id / dh, e = id - j * dh;
+    ks[j * ldp + e] = kb[(long)j * ldk + e];
+    vs[j * ldp + e] = vb[(long)j * ldv_ + e];
+  }
+  __syncthreads();
+  for (int ij = tid; ij < Lq * Lk; ij += 256) {  // scores and dP
+    const int i = ij / Lk, j = ij - i * Lk;
+    float s = 0.f, d = 0.f;
+    if (j < klen) {
+      const float* qr = qs + i * ldp;
+      const float* kr = ks + j * ldp;
+      const float* gr = gs + i * ldp;
+      const float* vr = vs + j * ldp;
+#pragma unroll 8
+      for (int e = 0; e < dh; ++e) {
+        s = fmaf(qr[e], kr[e], s);
+        d = fmaf(gr[e], vr[e], d);
+      }
+    }
+    P[ij] = j < klen ? s * scale : -1e30f;
+    dS[ij] = d;
+  }
+  __syncthreads();
+  for (int i = wave; i < Lq; i += 4) {
+    float* row = P + i * Lk;
+    float* drow = dS + i * Lk;
+    float m = -1e30f;
+    for (int j = lane; j < Lk; j += 64) m = fmaxf(m, row[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+      const float e = row[j] > -1e29f ? __expf(row[j] - m) : 0.f;
+      row[j] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    const float inv = s > 0.f ? 1.f / s : 0.f;
+    float dot = 0.f;
+    const unsigned long long base = ((unsigned long long)blockIdx.x * Lq + i) * (unsigned long long)Lk;
+    for (int j = lane; j < Lk; j += 64) {
+      row[j] *= inv;
+      if (drop.p > 0.f) drow[j] *= dropout_one(drop, base + j);
+      dot += row[j] * drow[j];
+    }
+    dot = wave_sum(dot);
+    for (int j = lane; j < Lk; j += 64) {
+      drow[j] = row[j] * (drow[j] - dot) * scale;
+      if (drop.p > 0.f) row[j] *= dropout_one(drop, base + j);  // P' for dV below
+    }
+  }
+  __syncthreads();
+  for (int id = tid; id < Lq * dh; id += 256) {  // dQ
+    const int i = id / dh, e = id - i * dh;
+    float a = 0.f;
+    const float* dr = dS + i * Lk;
+#pragma unroll 8
+    for (int j = 0; j < klen; ++j) a = fmaf(dr[j], ks[j * ldp + e], a);
+    gqb[(long)i * ldg + e] = a;
+  }
+  for (int id = tid; id < Lk * dh; id += 256) {  // dK, dV
+    const int j = id / dh, e = id - j * dh;
+    float a = 0.f, c = 0.f;
+    if (j < klen) {
+#pragma unroll 8
+      for (int i = 0; i < Lq; ++i) {
+        a = fmaf(dS[i * Lk + j], qs[i * ldp + e], a);
+        c = fmaf(P[i * Lk + j], gs[i * ldp + e], c);
       }
     }
     gkb[(long)j * ldg + e] = a;
@@ -556,9 +643,14 @@ extern "C" int tcavt_mha_bwd(const float* q, int64_t ldq, const float* k, int64_
   const long stage_bytes = 2L * (Lq + Lk) * (dh + 1) * 4;
   const int staged = lds + stage_bytes <= 64 * 1024;
   if (staged) lds += stage_bytes;
-  hipLaunchKernelGGL(mha_small_bwd_kernel, dim3(B * nh), dim3(256), lds, S_(stream), q, (long)ldq, k, (long)ldk, v,
-                     (long)ldv, go, (long)ldo, gq, gk, gv, (long)ldg, key_len, Lq, Lk, nh, dh, scale,
-                     make_dropout(dropout_p, dropout_seed, dropout_site), staged);
+  if (staged)
+    hipLaunchKernelGGL(mha_small_bwd_lds_kernel, dim3(B * nh), dim3(256), lds, S_(stream), q, (long)ldq, k, (long)ldk, v,
+                       (long)ldv, go, (long)ldo, gq, gk, gv, (long)ldg, key_len, Lq, Lk, nh, dh, scale,
+                       make_dropout(dropout_p, dropout_seed, dropout_site));
+  else
+    hipLaunchKernelGGL(mha_small_bwd_kernel, dim3(B * nh), dim3(256), lds, S_(stream), q, (long)ldq, k, (long)ldk, v,
+                       (long)ldv, go, (long)ldo, gq, gk, gv, (long)ldg, key_len, Lq, Lk, nh, dh, scale,
+                       make_dropout(dropout_p, dropout_seed, dropout_site));
   TCAVT_CHECK_LAUNCH("mha_bwd");
   return TCAVT_OK;
 }
