@@ -82,6 +82,7 @@ class Backward:
         self.pl, self.pp = prefix_ltsf, prefix_poly
         self.ws = model.ltsf._ws  # scratch for gradient activations
         self._leaf_streams, self._poly_stream, self._leaf_i = None, None, 0
+        self._v_ready = None
         self._serial = os.environ.get("TCAVT_BW_SERIAL", "") == "1"
 
     # ---- streams ---------------------------------------------------------------------------
@@ -337,9 +338,14 @@ class Backward:
         kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev)
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
         scale = 1.0 / math.sqrt(dh)
-        # v (non-transposed, bf16) is recomputed: the forward only kept v^T in fp16
-        v = self._buf("xa.v", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
-        ops.gemm_bf16(fh_b[: B * L], P.w_v, out=v, bias=P.b_v)
+        # v (non-transposed, bf16) is recomputed: the forward only kept v^T in fp16.  It depends on no gradient, so
+        # run() already started it on a side stream; here the chain only waits for it.
+        if self._v_ready is not None:
+            torch.cuda.current_stream().wait_event(self._v_ready)
+            self._v_ready = None
+            v = self._buf("xa.v", (B * L + XATTN_PAD, H), torch.bfloat16)
+        else:
+            v = self._recompute_v(B, L, H)
         # dP = dO V^T   [B*nh*To, Lp] fp32 (columns >= L are never read)
         dP = self._buf("xa.dP", (B * nh * To, Lp))
         ops.gemm_batched(g_att, v, dP, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
@@ -367,6 +373,12 @@ class Backward:
         with self._leaf(pin=0):
             g_k, g_v = self._xattn_kv_grads(g_att, dS, q, B, To, H, nh, dh, L, Lp, Tp)
         return g_q, g_k, g_v, L
+
+    def _recompute_v(self, B, L, H):
+        P = self.m.ltsf._prepared()
+        v = self._buf("xa.v", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
+        ops.gemm_bf16(self._fh_b[: B * L], P.w_v, out=v, bias=P.b_v)
+        return v
 
     def _xattn_kv_grads(self, g_att, dS, q, B, To, H, nh, dh, L, Lp, Tp):
         ws, dev = self.m.ltsf._ws, g_att.device
@@ -450,6 +462,12 @@ class Backward:
             self.polygon(g_poly)
             return
         main = torch.cuda.current_stream()
+        # the cross-attention backward needs V row-major (the forward kept only V^T): a chip-filling GEMM that depends on
+        # no gradient -> started now on a side stream, off the gradient chain
+        with _Fork(self._leaf_streams[0]):
+            self._recompute_v(B, L, fh_b.shape[1])
+            self._v_ready = torch.cuda.Event()
+            self._v_ready.record()
 
         def start_polygon(g_poly):
             with _Fork(self._poly_stream):
