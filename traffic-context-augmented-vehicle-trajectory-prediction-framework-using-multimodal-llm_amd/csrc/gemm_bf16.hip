@@ -1076,7 +1076,7 @@ static int launch_small(const GemmP& p, int tile, int batch, hipStream_t stream)
   if constexpr (EPI != EPI_ROPE) {
     // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
     // each K-tile costing a quarter of the DMA issue and MFMA time
-    if ((tile == 64 || (tile == 0 && wgs < 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
+    if ((tile == 64 || (tile == 0 && wgs <= 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
   }
   if (wgs <= 256 && !no_deep) return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
   return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
