@@ -136,3 +136,27 @@ def test_rmsnorm_fused_dropout_matches_two_pass(gpu):
         ops.dropout(xn2, ref, *spec)
         assert torch.equal(xn, xn2) and torch.equal(xd, ref)
         assert 0.05 < (xd == 0).float().mean().item() < 0.15
+
+
+def test_k_candidates_reuse_llm_prefix(gpu):
+    """with no dropout site inside the MLLM, the K MC-dropout candidates share one MLLM pass; the metrics
+    equal those of K full passes exactly (same per-module mask numbering), and it is refused when the MLLM has dropout."""
+    from tests.util import batch_tensors, load_case
+    from tcavt_amd import evaluate, model
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    with pytest.raises(ValueError):
+        evaluate.evaluate_model(m, [g], num_candidates=3, mc_dropout=True, reuse_prefix=True)
+    m.mllm.qformer.dropout_p = 0.0
+    m.mllm.llama_wrapper.lora_dropout = 0.0
+    m._fwd_count = 0
+    full = evaluate.evaluate_model(m, [g, g], num_candidates=4, mc_dropout=True)
+    m._fwd_count = 0
+    fast = evaluate.evaluate_model(m, [g, g], num_candidates=4, mc_dropout=True, reuse_prefix=True)
+    assert m._llm_cache is None and not m.training
+    for k in ("ADE", "FDE", "RMSE"):
+        assert abs(full[k] - fast[k]) <= 1e-6 * abs(full[k]), (k, full[k], fast[k])

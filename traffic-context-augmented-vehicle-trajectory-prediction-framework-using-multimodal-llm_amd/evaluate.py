@@ -89,11 +89,15 @@ def evaluate_cv(tracks, seq_len=6, out_len=30, batch_size=16, stride=6, downsamp
     return tot[0] / n, tot[1] / n, tot[2] / n, n
 
 
-def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_dropout=False):
+def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_dropout=False, reuse_prefix=False):
     """Test loop on the HIP path.  `batches` yields dicts in custom_collate_fn layout already on the GPU.
     K = 1: train.py:1274-1326; K > 1: test.py:1301-1382 (K forward passes per batch, min over K).
     mc_dropout=True runs the passes in train mode under no_grad, as test.py:1308-1309 does: the K candidates then
     differ through dropout (in-kernel Philox masks, one seed per pass).
+    reuse_prefix=True: when the MLLM has no active dropout site (``model.mllm_is_deterministic()``) its
+    pass -- 99 % of the work -- is identical for all K candidates of a batch, so it runs once and only the lane-polygon
+    encoder and the LTSF run K times; results are identical to K full passes (dropout sites are numbered per module).
+    Raises if the MLLM does have dropout: its candidates genuinely differ and must each be computed.
     Returns dict(ADE, FDE, RMSE, n) averaged over ALL ranks' samples."""
     from . import ops
 
@@ -102,22 +106,30 @@ def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_drop
     dev = next(model.parameters()).device
     sums = torch.zeros(5, dtype=torch.float32, device=dev)
     n = 0
-    with torch.no_grad():
-        for b in batches:
-            B = b["traj_emb"].shape[0]
-            preds = []
-            for _ in range(num_candidates):
-                out = model(b["traj_emb"], b["vision_emb"], None, b["lane_polygon"], b["lane_polygon_len"],
-                            input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=None)
-                preds.append(out)
-            pred = torch.stack(preds, dim=1).contiguous()  # (B, K, 2, T_out)
-            ns = b["norm_stat"]
-            ns = ns if torch.is_tensor(ns) else torch.tensor([list(t) for t in ns], dtype=torch.float32)
-            ns = ns.to(device=dev, dtype=torch.float32).contiguous()
-            ops.traj_metrics(pred, b["target_traj"].contiguous(), ns, sums, None, None, B, num_candidates,
-                             pred.shape[-1])
-            n += B
-    model.train(was_training)
+    try:
+        with torch.no_grad():
+            for b in batches:
+                B = b["traj_emb"].shape[0]
+                preds = []
+                if reuse_prefix and not model.mllm_is_deterministic():
+                    raise ValueError("reuse_prefix: the MLLM has active dropout sites (Q-Former / LoRA), its K passes differ")
+                for kc in range(num_candidates):
+                    out = model(b["traj_emb"], b["vision_emb"], None, b["lane_polygon"], b["lane_polygon_len"],
+                                input_ids=b["input_ids"], attention_mask=b["attention_mask"], labels=None)
+                    if reuse_prefix and kc == 0 and num_candidates > 1:
+                        model._llm_cache = (model.last.final_hidden, model.last.final_hidden_bf16)
+                    preds.append(out)
+                model._llm_cache = None
+                pred = torch.stack(preds, dim=1).contiguous()  # (B, K, 2, T_out)
+                ns = b["norm_stat"]
+                ns = ns if torch.is_tensor(ns) else torch.tensor([list(t) for t in ns], dtype=torch.float32)
+                ns = ns.to(device=dev, dtype=torch.float32).contiguous()
+                ops.traj_metrics(pred, b["target_traj"].contiguous(), ns, sums, None, None, B, num_candidates,
+                                 pred.shape[-1])
+                n += B
+    finally:  # also on errors: leave the caller's train/eval mode and no stale MLLM cache behind
+        model._llm_cache = None
+        model.train(was_training)
     stats = torch.cat([sums[2:5].double(), torch.tensor([float(n)], dtype=torch.float64, device=dev)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.all_reduce(stats, group=process_group)

@@ -909,6 +909,7 @@ class MultiModalTrajectoryModel(nn.Module):
                                     nhead=ltsf_nhead, dropout_rate=ltsf_dropout, cross_dim=self.llama_hidden_size,
                                     cross_nhead=2, output_feature_dim=feature_size)
         self.feature_size, self.out_len, self.seq_len = feature_size, out_len, seq_len
+        self._llm_cache = None  # (final_hidden, final_hidden_bf16) of an earlier pass on the same batch (evaluate_model)
         self.overlap_streams = True  # side stream for the LLM-independent small-kernel chains (see forward)
         self._side = None
         # Train-mode dropout (the MC-dropout K-candidate protocol, test.py:1301-1342): active when the module
@@ -945,6 +946,12 @@ class MultiModalTrajectoryModel(nn.Module):
             if isinstance(m, _Prepared):
                 m._invalidate()
 
+    def mllm_is_deterministic(self):
+        """True when a forward of the MLLM cannot depend on the dropout seed: eval mode, or no dropout site inside it
+        (Q-Former dropout 0 and no LoRA dropout).  Then the K candidates of test.py:1327-1339 share one MLLM pass."""
+        lw = self.mllm.llama_wrapper
+        return (not self.training) or (self.mllm.qformer.dropout_p == 0.0 and (not lw.use_lora or lw.lora_dropout == 0.0))
+
     def prefetch(self, vision_embs, ready=None):
         """Start the frozen Q-Former of the NEXT batch underneath the pass in flight (LlamaMultiModal.prefetch)."""
         dctx = DropoutCtx(self.dropout_seed + self._fwd_count).sub(1) if self.training else None  # the next forward's masks
@@ -977,13 +984,16 @@ class MultiModalTrajectoryModel(nn.Module):
         else:
             poly_emb = self.lane_polygon_encoder(lane_polygon_batch, lane_polygon_len)
             front = self.ltsf.front(x)
-        final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids,
-                                             attention_mask=attention_mask, labels=labels, return_bf16=True)
+        if self._llm_cache is not None:  # evaluate_model(reuse_prefix=True): the MLLM pass of an earlier candidate
+            final_hidden, final_b = self._llm_cache
+        else:
+            final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids,
+                                                 attention_mask=attention_mask, labels=labels, return_bf16=True)
         if main is not None and self.overlap_streams:
             main.wait_stream(self._side)
         decoded = self.ltsf(x, poly_emb, final_hidden, final_hidden_bf16=final_b, _fuse_last_residual=True,
                             _front=front)
-        self.last = SimpleNamespace(poly_emb=poly_emb, final_hidden=final_hidden)
+        self.last = SimpleNamespace(poly_emb=poly_emb, final_hidden=final_hidden, final_hidden_bf16=final_b)
         if y is not None and norm_stat is not None:
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat], dtype=torch.float32)
             ns = ns.to(device=dev, dtype=torch.float32).contiguous()
