@@ -224,10 +224,12 @@ class Backward:
         g_dt2 = self._buf("g_dt2", (M, C))
         self.lin_bwd_bf16("dp", dec_tb, dec.dec_proj.weight, g_proj, G[pl + "decoder.dec_proj.weight"],
                           G[pl + "decoder.dec_proj.bias"], gx=g_dt2)
-        ops.add_inplace(g_dec_t, g_dt2)
+        # total gradient of dec_t, accumulated into g_dt2 (NOT into g_dec_t: the dec_unproj bias-gradient leaf may still be
+        # reading g_dec_t on a side stream -- a buffer handed to a leaf is never written again in the same backward)
+        ops.add_inplace(g_dt2, g_dec_t)
         # dec_t [B,To,C] -> d1 [B,C,To]
         g_d1 = self._buf("g_d1", (B, C * To))
-        ops.transpose_ct(g_dec_t, g_d1, None, B, To, C)
+        ops.transpose_ct(g_dt2, g_d1, None, B, To, C)
         # post MLP: d1 = relu(d0 W0^T + b0) W3^T + b3
         d0 = fwd("dec0", (B, C * To))
         if dec.use_post_mlp:
