@@ -34,6 +34,18 @@ import torch.distributed as dist  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE = 509.8  # forward, L=256, 18->30
+
+
+def gflop_per_sample(cfg, L):
+    """Forward GFLOP per sample at fused length L (which is for L = 256, scaled by shape): dense
+    decoder GEMMs and the cross-attention K/V projections are linear in L, causal attention goes with L (L + 1) / 2."""
+    ll = cfg.llama
+    per_tok = 2.0 * ll.layers * (ll.hidden * (ll.n_q_heads + 2 * ll.n_kv_heads) * ll.head_dim + ll.n_q_heads * ll.head_dim * ll.hidden
+                                 + 3 * ll.hidden * ll.inter) / 1e9
+    lora = (2.0 * ll.layers * 2 * cfg.lora_r * (2 * ll.hidden + (ll.n_q_heads + ll.n_kv_heads) * ll.head_dim) / 1e9) if cfg.use_lora else 0.0
+    attn = 4.0 * ll.layers * ll.n_q_heads * ll.head_dim * (L * (L + 1) / 2) / 1e9
+    kv_proj = 2.0 * 2 * ll.hidden * ll.hidden / 1e9  # cross-attention K and V in-projections, per token
+    return (per_tok + lora + kv_proj) * L + attn + 1.84 + 0.05 + 0.58 + 0.07  # + Q-Former, q_proj, LTSF rest, polygon
 ATTN_MB_PER_SAMPLE = 41.9  # q,k,v in + o out, 16 layers, bf16 (SURVEY.md 8d)
 
 
@@ -313,7 +325,8 @@ def main():
                 "pipelining": ("Q-Former of batch i+1 prefetched on a side stream during step i (every timed step runs "
                                "one Q-Former pass; results identical)") if prefetch else "none",
             },
-            "achieved_model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 1),
+            "achieved_model_tflops": round(value * gflop_per_sample(cfg, L) / 1e3, 1),
+            "gflop_per_sample_forward": round(gflop_per_sample(cfg, L), 1),
             "roofline": {
                 "kernel": "gemm_bf16_w4_kernel<SILU> (256x256 tile, 4 waves x 128x128) (gate|up projection, M=%d N=%d K=%d)" % (M, 2 * ll.inter, ll.hidden),
                 "bound": "mfma", "achieved": round(gu_tflops, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
