@@ -104,19 +104,29 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("TCAVT_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(cfg, args):
-    """Oracle ("port") on the host cores: B=cpu_batch samples of the same workload, fp32."""
+def parity_batch(cfg, args):
+    from tcavt_amd import synth
+
+    b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True,
+                         min_text=128 if args.text_len > 128 else max(1, args.text_len // 2))
+    return {k: torch.from_numpy(v) for k, v in b.items()}
+
+
+def cpu_baseline(cfg, args, gpu_decoded=None, W=None):
+    """Oracle ("port") on the host cores: B=cpu_batch samples of the same workload, fp32.  With `gpu_model` (same seeded
+    weights) the HIP path's eval-mode results on those samples are also CHECKED against the oracle's at the full model
+    size: relative error of the decoded trajectories and of ADE / FDE -> "parity_full_size"."""
     from oracle import forward as O
     from tcavt_amd import synth
     from tcavt_amd.weights import make_weights
 
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: generating fp32 weights on the host ({cores} threads)")
-    W = make_weights(cfg, seed=1, backend="torch", device="cpu")
+    if W is None:
+        log(f"cpu_baseline: generating fp32 weights on the host ({cores} threads)")
+        W = make_weights(cfg, seed=1, backend="torch", device="cpu")
     log("cpu_baseline: timing the oracle")
-    b = synth.make_batch(cfg, args.cpu_batch, text_len=args.text_len, seed=1, ragged=True, min_text=128 if args.text_len > 128 else max(1, args.text_len // 2))
-    t = {k: torch.from_numpy(v) for k, v in b.items()}
+    t = parity_batch(cfg, args)
 
     train = args.mode == "train"
     if train:  # autograd over exactly the parameters train.py trains (everything outside mllm)
@@ -148,7 +158,34 @@ def cpu_baseline(cfg, args):
 
     same_work = timed(None, 3)
     faithful = timed(t["labels"], 2)
+    parity = None
+    if gpu_decoded is not None:
+        with torch.no_grad():
+            _, dec_o = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                                       t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
+                                       contract="fp32")
+            _, dec_c = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                                       t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
+                                       contract="bf16")
+        dec_g = gpu_decoded
+        mc = O.traj_metrics(dec_c, t["target_traj"], t["norm_stat"])
+        mo = O.traj_metrics(dec_o, t["target_traj"], t["norm_stat"])
+        mg = O.traj_metrics(dec_g, t["target_traj"], t["norm_stat"])
+        parity = {
+            "decoded_rel_err": round(((dec_g - dec_o).norm() / dec_o.norm()).item(), 6),
+            "ade_rel_diff": round(abs(mg["ade_sum"] - mo["ade_sum"]) / mo["ade_sum"], 6),
+            "fde_rel_diff": round(abs(mg["fde_sum"] - mo["fde_sum"]) / mo["fde_sum"], 6),
+            "bf16_contract_own_decoded_rel_err": round(((dec_c - dec_o).norm() / dec_o.norm()).item(), 6),
+            "decoded_rel_err_vs_bf16_contract": round(((dec_g - dec_c).norm() / dec_c.norm()).item(), 6),
+            "ade_rel_diff_vs_bf16_contract": round(abs(mg["ade_sum"] - mc["ade_sum"]) / mc["ade_sum"], 6),
+            "fde_rel_diff_vs_bf16_contract": round(abs(mg["fde_sum"] - mc["fde_sum"]) / mc["fde_sum"], 6),
+            "note": "HIP path (bf16 operands, eval arithmetic) vs the oracle on the cpu_baseline samples at the full model "
+                    "size; first three fields against the fp32 oracle, then the bf16-contract oracle's own distance from "
+                    "fp32 and the HIP path's distance from that contract",
+        }
+        log(f"full-size parity: {parity}")
     return {
+        "parity_full_size": parity,
         "value": round(args.cpu_batch / same_work, 4), "unit": "trajectories/sec", "cores": cores, "kind": "port",
         "sample": f"{args.cpu_batch} samples of the same workload (L={16 + args.text_len}, fp32, torch CPU ops"
                   f"{', forward + autograd backward of the trainable part' if train else ''}), "
@@ -187,9 +224,18 @@ def main():
     log(f"building {args.preset} model on {dev}")
     with torch.device(dev):
         m = model.MultiModalTrajectoryModel.from_config(cfg)
-    W = make_weights(cfg, seed=1, backend="torch", device=dev)
-    m.load_weights(W)
-    del W
+    # With the CPU baseline / full-size parity leg the weights are drawn ONCE on the host and copied to the GPU (torch's
+    # CPU and GPU generators give different streams for one seed); otherwise they are drawn on the GPU directly.
+    W_cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        log("generating fp32 weights on the host (shared by the GPU model and the CPU oracle)")
+        torch.set_num_threads(host_cores())
+        W_cpu = make_weights(cfg, seed=1, backend="torch", device="cpu")
+        m.load_weights(W_cpu)
+    else:
+        W = make_weights(cfg, seed=1, backend="torch", device=dev)
+        m.load_weights(W)
+        del W
     # (a captured graph would replay ONE set of dropout masks: seeds are kernel arguments -> graph mode runs eval arithmetic)
     dropout_on = args.mode == "train" and not args.no_dropout and args.launch != "graph"
     m.train(dropout_on)
@@ -199,6 +245,19 @@ def main():
     # rank r works on its own shard of the global batch (seeded by rank): weak scaling
     b = synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank, ragged=True, min_text=128 if args.text_len > 128 else max(1, args.text_len // 2))
     g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+
+    # full-size parity sample (checked against the oracle in the cpu_baseline leg): eval-mode output of the freshly seeded
+    # model on the cpu_baseline samples, before any optimizer step changes the weights
+    parity_dec = None
+    if not args.no_cpu_baseline and rank == 0:
+        pt = {k: v.to(dev) for k, v in parity_batch(cfg, args).items()}
+        was = m.training
+        m.eval()
+        with torch.no_grad():
+            parity_dec = m(pt["traj_emb"], pt["vision_emb"], None, pt["lane_polygon"], pt["lane_polygon_len"],
+                           input_ids=pt["input_ids"], attention_mask=pt["attention_mask"]).float().cpu()
+        m.train(was)
+        del pt
 
     trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4) if args.mode == "train" else None
 
@@ -338,7 +397,7 @@ def main():
             "setup_s": round(setup_s, 1),
         }
         if not args.no_cpu_baseline and world >= 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args) if args.gpus == 1 or world == 1 else None
+            out["cpu_baseline"] = cpu_baseline(cfg, args, gpu_decoded=parity_dec, W=W_cpu) if args.gpus == 1 or world == 1 else None
             if out["cpu_baseline"]:
                 out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
