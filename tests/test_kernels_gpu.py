@@ -398,3 +398,20 @@ def test_gemm_w4_persistent_stream(gpu):
             assert torch.equal(r8, r4), (K, sorted(kw))
         ref = a.float() @ w.float().T
         assert _rel(ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257), ref) < 2e-6
+
+
+def test_gemm_timing_experiment_codes_are_refused(gpu):
+    """Tile codes 261-267 are timing-only elimination experiments that compute wrong results: refused by the C ABI
+    unless TCAVT_GEMM_TIMING_EXPERIMENTS is set in the environment."""
+    import os
+
+    from tcavt_amd import capi, ops
+
+    if os.environ.get("TCAVT_GEMM_TIMING_EXPERIMENTS"):
+        pytest.skip("experiments explicitly enabled in this environment")
+    dev = gpu["device"]
+    a = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    for code in (261, 264, 267):
+        with pytest.raises(capi.TcavtError):
+            ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, silu_mul=True, tile=code)
