@@ -210,16 +210,21 @@ __global__ void out_head_kernel(const float* __restrict__ fused, const float* __
 
 // ---------------------------------------------------------------------------
 // De-normalise + squared error + ADE/FDE/RMSE with min over K candidates.
-// One block (64 threads = one wave) per sample; lanes over time steps.
+// ONE workgroup of 16 waves: wave w takes samples w, w + 16, ... (lanes over time steps) and keeps its five partial
+// sums in registers; the waves' partials meet in LDS and are added in wave order, then once to sums[] -- a fixed
+// summation order, so the loss and the metrics are bit-reproducible (a block per sample with float atomics was not).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void traj_metrics_kernel(const float* __restrict__ pred,
+__global__ __launch_bounds__(1024) void traj_metrics_kernel(const float* __restrict__ pred,
                                                           const float* __restrict__ gt,
                                                           const float* __restrict__ ns,
                                                           float* __restrict__ sums,
                                                           int* __restrict__ argmin,
                                                           float* __restrict__ per_sample, int B, int K,
                                                           int To) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  __shared__ float part[16][5];
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, acc4 = 0.f;
+  for (int b = wave; b < B; b += nwave) {
   const float minx = ns[b * 4], maxx = ns[b * 4 + 1], miny = ns[b * 4 + 2], maxy = ns[b * 4 + 3];
   const float rx = maxx - minx, ry = maxy - miny;
   float best_ade = 0.f, best_fde = 0.f, best_rmse = 0.f;
@@ -251,14 +256,18 @@ __global__ __launch_bounds__(64) void traj_metrics_kernel(const float* __restric
     if (k == 0 || rmse < best_rmse) { best_rmse = rmse; ir = k; }
     if (k == 0) { sx_tot = sx; sy_tot = sy; }
   }
+  acc0 += sx_tot; acc1 += sy_tot; acc2 += best_ade; acc3 += best_fde; acc4 += best_rmse;
   if (lane == 0) {
-    atomicAdd(&sums[0], sx_tot);
-    atomicAdd(&sums[1], sy_tot);
-    atomicAdd(&sums[2], best_ade);
-    atomicAdd(&sums[3], best_fde);
-    atomicAdd(&sums[4], best_rmse);
     if (argmin) { argmin[b * 3] = ia; argmin[b * 3 + 1] = ifd; argmin[b * 3 + 2] = ir; }
     if (per_sample) { per_sample[b * 3] = best_ade; per_sample[b * 3 + 1] = best_fde; per_sample[b * 3 + 2] = best_rmse; }
+  }
+  }  // samples of this wave
+  if (lane == 0) { part[wave][0] = acc0; part[wave][1] = acc1; part[wave][2] = acc2; part[wave][3] = acc3; part[wave][4] = acc4; }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    float t = 0.f;
+    for (int w = 0; w < nwave; ++w) t += part[w][threadIdx.x];
+    sums[threadIdx.x] += t;  // sums[] accumulates over calls (one call per batch), single writer
   }
 }
 
@@ -397,7 +406,7 @@ extern "C" int tcavt_traj_metrics(const float* pred, const float* gt, const floa
                                   float* sums, int32_t* argmin, float* per_sample, int B, int K, int To,
                                   tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(pred && gt && norm_stat && sums && B > 0 && K > 0 && To > 0, "traj_metrics: bad args");
-  hipLaunchKernelGGL(traj_metrics_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), pred, gt,
+  hipLaunchKernelGGL(traj_metrics_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), pred, gt,
                      norm_stat, sums, argmin, per_sample, B, K, To);
   TCAVT_CHECK_LAUNCH("traj_metrics");
   return TCAVT_OK;
