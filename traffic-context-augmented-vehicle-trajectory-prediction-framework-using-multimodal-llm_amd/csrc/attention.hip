@@ -147,11 +147,11 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
         rmax = fmaxf(rmax, sacc[15]);
         rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
         const float mnew = fmaxf(mrun, rmax * scale_log2e);
-        const float alpha = exp2f(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          p[i] = exp2f(fmaf(sacc[i], scale_log2e, -mnew));
+          p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale_log2e, -mnew));
           psum += p[i];
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);
-        const float alpha = exp2f(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float psum = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          p[i] = (p[i] > -1e29f) ? exp2f(p[i] - mnew) : 0.f;
+          p[i] = (p[i] > -1e29f) ? __builtin_amdgcn_exp2f(p[i] - mnew) : 0.f;
           psum += p[i];
         }
         psum += __shfl_xor(psum, 32, 64);
