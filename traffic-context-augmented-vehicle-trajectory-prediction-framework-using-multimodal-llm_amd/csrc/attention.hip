@@ -38,6 +38,14 @@ __device__ __forceinline__ f16x8 cvt8_f16(const float* v) {
   return o;
 }
 
+// the two half-waves' copies of x (lanes l and l ^ 32) in every lane, through v_permlane32_swap (gfx950): a register
+// permute, where __shfl_xor(x, 32) is a ds_bpermute round trip through the LDS crossbar with an lgkmcnt wait
+__device__ __forceinline__ void halves(float x, float& lo, float& hi) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  lo = __uint_as_float(r[0]);
+  hi = __uint_as_float(r[1]);
+}
+
 // two bf16 (same feature, keys r0 and r1) -> packed fp16 pair, clamped to the fp16 range
 __device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits, unsigned int k1_bits) {
   const float a = fminf(fmaxf(__uint_as_float(k0_bits << 16), -65504.f), 65504.f);
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
 #pragma unroll
         for (int i = 3; i + 1 < 16; i += 2) rmax = fmaxf(fmaxf(rmax, sacc[i]), sacc[i + 1]);
         rmax = fmaxf(rmax, sacc[15]);
-        rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+        { float a, b; halves(rmax, a, b); rmax = fmaxf(a, b); }
         const float mnew = fmaxf(mrun, rmax * scale_log2e);
         const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float psum = 0.f;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
           p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[i], scale_log2e, -mnew));
           psum += p[i];
         }
-        psum += __shfl_xor(psum, 32, 64);
+        { float a, b; halves(psum, a, b); psum = a + b; }
         lrun = lrun * alpha + psum;
         mrun = mnew;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
           p[i] = ok ? sacc[i] * scale_log2e : -1e30f;
           tmax = fmaxf(tmax, p[i]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        { float a, b; halves(tmax, a, b); tmax = fmaxf(a, b); }
         const float mnew = fmaxf(mrun, tmax);
         const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float psum = 0.f;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
           p[i] = (p[i] > -1e29f) ? __builtin_amdgcn_exp2f(p[i] - mnew) : 0.f;
           psum += p[i];
         }
-        psum += __shfl_xor(psum, 32, 64);
+        { float a, b; halves(psum, a, b); psum = a + b; }
         lrun = lrun * alpha + psum;
         mrun = mnew;
         // rescale the running output only when some query's maximum moved (wave-uniform; x 1.0f is exact, so
