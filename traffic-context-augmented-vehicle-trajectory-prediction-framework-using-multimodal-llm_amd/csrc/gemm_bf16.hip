@@ -156,18 +156,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
         for (int hh = 0; hh < TN / 4; ++hh) {
           const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
+          // (two separate bodies: merging rotated temporaries with the un-rotated accumulators in one variable made the
+          // compiler shuttle ~1000 values through v_accvgpr_write / _mov per tile)
+          if (rot) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
-            if (rot) {
+            for (int i = 0; i < 2; ++i) {
+              const f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
               const f32x4 c = *reinterpret_cast<const f32x4*>(crp + i * 16);
               const f32x4 s = *reinterpret_cast<const f32x4*>(srp + i * 16);
               const f32x4 l2 = lo * c - hi * s;
               const f32x4 h2 = hi * c + lo * s;
-              lo = l2; hi = h2;
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(l2[0], l2[1]), pack_bf16x2(l2[2], l2[3])};
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + 32 + i * 16) = u32x2{pack_bf16x2(h2[0], h2[1]), pack_bf16x2(h2[2], h2[3])};
             }
-            *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3])};
-            *reinterpret_cast<u32x2*>(crow + hh * 64 + 32 + i * 16) = u32x2{pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 v = acc[hh * 4 + i][j];
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
           }
         }
       }
