@@ -42,7 +42,7 @@ def gflop_per_sample(cfg, L):
     ll = cfg.llama
     per_tok = 2.0 * ll.layers * (ll.hidden * (ll.n_q_heads + 2 * ll.n_kv_heads) * ll.head_dim + ll.n_q_heads * ll.head_dim * ll.hidden
                                  + 3 * ll.hidden * ll.inter) / 1e9
-    lora = (2.0 * ll.layers * 2 * cfg.lora_r * (2 * ll.hidden + (ll.n_q_heads + ll.n_kv_heads) * ll.head_dim) / 1e9) if cfg.use_lora else 0.0
+    lora = (2.0 * ll.layers * cfg.lora_r * (2 * ll.hidden + (ll.n_q_heads + ll.n_kv_heads) * ll.head_dim) / 1e9) if cfg.use_lora else 0.0
     attn = 4.0 * ll.layers * ll.n_q_heads * ll.head_dim * (L * (L + 1) / 2) / 1e9
     kv_proj = 2.0 * 2 * ll.hidden * ll.hidden / 1e9  # cross-attention K and V in-projections, per token
     return (per_tok + lora + kv_proj) * L + attn + 1.84 + 0.05 + 0.58 + 0.07  # + Q-Former, q_proj, LTSF rest, polygon
