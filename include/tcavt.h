@@ -319,6 +319,22 @@ int tcavt_colsum(const void* g, int64_t ld, int dtype, float* out, int M, int N,
 int tcavt_relu_bwd(float* g, const void* y, int y_dtype, int64_t n, tcavt_stream_t stream);
 /* a[i] += b[i] */
 int tcavt_add_inplace(float* a, const float* b, int64_t n, tcavt_stream_t stream);
+/* ---- decoder-layer backward for the LoRA-trainable variant (modify_scripts/modify_train.py:512-528) ---- */
+/* d(silu(gate) * up): gu [M, 2I] bf16 in the interleaved TCAVT_EPI_SILU_MUL layout, g_act [M, I] bf16 -> g_gu [M, 2I] bf16 */
+int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
+                       tcavt_stream_t stream);
+/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32; gy (+ gy2, optional) bf16 [M, H]; gx = or += (accumulate) */
+int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
+                      float* gx, int accumulate, int M, int H, tcavt_stream_t stream);
+/* fp32 gradient of the rotated q|k|v [M, ncols] -> bf16 gradient of the projection outputs: transposed RoPE rotation on
+   the first rope_cols columns (heads of 64), plain conversion on the rest; tables as for TCAVT_EPI_ROPE ([L, 32]) */
+int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
+                        int ncols, int rope_cols, int L, tcavt_stream_t stream);
+/* backward of tcavt_attn_causal_gqa (head_dim 64, T <= 280): qkv = the forward's rotated q|k|v [B*T, (nq+2nkv)*64] bf16,
+   dO [B*T, nq*64] bf16; g32 [B*T, (nq+2nkv)*64] fp32 in the same layout, ZEROED by the caller (k/v parts are accumulated
+   with float atomics) */
+int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf16, float* g32, const int32_t* kv_len, int B, int T,
+                              int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream);
 /* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
 int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
                         float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);

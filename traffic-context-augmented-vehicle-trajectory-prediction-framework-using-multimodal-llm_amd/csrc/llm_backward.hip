@@ -1,0 +1,256 @@
+// Backward of the decoder layers for the LoRA-trainable variant (SURVEY.md 8f.1;
+// modify_scripts/modify_train.py:512-528 trains lora_A / lora_B of q_proj, v_proj while every base weight stays frozen):
+// the activation gradient walks back through all layers -- dgrad GEMMs against transposed copies of the frozen
+// weights (gemm_bf16.hip), and the pointwise / row / attention pieces here.
+// First correct form: the attention backward is a scalar-FMA kernel with the score block in LDS (no MFMA yet).
+#include "common.hpp"
+#include "philox.hpp"
+
+namespace tcavt {
+
+__device__ __forceinline__ float sigmoid_f(float g) { return __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
+
+// gu: [M, 2I] bf16 in the interleaved layout of TCAVT_EPI_SILU_MUL (blocks of 16 gate columns, then the 16 up columns
+// of the same features); g_act: [M, I] bf16 = dL/d(silu(gate) * up).  g_gu gets dL/dgate, dL/dup in the same layout.
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ g_act,
+                                                           bf16_t* __restrict__ g_gu, long M, int I) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * I) return;
+  const long row = idx / I;
+  const int f = (int)(idx - row * I);
+  const long o = row * 2 * I + (f >> 4) * 32 + (f & 15);
+  const float g = bf16_to_f32(gu[o]), u = bf16_to_f32(gu[o + 16]), d = bf16_to_f32(g_act[idx]);
+  const float s = sigmoid_f(g);
+  g_gu[o] = f32_to_bf16(d * u * s * (1.f + g * (1.f - s)));
+  g_gu[o + 16] = f32_to_bf16(d * g * s);
+}
+
+// RMSNorm backward, one wave per row:  y = x * r * gamma,  r = rsqrt(mean(x^2) + eps)
+//   gx = r * (gy*gamma) - x * r^3 * mean(gy*gamma*x)
+// gy = gy_a (+ gy_b): the LoRA branch hands in its own gradient of the same normed row.  accumulate: gx += .
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const bf16_t* __restrict__ gy_a, const bf16_t* __restrict__ gy_b,
+                                                          float eps, float* __restrict__ gx, int accumulate, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * H;
+  const bf16_t* ga = gy_a + (long)row * H;
+  const bf16_t* gb = gy_b ? gy_b + (long)row * H : nullptr;
+  float ss = 0.f, dot = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float xv = xr[c];
+    float g = bf16_to_f32(ga[c]);
+    if (gb) g += bf16_to_f32(gb[c]);
+    ss = fmaf(xv, xv, ss);
+    dot = fmaf(g * gamma[c], xv, dot);
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float r = rsqrtf(ss / (float)H + eps);
+  const float k = dot / (float)H * r * r * r;
+  float* o = gx + (long)row * H;
+  for (int c = lane; c < H; c += 64) {
+    float g = bf16_to_f32(ga[c]);
+    if (gb) g += bf16_to_f32(gb[c]);
+    const float v = r * g * gamma[c] - xr[c] * k;
+    o[c] = accumulate ? o[c] + v : v;
+  }
+}
+
+// fp32 [M, ncols] gradient of the rotated q | k | v  ->  bf16 gradient of the projections' outputs: the first
+// rope_cols columns (q and k heads, head_dim 64 each) get the transposed rotation
+//   g_t1 = g_o1 * cos + g_o2 * sin,   g_t2 = g_o2 * cos - g_o1 * sin      (forward: o1 = t1 cos - t2 sin, o2 = t2 cos + t1 sin)
+__global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const float* __restrict__ g32, bf16_t* __restrict__ out,
+                                                            const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                            long M, int ncols, int rope_cols, int L) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (row, column pair c / c + 32 of a head)
+  const int half = ncols / 2;
+  if (idx >= M * half) return;
+  const long row = idx / half;
+  const int p = (int)(idx - row * half);
+  const int head = p >> 5, w = p & 31;
+  const int c1 = head * 64 + w, c2 = c1 + 32;
+  const float a = g32[row * ncols + c1], b = g32[row * ncols + c2];
+  float o1 = a, o2 = b;
+  if (c1 < rope_cols) {
+    const int pos = (int)(row % L);
+    const float cs = cosT[pos * 32 + w], sn = sinT[pos * 32 + w];
+    o1 = a * cs + b * sn;
+    o2 = b * cs - a * sn;
+  }
+  out[row * ncols + c1] = f32_to_bf16(o1);
+  out[row * ncols + c2] = f32_to_bf16(o2);
+}
+
+// ---------------------------------------------------------------------------
+// Causal GQA attention backward, head_dim 64.  One workgroup per (sample, query head, block of QB = 32 query rows).
+//   P = softmax(scale * q K^T) over keys c < min(i + 1, kv_len[b]);   dP = dO V^T;   dS = scale * P * (dP - rowsum(P dP))
+//   dQ_i = sum_c dS_ic K_c  (written);   dK_c += sum_i dS_ic q_i,  dV_c += sum_i P_ic dO_i  (float atomics: the four
+//   query heads of a group and the query blocks all add into the same key rows).
+// q, k, v are read from the forward's rotated q|k|v buffer [B*T, (nq + 2 nkv) * 64] (bf16), dO from [B*T, nq*64] (bf16);
+// g32 is the fp32 gradient in the q|k|v layout, zeroed by the caller.
+// ---------------------------------------------------------------------------
+constexpr int AB_QB = 32, AB_HD = 64, AB_LDK = 66;  // K/V rows padded to 33 dwords (conflict-free down a column)
+
+__global__ __launch_bounds__(256) void attn_causal_gqa_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                                  float* __restrict__ g32, const int* __restrict__ kv_len,
+                                                                  int T, int nq, int nkv, float scale, int nqb) {
+  extern __shared__ float sm[];
+  const int blk = blockIdx.x;
+  const int qb = blk % nqb, h = (blk / nqb) % nq, b = blk / (nqb * nq);
+  const int j = h / (nq / nkv);
+  const int q0 = qb * AB_QB;
+  const int klen = min(kv_len[b], T);
+  const int nk = min(min(q0 + AB_QB, T), klen);  // keys any row of this block can see
+  const int nqkv = (nq + 2 * nkv) * AB_HD;
+  float* S = sm;                                   // [QB][nk]  scores -> P
+  float* D = S + AB_QB * nk;                       // [QB][nk]  dP -> dS
+  float* qs = D + AB_QB * nk;                      // [QB][65]
+  float* gs = qs + AB_QB * (AB_HD + 1);            // [QB][65]
+  bf16_t* ks = reinterpret_cast<bf16_t*>(gs + AB_QB * (AB_HD + 1));  // [nk][66]
+  bf16_t* vs = ks + (long)nk * AB_LDK;                                // [nk][66]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row0 = (long)b * T;
+  for (int id = tid; id < AB_QB * AB_HD; id += 256) {
+    const int i = id >> 6, e = id & 63;
+    const bool ok = q0 + i < T;
+    qs[i * 65 + e] = ok ? bf16_to_f32(qkv[(row0 + q0 + i) * nqkv + h * AB_HD + e]) : 0.f;
+    gs[i * 65 + e] = ok ? bf16_to_f32(dO[(row0 + q0 + i) * (long)(nq * AB_HD) + h * AB_HD + e]) : 0.f;
+  }
+  for (int id = tid; id < nk * AB_HD; id += 256) {
+    const int c = id >> 6, e = id & 63;
+    ks[c * AB_LDK + e] = qkv[(row0 + c) * nqkv + (nq + j) * AB_HD + e];
+    vs[c * AB_LDK + e] = qkv[(row0 + c) * nqkv + (nq + nkv + j) * AB_HD + e];
+  }
+  __syncthreads();
+  for (int ij = tid; ij < AB_QB * nk; ij += 256) {
+    const int i = ij / nk, c = ij - i * nk;
+    float s = -1e30f, d = 0.f;
+    if (q0 + i < T && c < min(q0 + i + 1, klen)) {
+      s = 0.f;
+      const float* qr = qs + i * 65;
+      const float* gr = gs + i * 65;
+      const unsigned int* kr = reinterpret_cast<const unsigned int*>(ks + c * AB_LDK);
+      const unsigned int* vr = reinterpret_cast<const unsigned int*>(vs + c * AB_LDK);
+#pragma unroll 8
+      for (int e2 = 0; e2 < AB_HD / 2; ++e2) {
+        const unsigned int kk = kr[e2], vv = vr[e2];
+        s = fmaf(qr[2 * e2], __uint_as_float(kk << 16), s);
+        s = fmaf(qr[2 * e2 + 1], __uint_as_float(kk & 0xffff0000u), s);
+        d = fmaf(gr[2 * e2], __uint_as_float(vv << 16), d);
+        d = fmaf(gr[2 * e2 + 1], __uint_as_float(vv & 0xffff0000u), d);
+      }
+      s *= scale;
+    }
+    S[ij] = s;
+    D[ij] = d;
+  }
+  __syncthreads();
+  for (int i = wave; i < AB_QB; i += 4) {
+    float* row = S + i * nk;
+    float* drow = D + i * nk;
+    float m = -1e30f;
+    for (int c = lane; c < nk; c += 64) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < nk; c += 64) {
+      const float e = row[c] > -1e29f ? __expf(row[c] - m) : 0.f;
+      row[c] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    float dot = 0.f;
+    for (int c = lane; c < nk; c += 64) {
+      row[c] *= inv;
+      dot = fmaf(row[c], drow[c], dot);
+    }
+    dot = wave_sum(dot);
+    for (int c = lane; c < nk; c += 64) drow[c] = row[c] * (drow[c] - dot) * scale;
+  }
+  __syncthreads();
+  for (int id = tid; id < AB_QB * AB_HD; id += 256) {  // dQ
+    const int i = id >> 6, e = id & 63;
+    if (q0 + i >= T) continue;
+    const float* dr = D + i * nk;
+    float a = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < nk; ++c) a = fmaf(dr[c], bf16_to_f32(ks[c * AB_LDK + e]), a);
+    g32[(row0 + q0 + i) * nqkv + h * AB_HD + e] = a;
+  }
+  for (int id = tid; id < nk * AB_HD; id += 256) {  // dK, dV
+    const int c = id >> 6, e = id & 63;
+    float a = 0.f, v = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < AB_QB; ++i) {
+      a = fmaf(D[i * nk + c], qs[i * 65 + e], a);
+      v = fmaf(S[i * nk + c], gs[i * 65 + e], v);
+    }
+    atomicAdd(g32 + (row0 + c) * nqkv + (nq + j) * AB_HD + e, a);
+    atomicAdd(g32 + (row0 + c) * nqkv + (nq + nkv + j) * AB_HD + e, v);
+  }
+}
+
+static size_t attn_bwd_lds(int T) {
+  return (size_t)2 * AB_QB * T * 4 + (size_t)2 * AB_QB * (AB_HD + 1) * 4 + (size_t)2 * T * AB_LDK * 2;
+}
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
+                                  tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(gu_bf16 && g_act_bf16 && g_gu_bf16 && M > 0 && I > 0 && I % 16 == 0, "silu_mul_bwd: bad args (I %% 16 == 0)");
+  const long n = (long)M * I;
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(gu_bf16), static_cast<const bf16_t*>(g_act_bf16),
+                     static_cast<bf16_t*>(g_gu_bf16), (long)M, I);
+  TCAVT_CHECK_LAUNCH("silu_mul_bwd");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
+                                 float* gx, int accumulate, int M, int H, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && gamma && gy_bf16 && gx && M > 0 && H > 0, "rmsnorm_bwd: bad args");
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
+                     static_cast<const bf16_t*>(gy_bf16), static_cast<const bf16_t*>(gy2_bf16), eps, gx, accumulate, M, H);
+  TCAVT_CHECK_LAUNCH("rmsnorm_bwd");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
+                                   int ncols, int rope_cols, int L, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(g32 && out_bf16 && rope_cos && rope_sin && M > 0 && L > 0, "rope_bwd_pack: bad args");
+  TCAVT_CHECK_ARG(ncols % 64 == 0 && rope_cols % 64 == 0 && rope_cols <= ncols, "rope_bwd_pack: columns come in heads of 64");
+  const long n = (long)M * (ncols / 2);
+  hipLaunchKernelGGL(rope_bwd_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     g32, static_cast<bf16_t*>(out_bf16), rope_cos, rope_sin, (long)M, ncols, rope_cols, L);
+  TCAVT_CHECK_LAUNCH("rope_bwd_pack");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf16, float* g32, const int32_t* kv_len, int B,
+                                         int T, int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && g32 && kv_len && B > 0 && T > 0, "attn_causal_gqa_bwd: bad args");
+  TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_causal_gqa_bwd: head_dim 64 and nq %% nkv == 0 required");
+  const size_t lds = attn_bwd_lds(T);
+  TCAVT_CHECK_ARG(lds <= 160 * 1024, "attn_causal_gqa_bwd: T=%d needs %zu bytes of LDS (limit 160 KB, T <= 280)", T, lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_causal_gqa_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      tcavt::set_error("attn_causal_gqa_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int nqb = (T + AB_QB - 1) / AB_QB;
+  hipLaunchKernelGGL(attn_causal_gqa_bwd_kernel, dim3((unsigned)(B * nq * nqb)), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16), g32, kv_len, T, nq, nkv, scale,
+                     nqb);
+  TCAVT_CHECK_LAUNCH("attn_causal_gqa_bwd");
+  return TCAVT_OK;
+}

@@ -414,6 +414,55 @@ def add_inplace(a, b):
     check(lib().tcavt_add_inplace(ptr(a), ptr(b), a.numel(), stream_ptr()), "tcavt_add_inplace")
 
 
+def silu_mul_bwd(gu, g_act, g_gu):
+    """d(silu(gate) * up) in the interleaved gate|up layout (layout.interleave_gate_up)."""
+    M, I = g_act.shape
+    for t, n, nm in ((gu, 2 * M * I, "gu"), (g_act, M * I, "g_act"), (g_gu, 2 * M * I, "g_gu")):
+        _req(t, torch.bfloat16, "silu_mul_bwd." + nm)
+        _need(t, n, "silu_mul_bwd." + nm)
+    check(lib().tcavt_silu_mul_bwd(ptr(gu), ptr(g_act), ptr(g_gu), M, I, stream_ptr()), "tcavt_silu_mul_bwd")
+
+
+def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False):
+    M, H = x.shape
+    _req(x, torch.float32, "rmsnorm_bwd.x")
+    _req(gx, torch.float32, "rmsnorm_bwd.gx")
+    _req(gamma, torch.float32, "rmsnorm_bwd.gamma")
+    _need(gamma, H, "rmsnorm_bwd.gamma")
+    _need(gx, M * H, "rmsnorm_bwd.gx")
+    for t, nm in ((gy, "gy"), (gy2, "gy2")):
+        if t is not None:
+            _req(t, torch.bfloat16, "rmsnorm_bwd." + nm)
+            _need(t, M * H, "rmsnorm_bwd." + nm)
+    check(lib().tcavt_rmsnorm_bwd(ptr(x), ptr(gamma), ptr(gy), ptr(gy2) if gy2 is not None else None, eps, ptr(gx),
+                                  int(accumulate), M, H, stream_ptr()), "tcavt_rmsnorm_bwd")
+
+
+def rope_bwd_pack(g32, out, cos, sin, rope_cols, L):
+    M, ncols = g32.shape
+    _req(g32, torch.float32, "rope_bwd_pack.g32")
+    _req(out, torch.bfloat16, "rope_bwd_pack.out")
+    _need(out, M * ncols, "rope_bwd_pack.out")
+    _need(cos, L * 32, "rope_bwd_pack.cos")
+    _need(sin, L * 32, "rope_bwd_pack.sin")
+    check(lib().tcavt_rope_bwd_pack(ptr(g32), ptr(out), ptr(cos), ptr(sin), M, ncols, rope_cols, L, stream_ptr()),
+          "tcavt_rope_bwd_pack")
+
+
+def attn_causal_gqa_bwd(qkv, dO, g32, kv_len, B, T, nq, nkv, scale):
+    """Backward of attn_causal_gqa; g32 (fp32, q|k|v layout) must be zeroed by the caller."""
+    ncols = (nq + 2 * nkv) * 64
+    _req(qkv, torch.bfloat16, "attn_causal_gqa_bwd.qkv")
+    _req(dO, torch.bfloat16, "attn_causal_gqa_bwd.dO")
+    _req(g32, torch.float32, "attn_causal_gqa_bwd.g32")
+    _need(qkv, B * T * ncols, "attn_causal_gqa_bwd.qkv")
+    _need(g32, B * T * ncols, "attn_causal_gqa_bwd.g32")
+    _need(dO, B * T * nq * 64, "attn_causal_gqa_bwd.dO")
+    _need(kv_len, B, "attn_causal_gqa_bwd.kv_len")
+    check(lib().tcavt_attn_causal_gqa_bwd(ptr(qkv), ptr(dO), ptr(g32), ptr(kv_len), B, T, nq, nkv, 64, scale,
+                                          stream_ptr()), "tcavt_attn_causal_gqa_bwd")
+
+
 def layernorm_bwd(x, gamma, gy, gx, ggamma, gbeta, eps=1e-5):
     M, D = x.shape
     for t, n, nm in ((gamma, D, "gamma"), (gy, M * D, "gy"), (gx, M * D, "gx"), (ggamma, D, "ggamma"), (gbeta, D, "gbeta")):
