@@ -1,0 +1,137 @@
+"""Backward through the frozen decoder layers for the LoRA-trainable variant.
+
+modify_scripts/modify_train.py:512-528 freezes every base weight of the LLM and leaves `lora_A` / `lora_B` of q_proj and
+v_proj trainable; the loss reaches them through the LTSF cross-attention's keys and values, i.e. through the decoder's
+final hidden states.  This module walks the activation gradient back through the layers (the decoder saved its per-layer
+residual streams, rotated q|k|v and LoRA down-projections: LlamaWithCrossAttnPEFT.save_for_backward) and produces the
+adapter gradients:
+
+    final RMSNorm  <-  g_final (bf16, two addends: through the key and through the value projection)
+    per layer, last to first:
+        down^T (dgrad GEMM)  ->  d(silu*up)  ->  gate|up^T (dgrad GEMM)  ->  RMSNorm backward        (MLP half)
+        o^T (dgrad GEMM)  ->  causal GQA attention backward  ->  RoPE^T  ->  g(q|k|v)
+        LoRA:  g_t = s * g(q|k|v) B_ext ;  dB = g(q|k|v)^T t ;  dA = g_t^T dropout(xn) ;  g_xl = mask * (g_t A_cat)
+        q|k|v^T (dgrad GEMM)  ->  RMSNorm backward                                                    (attention half)
+
+The dgrad GEMMs are the forward's MFMA kernel on transposed copies of the frozen weights (prepared_T); gate|up
+pre-activations and the normed rows are recomputed (the forward's fused SiLU epilogue never stores them).
+Layer 0's input gradient is not formed: nothing below it is trainable.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def lora_named_parameters(model):
+    """(name, parameter) of every LoRA matrix, in the order their gradients become ready (last layer first)."""
+    out = []
+    lw = model.mllm.llama_wrapper
+    pre = "mllm.llama_wrapper.llama_model.model.layers."
+    for li in reversed(range(lw.shape.layers)):
+        a = lw.llama_model.model.layers[li].self_attn
+        for proj, mod in (("q_proj", a.q_proj), ("v_proj", a.v_proj)):
+            out.append((f"{pre}{li}.self_attn.{proj}.lora_A.weight", mod.lora_A.weight))
+            out.append((f"{pre}{li}.self_attn.{proj}.lora_B.weight", mod.lora_B.weight))
+    return out
+
+
+class LoraBackward:
+    def __init__(self, model, book):
+        self.m, self.book = model, book
+        self.lw = model.mllm.llama_wrapper
+        if not self.lw.use_lora:
+            raise ValueError("LoraBackward: the model has no LoRA adapters (use_lora=False)")
+        self.ws = self.lw._ws
+
+    def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):
+        return self.ws.get("llbw." + name, shape, dtype, self.book.grads.device, zero=zero)
+
+    def _wgrad(self, tag, x, y, out):
+        """out[n, m] (fp32) = x^T y for bf16 x [M, n], y [M, m]: contraction over rows, both operands transposed
+        (rows zero-padded to a multiple of 64, the GEMM's K granule)."""
+        M, n = x.shape
+        m = y.shape[1]
+        Mp = _rup(M, 64)
+        xT = self._buf(tag + ".xT", (n, Mp))
+        yT = self._buf(tag + ".yT", (m, Mp))
+        ops.transpose16(x, xT, M, n, Mp)
+        ops.transpose16(y, yT, M, m, Mp)
+        ops.gemm_bf16(xT, yT, out=out)
+
+    def run(self, g_final_a, g_final_b=None):
+        """g_final_a (+ g_final_b): bf16 [B*L, H] gradient of the post-final-norm hidden states."""
+        lw, G = self.lw, self.book.g
+        tape = lw.tape
+        if tape is None:
+            raise RuntimeError("LoraBackward.run: no tape (set llama_wrapper.save_for_backward before the forward)")
+        ll = lw.shape
+        P, PT = lw._prepared(), lw.prepared_T()
+        B, L = tape.B, tape.L
+        M, H, I = B * L, ll.hidden, ll.inter
+        nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
+        nqkv, r = (nq + 2 * nkv) * hd, lw.lora_r
+        dev = tape.h_last.device
+        cos, sin = lw._rope_tables(L, dev)
+        s = lw.lora_alpha / lw.lora_r
+        eps = ll.rms_eps
+        pre = "mllm.llama_wrapper.llama_model.model.layers."
+
+        g_h = self._buf("g_h", (M, H), torch.float32)
+        g_hb = self._buf("g_hb", (M, H))
+        xn = self._buf("xn", (M, H))
+        xl = self._buf("xl", (M, H))
+        g_xn = self._buf("g_xn", (M, H))
+        g_xl = self._buf("g_xl", (M, H))
+        g_act = self._buf("g_act", (M, I))
+        gu = self._buf("gu", (M, 2 * I))
+        g_att = self._buf("g_att", (M, nq * hd))
+        g32 = self._buf("g32", (M, nqkv), torch.float32)
+        g_qkv = self._buf("g_qkv", (M, nqkv))
+        g_t = self._buf("g_t", (M, 64))
+        dA = self._buf("dA", (64, H), torch.float32)
+        dB = self._buf("dB", (nqkv, 64), torch.float32)
+
+        ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b)
+        for li in reversed(range(ll.layers)):
+            d, dT, sv = P.layers[li], PT[li], tape.layers[li]
+            # ---- MLP half: h_out = h_mid + (silu(gate) * up) W_d^T,  gate|up = rmsnorm(h_mid) W_gu^T
+            ops.cast_bf16(g_h, out=g_hb)
+            ops.gemm_bf16(g_hb, dT.w_d, out=g_act)
+            ops.rmsnorm(sv.h_mid, d.g2, eps, out_bf16=xn)
+            ops.gemm_bf16(xn, d.w_gu, out=gu)
+            ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its gate / up pair before writing it
+            ops.gemm_bf16(gu, dT.w_gu, out=g_xn)
+            ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True)
+            # ---- attention half: h_mid = h_in + att W_o^T
+            ops.cast_bf16(g_h, out=g_hb)
+            ops.gemm_bf16(g_hb, dT.w_o, out=g_att)
+            g32.zero_()
+            ops.attn_causal_gqa_bwd(sv.qkv, g_att, g32, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd))
+            ops.rope_bwd_pack(g32, g_qkv, cos, sin, (nq + nkv) * hd, L)
+            # ---- adapters: q|k|v += t B_ext^T,  t = bf16(s * dropout(xn) A_cat^T)
+            if sv.dspec is not None:
+                ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec)
+                x_lora = xl
+            else:
+                ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
+                x_lora = xn
+            ops.gemm_bf16(g_qkv, dT.b_ext, out=g_t, acc_scale=s)
+            self._wgrad("dB", g_qkv, sv.t, dB)
+            self._wgrad("dA", g_t, x_lora, dA)
+            p = f"{pre}{li}.self_attn."
+            G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
+            G[p + "v_proj.lora_A.weight"].copy_(dA[r:2 * r])
+            G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
+            G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, r:2 * r])
+            if li == 0:
+                break
+            ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
+            ops.dropout_(g_xl, sv.dspec)
+            ops.gemm_bf16(g_qkv, dT.w_qkv, out=g_xn)
+            ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True)

@@ -442,6 +442,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self._ws = _Workspace()
         self._prep = None
         self._rope = {}
+        # LoRA-trainable variant (modify_scripts/modify_train.py:512-528; llm_backward.LoraBackward): when True the
+        # decoder keeps, per layer, what the backward through the frozen layers needs (self.tape)
+        self.save_for_backward = False
+        self.tape = None
+        self._prep_T = None
 
     # ---- packed device-side weights -------------------------------------------------
     def _prepare(self):
@@ -471,6 +476,40 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         return SimpleNamespace(layers=layers, g_final=rnd(self.llama_model.model.norm.weight),
                                table=_bf16(self.llama_model.model.embed_tokens.weight))
 
+    def prepared_T(self):
+        """Transposed bf16 copies of the frozen weights: the `w` operands of the backward's dgrad GEMMs
+        (g_in = g_out . W  ==  gemm_bf16(g_out, W^T stored [K_in, N_out])).  Built once; refresh_lora() keeps the
+        adapter entries current."""
+        if self._prep_T is None:
+            P = self._prepared()
+            tr = lambda w: w.t().contiguous()
+            self._prep_T = [SimpleNamespace(w_qkv=tr(d.w_qkv), w_o=tr(d.w_o), w_gu=tr(d.w_gu), w_d=tr(d.w_d),
+                                            a_cat=tr(d.a_cat) if self.use_lora else None,
+                                            b_ext=tr(d.b_ext) if self.use_lora else None) for d in P.layers]
+        return self._prep_T
+
+    def _invalidate(self):
+        self._prep_T = None
+        _Prepared._invalidate(self)
+
+    def refresh_lora(self):
+        """Re-pack the adapter matrices (a_cat, b_ext and their transposes) from the lora_A / lora_B parameters after
+        an optimizer step; the frozen base weights are left alone."""
+        if not self.use_lora or self._prep is None:
+            return
+        ll, r = self.shape, self.lora_r
+        nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
+        P = self._prepared()
+        for li, lyr in enumerate(self.llama_model.model.layers):
+            a, d = lyr.self_attn, P.layers[li]
+            d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
+            d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
+            d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
+            d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
+            if self._prep_T is not None:
+                self._prep_T[li].a_cat.copy_(d.a_cat.t())
+                self._prep_T[li].b_ext.copy_(d.b_ext.t())
+
     def _rope_tables(self, L, dev):
         key = (L, str(dev))
         if key not in self._rope:
@@ -496,9 +535,24 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         tm = self.timer
         mark = (lambda n: tm.start(n)) if tm else (lambda n: None)
         done = (lambda n: tm.stop(n)) if tm else (lambda n: None)
-        for d in P.layers:
+        tape = None
+        if self.save_for_backward:
+            tape = self.tape = SimpleNamespace(layers=[], kv_len=kv_len, B=B, L=L, h_last=None)
+        for li, d in enumerate(P.layers):
             xl = xn
             dspec = _spec(self.dctx, self.lora_dropout) if self.use_lora else None
+            if tape is not None:
+                # per-layer buffers instead of the shared ones: the residual stream is written to a new buffer by each
+                # residual epilogue (no copies), q|k|v and the LoRA down-projection stay where the backward finds them
+                sv = SimpleNamespace(h_in=h, dspec=dspec,
+                                     h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
+                                     h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
+                                     qkv=ws.get(f"ll.sv.qkv{li}", (M, nqkv), torch.bfloat16, dev),
+                                     t=ws.get(f"ll.sv.t{li}", (M, 64), torch.bfloat16, dev) if self.use_lora else None)
+                tape.layers.append(sv)
+                qkv, t, h_mid, h_out = sv.qkv, sv.t, sv.h_mid, sv.h_out
+            else:
+                h_mid = h_out = h
             if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
                 xl = ws.get("ll.xn_drop", (M, H), torch.bfloat16, dev)
                 ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xl, dropout=dspec)  # both from one pass over h
@@ -517,15 +571,18 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             ops.attn_causal_gqa(qkv, att, kv_len, B, L, nq, nkv, scale)
             done("attn")
             mark("o")
-            ops.gemm_bf16(att, d.w_o, out=h, residual=h, tile=tile)
+            ops.gemm_bf16(att, d.w_o, out=h_mid, residual=h, tile=tile)
             done("o")
-            ops.rmsnorm(h, d.g2, ll.rms_eps, out_bf16=xn)
+            ops.rmsnorm(h_mid, d.g2, ll.rms_eps, out_bf16=xn)
             mark("gateup")
             ops.gemm_bf16(xn, d.w_gu, out=act, silu_mul=True, tile=tile)
             done("gateup")
             mark("down")
-            ops.gemm_bf16(act, d.w_d, out=h, residual=h, tile=tile)
+            ops.gemm_bf16(act, d.w_d, out=h_out, residual=h_mid, tile=tile)
             done("down")
+            h = h_out
+        if tape is not None:
+            tape.h_last = h
         ops.rmsnorm(h, P.g_final, ll.rms_eps, out_bf16=out_bf16, out_f32=out_f32)
 
     def forward(self, inputs_embeds, attention_mask, labels=None, output_hidden_states=False):

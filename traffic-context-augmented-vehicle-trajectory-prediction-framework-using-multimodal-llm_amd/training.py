@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 from . import ops
 from .backward import Backward, GradBook
+from .llm_backward import LoraBackward, lora_named_parameters
 
 
 def trainable_named_parameters(model):
@@ -26,19 +27,37 @@ def trainable_named_parameters(model):
 
 
 class Trainer:
-    def __init__(self, model, lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    """lora_trainable=False: scripts/train.py (whole MLLM frozen).  lora_trainable=True: the variant of
+    modify_scripts/modify_train.py:512-528,1192 -- lora_A / lora_B of q_proj, v_proj train as well (the backward walks
+    through the frozen decoder layers, llm_backward.LoraBackward) and gradients are clipped to max_grad_norm."""
+
+    def __init__(self, model, lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None,
+                 lora_trainable=False, max_grad_norm=None):
         self.model = model
         dev = next(model.parameters()).device
         named = trainable_named_parameters(model)
         for p in model.mllm.parameters():  # train.py:1141-1142
             p.requires_grad_(False)
+        self.lora_trainable = bool(lora_trainable)
+        self.max_grad_norm = max_grad_norm
+        n_frozen_variant = len(named)
+        if self.lora_trainable:
+            lora = lora_named_parameters(model)
+            for _, p in lora:
+                p.requires_grad_(True)
+            named = named + lora  # their gradients are the last to become ready
         self.book = GradBook(named, dev)
+        self.n_base = self.book.end_of(named[n_frozen_variant - 1][0])  # end of the train.py parameter set
         self.n_ltsf = self.book.end_of([n for n, _ in named if n.startswith("ltsf.")][-1])
         self.m = torch.zeros_like(self.book.params)
         self.v = torch.zeros_like(self.book.params)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.step_count = 0
         self.bw = Backward(model, self.book)
+        self.lbw = None
+        if self.lora_trainable:
+            self.lbw = LoraBackward(model, self.book)
+            model.mllm.llama_wrapper.save_for_backward = True
         model.lane_polygon_encoder.save_for_backward = True
         model.ltsf.save_for_backward = True
         self.pg = process_group
@@ -85,18 +104,50 @@ class Trainer:
             fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), torch.bfloat16, x.device)
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
                         after_ltsf=lambda: self._allreduce_bucket(0, self.n_ltsf))
-            self._allreduce_bucket(self.n_ltsf, self.book.total)
+            self._allreduce_bucket(self.n_ltsf, self.n_base)
+            if self.lbw is not None:
+                self._lora_backward(B, L)
+                self._allreduce_bucket(self.n_base, self.book.total)
             self._wait_comm()
         return loss, decoded
+
+    def _lora_backward(self, B, L):
+        """Gradient of the decoder's final hidden states = what flows back through the cross-attention's key and value
+        in-projections (k = fh W_k^T + b_k, v = fh W_v^T + b_v; the LTSF backward left dL/dk, dL/dv behind), then the
+        walk through the frozen layers."""
+        m, bw = self.model, self.bw
+        H = m.llama_hidden_size
+        ca = m.ltsf.decoder.cross_attn
+        g_k = bw._buf("xa.g_k", (B * L + 64, H), torch.bfloat16)
+        g_v = bw._buf("xa.g_v", (B * L + 64, H), torch.bfloat16)
+        gfa = bw._buf("lora.gfa", (B * L, H), torch.bfloat16)
+        gfb = bw._buf("lora.gfb", (B * L, H), torch.bfloat16)
+        for W, g, out, tag in ((ca.in_proj_weight[H:2 * H], g_k, gfa, "k"), (ca.in_proj_weight[2 * H:], g_v, gfb, "v")):
+            WT = bw._buf(f"lora.WT{tag}", (H, H), torch.bfloat16)
+            ops.transpose_f32_bf16(W.detach(), WT, H, H, H)
+            ops.gemm_bf16(g[: B * L], WT, out=out)
+        self.lbw.run(gfa, gfb)
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_(trainable, max_norm) (modify_train.py:1192) on the flat gradient vector,
+        without a host synchronisation."""
+        g = self.book.grads
+        norm = torch.linalg.vector_norm(g)
+        g.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
+        return norm
 
     def optimizer_step(self):
         m = self.model
         with torch.no_grad():
+            if self.max_grad_norm is not None:
+                self.clip_grad_norm_(self.max_grad_norm)
             self.step_count += 1
             ops.adamw(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world)
             # bf16 shadows / stacked copies of the trainable weights are stale now
             m.ltsf._invalidate()
+            if self.lora_trainable:
+                m.mllm.llama_wrapper.refresh_lora()
 
     def prefetch(self, vision_embs, ready=None):
         """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
