@@ -119,6 +119,11 @@ typedef struct tcavt_gemm_args {
   float dropout_p;
   uint32_t dropout_site;
   uint64_t dropout_seed;
+  /* Batched form, grouped operands: when > 1, W uses (i % batch_inner) / batch_w_group in place of i % batch_inner --
+   * `batch_w_group` consecutive products share one W (the query heads of a grouped-query attention group share a key /
+   * value head).  0 or 1: off. */
+  int32_t batch_w_group;
+  int32_t reserved0;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -335,6 +340,13 @@ int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos,
    with float atomics) */
 int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf16, float* g32, const int32_t* kv_len, int B, int T,
                               int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream);
+/* row-wise middle of the composed attention backward: S (scaled scores) and dP = dO V^T, fp32 [B*nq*T, Tp];
+   P = causal softmax (keys < min(i+1, kv_len[b])), dS = scale * P * (dP - sum P dP); both bf16 [.., Tp], zero-filled */
+int tcavt_causal_softmax_bwd_rows(const float* S, const float* dP, void* P_bf16, void* dS_bf16, const int32_t* kv_len,
+                                  int B, int T, int Tp, int nq, float scale, tcavt_stream_t stream);
+/* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
+int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
+                            int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);
 /* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
 int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
                         float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);

@@ -45,6 +45,7 @@ class GemmArgs(ctypes.Structure):
         ("batch", ctypes.c_int32), ("batch_inner", ctypes.c_int32),
         ("sAo", c_int64), ("sAi", c_int64), ("sWo", c_int64), ("sWi", c_int64), ("sCo", c_int64), ("sCi", c_int64),
         ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
+        ("batch_w_group", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -91,6 +92,9 @@ _SIGNATURES = {
     "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_attn_causal_gqa_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_void_p],
+    "tcavt_causal_softmax_bwd_rows": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                      c_void_p],
+    "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                       c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64,

@@ -43,6 +43,7 @@ struct GemmP {
   int tiles_m, tiles_n;
   float acc_scale;
   int batch_inner;
+  int w_group;  // >= 1: the inner batch index is divided by this for W (grouped-query heads share one W)
   long sAo, sAi, sWo, sWi, sCo, sCi;
   int xcd_gx;  // XCD partition of the tile grid (block_to_tile)
   DropoutP drop;  // epilogue dropout (generic epilogue only)
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   if (gridDim.y > 1) {  // batched form: product blockIdx.y
     const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
     p.A += bo * p.sAo + bi * p.sAi;
-    p.W += bo * p.sWo + bi * p.sWi;
+    p.W += bo * p.sWo + (bi / p.w_group) * p.sWi;
     const long co = bo * p.sCo + bi * p.sCi;
     p.C = p.out_kind == TCAVT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + co)
                                   : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + co);
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
   if (gridDim.y > 1) {
     const int bo = blockIdx.y / p.batch_inner, bi = blockIdx.y - bo * p.batch_inner;
     p.A += bo * p.sAo + bi * p.sAi;
-    p.W += bo * p.sWo + bi * p.sWi;
+    p.W += bo * p.sWo + (bi / p.w_group) * p.sWi;
     const long co = bo * p.sCo + bi * p.sCi;
     p.C = p.out_kind == TCAVT_F32 ? static_cast<void*>(reinterpret_cast<float*>(p.C) + co)
                                   : static_cast<void*>(reinterpret_cast<bf16_t*>(p.C) + co);
@@ -1231,6 +1232,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = K2;
   p.out_kind = a->out_dtype;
   p.batch_inner = batch > 1 ? a->batch_inner : 1;
+  p.w_group = a->batch_w_group > 1 ? a->batch_w_group : 1;
   p.sAo = a->sAo; p.sAi = a->sAi; p.sWo = a->sWo; p.sWi = a->sWi; p.sCo = a->sCo; p.sCi = a->sCi;
   p.flags = epi;
   p.rope_L = a->rope_L; p.rope_cols = a->rope_cols;

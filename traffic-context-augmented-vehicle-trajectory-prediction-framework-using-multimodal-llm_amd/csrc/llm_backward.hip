@@ -192,6 +192,91 @@ __global__ __launch_bounds__(256) void attn_causal_gqa_bwd_kernel(const bf16_t* 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Composed attention backward (the production path; the scalar kernel above is its cross-check): the five products run
+// on the batched MFMA GEMM, and this kernel is the row-wise middle.  Row r = (b * nq + h) * T + i of S (already scaled
+// scores, fp32 [.., Tp]) and dP = dO V^T (fp32):
+//   P = softmax(S[:nv]), nv = min(i + 1, kv_len[b]);   dS = scale * P * (dP - sum P dP)
+// both written as bf16 rows of Tp columns, zero beyond nv (the GEMMs that consume them contract over all Tp columns).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void causal_softmax_bwd_rows_kernel(const float* __restrict__ S, const float* __restrict__ dP,
+                                                                      bf16_t* __restrict__ P, bf16_t* __restrict__ dS,
+                                                                      const int* __restrict__ kv_len, int T, int Tp, int nq,
+                                                                      float scale, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int i = (int)(row % T);
+  const int b = (int)(row / ((long)T * nq));
+  const int nv = min(i + 1, min(kv_len[b], T));
+  const float* s = S + row * Tp;
+  const float* d = dP + row * Tp;
+  float m = -1e30f;
+  for (int c = lane; c < nv; c += 64) m = fmaxf(m, s[c]);
+  m = wave_max(m);
+  float sum = 0.f, dot = 0.f;
+  for (int c = lane; c < nv; c += 64) {
+    const float e = __expf(s[c] - m);
+    sum += e;
+    dot = fmaf(e, d[c], dot);
+  }
+  sum = wave_sum(sum);
+  dot = wave_sum(dot);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  dot *= inv;
+  bf16_t* po = P + row * Tp;
+  bf16_t* so = dS + row * Tp;
+  for (int c = lane; c < Tp; c += 64) {
+    float pv = 0.f, dv = 0.f;
+    if (c < nv) {
+      pv = __expf(s[c] - m) * inv;
+      dv = scale * pv * (d[c] - dot);
+    }
+    po[c] = f32_to_bf16(pv);
+    so[c] = f32_to_bf16(dv);
+  }
+}
+
+// G3 fp32 [M, 3 * nq * 64] = dQ | dK per QUERY head | dV per QUERY head  ->  bf16 [M, (nq + 2 nkv) * 64]: the query heads of
+// a group are summed into their key / value head, q and k get the transposed RoPE rotation (rope_bwd_pack_kernel).
+__global__ __launch_bounds__(256) void gqa_rope_bwd_pack_kernel(const float* __restrict__ G3, bf16_t* __restrict__ out,
+                                                                const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                                long M, int nq, int nkv, int L) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int heads = nq + 2 * nkv;
+  if (idx >= M * heads * 32) return;
+  const int w = (int)(idx & 31);
+  const int oh = (int)((idx >> 5) % heads);
+  const long row = idx / ((long)heads * 32);
+  const int grp = nq / nkv;
+  const float* g = G3 + row * (3L * nq * 64);
+  float a = 0.f, b = 0.f;
+  bool rot = true;
+  if (oh < nq) {
+    a = g[oh * 64 + w];
+    b = g[oh * 64 + w + 32];
+  } else {
+    const bool isv = oh >= nq + nkv;
+    const int j = oh - nq - (isv ? nkv : 0);
+    const float* src = g + (isv ? 2 : 1) * nq * 64 + j * grp * 64;
+    for (int q = 0; q < grp; ++q) {
+      a += src[q * 64 + w];
+      b += src[q * 64 + w + 32];
+    }
+    rot = !isv;
+  }
+  float o1 = a, o2 = b;
+  if (rot) {
+    const int pos = (int)(row % L);
+    const float cs = cosT[pos * 32 + w], sn = sinT[pos * 32 + w];
+    o1 = a * cs + b * sn;
+    o2 = b * cs - a * sn;
+  }
+  out[row * (heads * 64L) + oh * 64 + w] = f32_to_bf16(o1);
+  out[row * (heads * 64L) + oh * 64 + w + 32] = f32_to_bf16(o2);
+}
+
 static size_t attn_bwd_lds(int T) {
   return (size_t)2 * AB_QB * T * 4 + (size_t)2 * AB_QB * (AB_HD + 1) * 4 + (size_t)2 * T * AB_LDK * 2;
 }
@@ -252,5 +337,28 @@ extern "C" int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf
                      static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16), g32, kv_len, T, nq, nkv, scale,
                      nqb);
   TCAVT_CHECK_LAUNCH("attn_causal_gqa_bwd");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_causal_softmax_bwd_rows(const float* S, const float* dP, void* P_bf16, void* dS_bf16,
+                                             const int32_t* kv_len, int B, int T, int Tp, int nq, float scale,
+                                             tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(S && dP && P_bf16 && dS_bf16 && kv_len && B > 0 && T > 0 && Tp >= T && nq > 0, "causal_softmax_bwd_rows: bad args");
+  const long rows = (long)B * nq * T;
+  hipLaunchKernelGGL(causal_softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), S, dP, static_cast<bf16_t*>(P_bf16), static_cast<bf16_t*>(dS_bf16),
+                     kv_len, T, Tp, nq, scale, rows);
+  TCAVT_CHECK_LAUNCH("causal_softmax_bwd_rows");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
+                                       int nq, int nkv, int head_dim, int L, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(G3 && out_bf16 && rope_cos && rope_sin && M > 0 && L > 0, "gqa_rope_bwd_pack: bad args");
+  TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "gqa_rope_bwd_pack: head_dim 64 and nq %% nkv == 0 required");
+  const long n = (long)M * (nq + 2 * nkv) * 32;
+  hipLaunchKernelGGL(gqa_rope_bwd_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     G3, static_cast<bf16_t*>(out_bf16), rope_cos, rope_sin, (long)M, nq, nkv, L);
+  TCAVT_CHECK_LAUNCH("gqa_rope_bwd_pack");
   return TCAVT_OK;
 }

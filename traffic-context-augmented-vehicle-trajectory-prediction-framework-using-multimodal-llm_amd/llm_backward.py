@@ -41,6 +41,50 @@ def lora_named_parameters(model):
     return out
 
 
+def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv):
+    """Backward of the causal grouped-query attention as five batched MFMA products around one row kernel.
+    qkv: the forward's rotated q|k|v, bf16, rows B*T (+ >= 63 readable pad rows: the score products address keys up to
+    the next multiple of 64); dO bf16 [B*T, nq*64]; g_qkv (out) bf16 [B*T, (nq+2nkv)*64] = gradient of the
+    projections' outputs (RoPE undone).  buf(name, shape, dtype) hands out reusable scratch.
+
+        S = scale q K^T, dP = dO V^T                      per (sample, query head); the heads of a group share K / V
+        P, dS = causal softmax backward rows               (ops.causal_softmax_bwd_rows)
+        dQ = dS K,  dK_h = dS^T q,  dV_h = P^T dO          per query head; contraction over keys resp. queries
+        g(q|k|v) = RoPE^T(dQ | sum_group dK_h) | sum_group dV_h
+    """
+    hd = 64
+    Tp = _rup(T, 64)
+    nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
+    f32, b16 = torch.float32, torch.bfloat16
+    S, dP = buf("at.S", (BH * T, Tp), f32), buf("at.dP", (BH * T, Tp), f32)
+    P, dS = buf("at.P", (BH * T, Tp), b16), buf("at.dS", (BH * T, Tp), b16)
+    PT, dST = buf("at.PT", (BH * Tp, Tp), b16), buf("at.dST", (BH * Tp, Tp), b16)
+    kT = buf("at.kT", (nkv * hd, B * Tp), b16)
+    qT = buf("at.qT", (nq * hd, B * Tp), b16)
+    gT = buf("at.gT", (nq * hd, B * Tp), b16)
+    G3 = buf("at.G3", (B * T, 3 * nq * hd), f32)
+    k, v = qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:]
+    ops.gemm_batched(qkv, k, S, M=T, N=Tp, K=hd, lda=nqkv, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
+                     sA=(T * nqkv, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), acc_scale=scale, w_group=grp)
+    ops.gemm_batched(dO, v, dP, M=T, N=Tp, K=hd, lda=nq * hd, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
+                     sA=(T * nq * hd, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), w_group=grp)
+    ops.causal_softmax_bwd_rows(S, dP, P, dS, kv_len, B, T, Tp, nq, scale)
+    ops.transpose16(P, PT, T, Tp, Tp, ld_in=Tp, ld_out=Tp, batch=BH, s_in=T * Tp, s_out=Tp * Tp)
+    ops.transpose16(dS, dST, T, Tp, Tp, ld_in=Tp, ld_out=Tp, batch=BH, s_in=T * Tp, s_out=Tp * Tp)
+    ops.transpose16(k, kT, T, nkv * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
+    ops.transpose16(qkv, qT, T, nq * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
+    ops.transpose16(dO, gT, T, nq * hd, Tp, ld_in=nq * hd, ld_out=B * Tp, batch=B, s_in=T * nq * hd, s_out=Tp)
+    ld3 = 3 * nq * hd
+    ops.gemm_batched(dS, kT, G3, M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
+                     sA=(nq * T * Tp, T * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), w_group=grp)
+    ops.gemm_batched(dST, qT, G3[:, nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
+                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd))
+    ops.gemm_batched(PT, gT, G3[:, 2 * nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
+                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd))
+    ops.gqa_rope_bwd_pack(G3, g_qkv, cos, sin, nq, nkv, T)
+    return g_qkv
+
+
 class LoraBackward:
     def __init__(self, model, book):
         self.m, self.book = model, book
@@ -49,7 +93,7 @@ class LoraBackward:
             raise ValueError("LoraBackward: the model has no LoRA adapters (use_lora=False)")
         self.ws = self.lw._ws
 
-    def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):
+    def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):  # noqa: D401 (scratch from the decoder's workspace)
         return self.ws.get("llbw." + name, shape, dtype, self.book.grads.device, zero=zero)
 
     def _wgrad(self, tag, x, y, out):
@@ -91,7 +135,6 @@ class LoraBackward:
         g_act = self._buf("g_act", (M, I))
         gu = self._buf("gu", (M, 2 * I))
         g_att = self._buf("g_att", (M, nq * hd))
-        g32 = self._buf("g32", (M, nqkv), torch.float32)
         g_qkv = self._buf("g_qkv", (M, nqkv))
         g_t = self._buf("g_t", (M, 64))
         dA = self._buf("dA", (64, H), torch.float32)
@@ -111,9 +154,8 @@ class LoraBackward:
             # ---- attention half: h_mid = h_in + att W_o^T
             ops.cast_bf16(g_h, out=g_hb)
             ops.gemm_bf16(g_hb, dT.w_o, out=g_att)
-            g32.zero_()
-            ops.attn_causal_gqa_bwd(sv.qkv, g_att, g32, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd))
-            ops.rope_bwd_pack(g32, g_qkv, cos, sin, (nq + nkv) * hd, L)
+            attn_bwd_composed(self._buf, sv.qkv_padded, g_att, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd), cos, sin,
+                              g_qkv)
             # ---- adapters: q|k|v += t B_ext^T,  t = bf16(s * dropout(xn) A_cat^T)
             if sv.dspec is not None:
                 ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec)

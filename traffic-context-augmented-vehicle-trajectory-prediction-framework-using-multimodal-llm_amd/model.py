@@ -547,8 +547,9 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 sv = SimpleNamespace(h_in=h, dspec=dspec,
                                      h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
                                      h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
-                                     qkv=ws.get(f"ll.sv.qkv{li}", (M, nqkv), torch.bfloat16, dev),
+                                     qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), torch.bfloat16, dev, zero=True),
                                      t=ws.get(f"ll.sv.t{li}", (M, 64), torch.bfloat16, dev) if self.use_lora else None)
+                sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
                 qkv, t, h_mid, h_out = sv.qkv, sv.t, sv.h_mid, sv.h_out
             else:

@@ -117,7 +117,7 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: capi.F16}
 
 
 def gemm_batched(a, w, out, *, M, N, K, lda, ldw, ldc, batch, inner, sA, sW, sC, bias_row=None, acc_scale=1.0,
-                 tile=128):
+                 tile=128, w_group=1):
     """`batch` independent products C_i = A_i . W_i^T with two-level strides (outer, inner) in elements:
     product i uses a + (i // inner) * sA[0] + (i % inner) * sA[1], likewise w and out.  a/w share a
     16-bit dtype (bf16 or fp16); out may be fp32, bf16 or fp16.  See tcavt_gemm_args (include/tcavt.h)."""
@@ -129,7 +129,8 @@ def gemm_batched(a, w, out, *, M, N, K, lda, ldw, ldc, batch, inner, sA, sW, sC,
     for t, s, rows, ld, cols, nm in ((a, sA, M, lda, K, "a"), (w, sW, N, ldw, K, "w"), (out, sC, M, ldc, N, "out")):
         if not t.is_cuda and not _ALLOW_CPU:
             raise capi.TcavtError(f"gemm_batched.{nm}: tensor must live on the GPU")
-        need = (outer - 1) * s[0] + (inner - 1) * s[1] + (rows - 1) * ld + cols
+        last_inner = (inner - 1) // w_group if nm == "w" else inner - 1  # w_group products share one W
+        need = (outer - 1) * s[0] + last_inner * s[1] + (rows - 1) * ld + cols
         if _avail(t) < need:
             raise capi.TcavtError(f"gemm_batched.{nm}: buffer has {_avail(t)} elements past its pointer, needs {need}")
     args = capi.GemmArgs()
@@ -147,6 +148,7 @@ def gemm_batched(a, w, out, *, M, N, K, lda, ldw, ldc, batch, inner, sA, sW, sC,
         args.bias = bias_row.data_ptr()
         args.epilogue = capi.EPI_BIAS_ROW
     args.batch, args.batch_inner = batch, inner
+    args.batch_w_group = w_group
     args.sAo, args.sAi = sA
     args.sWo, args.sWi = sW
     args.sCo, args.sCi = sC
@@ -461,6 +463,28 @@ def attn_causal_gqa_bwd(qkv, dO, g32, kv_len, B, T, nq, nkv, scale):
     _need(kv_len, B, "attn_causal_gqa_bwd.kv_len")
     check(lib().tcavt_attn_causal_gqa_bwd(ptr(qkv), ptr(dO), ptr(g32), ptr(kv_len), B, T, nq, nkv, 64, scale,
                                           stream_ptr()), "tcavt_attn_causal_gqa_bwd")
+
+
+def causal_softmax_bwd_rows(S, dP, P, dS, kv_len, B, T, Tp, nq, scale):
+    rows = B * nq * T
+    for t, dt, nm in ((S, torch.float32, "S"), (dP, torch.float32, "dP"), (P, torch.bfloat16, "P"), (dS, torch.bfloat16, "dS")):
+        _req(t, dt, "causal_softmax_bwd_rows." + nm)
+        _need(t, rows * Tp, "causal_softmax_bwd_rows." + nm)
+    _need(kv_len, B, "causal_softmax_bwd_rows.kv_len")
+    check(lib().tcavt_causal_softmax_bwd_rows(ptr(S), ptr(dP), ptr(P), ptr(dS), ptr(kv_len), B, T, Tp, nq, scale,
+                                              stream_ptr()), "tcavt_causal_softmax_bwd_rows")
+
+
+def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
+    M = G3.shape[0]
+    _req(G3, torch.float32, "gqa_rope_bwd_pack.G3")
+    _req(out, torch.bfloat16, "gqa_rope_bwd_pack.out")
+    _need(G3, M * 3 * nq * 64, "gqa_rope_bwd_pack.G3")
+    _need(out, M * (nq + 2 * nkv) * 64, "gqa_rope_bwd_pack.out")
+    _need(cos, L * 32, "gqa_rope_bwd_pack.cos")
+    _need(sin, L * 32, "gqa_rope_bwd_pack.sin")
+    check(lib().tcavt_gqa_rope_bwd_pack(ptr(G3), ptr(out), ptr(cos), ptr(sin), M, nq, nkv, 64, L, stream_ptr()),
+          "tcavt_gqa_rope_bwd_pack")
 
 
 def layernorm_bwd(x, gamma, gy, gx, ggamma, gbeta, eps=1e-5):
