@@ -328,9 +328,10 @@ int tcavt_add_inplace(float* a, const float* b, int64_t n, tcavt_stream_t stream
 /* d(silu(gate) * up): gu [M, 2I] bf16 in the interleaved TCAVT_EPI_SILU_MUL layout, g_act [M, I] bf16 -> g_gu [M, 2I] bf16 */
 int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
                        tcavt_stream_t stream);
-/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32; gy (+ gy2, optional) bf16 [M, H]; gx = or += (accumulate) */
+/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32 (H % 8 == 0); gy (+ gy2, optional) bf16 [M, H];
+   gx = or += (accumulate); gx_bf16 (optional): a bf16 copy of the updated gx, the next dgrad GEMM's operand */
 int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
-                      float* gx, int accumulate, int M, int H, tcavt_stream_t stream);
+                      float* gx, void* gx_bf16, int accumulate, int M, int H, tcavt_stream_t stream);
 /* fp32 gradient of the rotated q|k|v [M, ncols] -> bf16 gradient of the projection outputs: transposed RoPE rotation on
    the first rope_cols columns (heads of 64), plain conversion on the rest; tables as for TCAVT_EPI_ROPE ([L, 32]) */
 int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,

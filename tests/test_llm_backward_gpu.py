@@ -46,8 +46,10 @@ def test_rmsnorm_bwd(gpu, two):
     gx = base.clone().to(dev)
     ops.rmsnorm_bwd(x.detach().to(dev), gamma.to(dev), gy.to(dev), gx, eps, gy2=gy2.to(dev) if two else None, accumulate=True)
     assert rel_err(gx.cpu() - base, x.grad) < 1e-5
-    ops.rmsnorm_bwd(x.detach().to(dev), gamma.to(dev), gy.to(dev), gx, eps, gy2=gy2.to(dev) if two else None)
+    gxb = torch.empty(M, H, dtype=torch.bfloat16, device=dev)
+    ops.rmsnorm_bwd(x.detach().to(dev), gamma.to(dev), gy.to(dev), gx, eps, gy2=gy2.to(dev) if two else None, gx_bf16=gxb)
     assert rel_err(gx.cpu(), x.grad) < 1e-5
+    assert torch.equal(gxb, gx.to(torch.bfloat16))  # the fused bf16 copy = a cast of the fp32 result
 
 
 def test_rope_bwd_pack(gpu):

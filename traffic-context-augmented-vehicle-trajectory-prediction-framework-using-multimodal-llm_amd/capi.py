@@ -88,7 +88,7 @@ _SIGNATURES = {
     "tcavt_relu_bwd": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "tcavt_add_inplace": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_silu_mul_bwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
-    "tcavt_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_attn_causal_gqa_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_void_p],

@@ -14,15 +14,33 @@ __device__ __forceinline__ float sigmoid_f(float g) { return __builtin_amdgcn_rc
 // of the same features); g_act: [M, I] bf16 = dL/d(silu(gate) * up).  g_gu gets dL/dgate, dL/dup in the same layout.
 __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ g_act,
                                                            bf16_t* __restrict__ g_gu, long M, int I) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * I) return;
-  const long row = idx / I;
-  const int f = (int)(idx - row * I);
-  const long o = row * 2 * I + (f >> 4) * 32 + (f & 15);
-  const float g = bf16_to_f32(gu[o]), u = bf16_to_f32(gu[o + 16]), d = bf16_to_f32(g_act[idx]);
-  const float s = sigmoid_f(g);
-  g_gu[o] = f32_to_bf16(d * u * s * (1.f + g * (1.f - s)));
-  g_gu[o + 16] = f32_to_bf16(d * g * s);
+  // one thread per block of 16 features: 32 B of gate, 32 B of up (adjacent), 32 B of g_act
+  const long blk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nblk = M * (I >> 4);
+  if (blk >= nblk) return;
+  const u32x4* src = reinterpret_cast<const u32x4*>(gu + blk * 32);
+  const u32x4* dsrc = reinterpret_cast<const u32x4*>(g_act + blk * 16);
+  u32x4 gv[2] = {src[0], src[1]}, uv[2] = {src[2], src[3]}, dv[2] = {dsrc[0], dsrc[1]};
+  u32x4 og[2], ou[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r[2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float g = __uint_as_float(k ? (gv[h][e] & 0xffff0000u) : (gv[h][e] << 16));
+        const float u = __uint_as_float(k ? (uv[h][e] & 0xffff0000u) : (uv[h][e] << 16));
+        const float d = __uint_as_float(k ? (dv[h][e] & 0xffff0000u) : (dv[h][e] << 16));
+        const float sg = sigmoid_f(g);
+        r[0][k] = d * u * sg * (1.f + g * (1.f - sg));
+        r[1][k] = d * g * sg;
+      }
+      og[h][e] = pack_bf16x2(r[0][0], r[0][1]);
+      ou[h][e] = pack_bf16x2(r[1][0], r[1][1]);
+    }
+  u32x4* dst = reinterpret_cast<u32x4*>(g_gu + blk * 32);
+  dst[0] = og[0]; dst[1] = og[1]; dst[2] = ou[0]; dst[3] = ou[1];
 }
 
 // RMSNorm backward, one wave per row:  y = x * r * gamma,  r = rsqrt(mean(x^2) + eps)
@@ -30,31 +48,76 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
 // gy = gy_a (+ gy_b): the LoRA branch hands in its own gradient of the same normed row.  accumulate: gx += .
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const bf16_t* __restrict__ gy_a, const bf16_t* __restrict__ gy_b,
-                                                          float eps, float* __restrict__ gx, int accumulate, int M, int H) {
+                                                          float eps, float* __restrict__ gx, bf16_t* __restrict__ gx_bf16,
+                                                          int accumulate, int M, int H) {
+  // H % 8 == 0: a lane handles 8 consecutive columns per step (2 x 16 B of x, 16 B of each gradient)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (long)row * H;
   const bf16_t* ga = gy_a + (long)row * H;
   const bf16_t* gb = gy_b ? gy_b + (long)row * H : nullptr;
+  auto load_g = [&](int c, float (&g)[8]) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(ga + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g[2 * e] = __uint_as_float(a[e] << 16);
+      g[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+    }
+    if (gb) {
+      const u32x4 b = *reinterpret_cast<const u32x4*>(gb + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        g[2 * e] += __uint_as_float(b[e] << 16);
+        g[2 * e + 1] += __uint_as_float(b[e] & 0xffff0000u);
+      }
+    }
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(gamma + c), w1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      g[e] *= w0[e];
+      g[4 + e] *= w1[e];
+    }
+  };
   float ss = 0.f, dot = 0.f;
-  for (int c = lane; c < H; c += 64) {
-    const float xv = xr[c];
-    float g = bf16_to_f32(ga[c]);
-    if (gb) g += bf16_to_f32(gb[c]);
-    ss = fmaf(xv, xv, ss);
-    dot = fmaf(g * gamma[c], xv, dot);
+  for (int c = lane * 8; c < H; c += 512) {
+    float g[8];
+    load_g(c, g);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + c), x1 = *reinterpret_cast<const f32x4*>(xr + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ss = fmaf(x0[e], x0[e], ss);
+      ss = fmaf(x1[e], x1[e], ss);
+      dot = fmaf(g[e], x0[e], dot);
+      dot = fmaf(g[4 + e], x1[e], dot);
+    }
   }
   ss = wave_sum(ss);
   dot = wave_sum(dot);
   const float r = rsqrtf(ss / (float)H + eps);
   const float k = dot / (float)H * r * r * r;
   float* o = gx + (long)row * H;
-  for (int c = lane; c < H; c += 64) {
-    float g = bf16_to_f32(ga[c]);
-    if (gb) g += bf16_to_f32(gb[c]);
-    const float v = r * g * gamma[c] - xr[c] * k;
-    o[c] = accumulate ? o[c] + v : v;
+  for (int c = lane * 8; c < H; c += 512) {
+    float g[8];
+    load_g(c, g);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + c), x1 = *reinterpret_cast<const f32x4*>(xr + c + 4);
+    f32x4 v0, v1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v0[e] = r * g[e] - x0[e] * k;
+      v1[e] = r * g[4 + e] - x1[e] * k;
+    }
+    if (accumulate) {
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(o + c), p1 = *reinterpret_cast<const f32x4*>(o + c + 4);
+      v0 += p0;
+      v1 += p1;
+    }
+    *reinterpret_cast<f32x4*>(o + c) = v0;
+    *reinterpret_cast<f32x4*>(o + c + 4) = v1;
+    if (gx_bf16) {
+      u32x4 b = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+      *reinterpret_cast<u32x4*>(gx_bf16 + (long)row * H + c) = b;
+    }
   }
 }
 
@@ -210,31 +273,49 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_rows_kernel(const floa
   const int i = (int)(row % T);
   const int b = (int)(row / ((long)T * nq));
   const int nv = min(i + 1, min(kv_len[b], T));
-  const float* s = S + row * Tp;
-  const float* d = dP + row * Tp;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(S + row * Tp);
+  const f32x4* d4 = reinterpret_cast<const f32x4*>(dP + row * Tp);
+  const int nv4 = (nv + 3) >> 2, n4 = Tp >> 2;
   float m = -1e30f;
-  for (int c = lane; c < nv; c += 64) m = fmaxf(m, s[c]);
+  for (int q = lane; q < nv4; q += 64) {
+    const f32x4 v = s4[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < nv) m = fmaxf(m, v[e]);
+  }
   m = wave_max(m);
   float sum = 0.f, dot = 0.f;
-  for (int c = lane; c < nv; c += 64) {
-    const float e = __expf(s[c] - m);
-    sum += e;
-    dot = fmaf(e, d[c], dot);
+  for (int q = lane; q < nv4; q += 64) {
+    const f32x4 v = s4[q], dd = d4[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < nv) {
+        const float ex = __expf(v[e] - m);
+        sum += ex;
+        dot = fmaf(ex, dd[e], dot);
+      }
   }
   sum = wave_sum(sum);
   dot = wave_sum(dot);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
   dot *= inv;
-  bf16_t* po = P + row * Tp;
-  bf16_t* so = dS + row * Tp;
-  for (int c = lane; c < Tp; c += 64) {
-    float pv = 0.f, dv = 0.f;
-    if (c < nv) {
-      pv = __expf(s[c] - m) * inv;
-      dv = scale * pv * (d[c] - dot);
+  u32x2* po = reinterpret_cast<u32x2*>(P + row * Tp);
+  u32x2* so = reinterpret_cast<u32x2*>(dS + row * Tp);
+  for (int q = lane; q < n4; q += 64) {
+    float pv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q < nv4) {
+      const f32x4 v = s4[q], dd = d4[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < nv) {
+          pv[e] = __expf(v[e] - m) * inv;
+          dv[e] = scale * pv[e] * (dd[e] - dot);
+        }
     }
-    po[c] = f32_to_bf16(pv);
-    so[c] = f32_to_bf16(dv);
+    const u32x2 pb = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+    const u32x2 db = {pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3])};
+    po[q] = pb;
+    so[q] = db;
   }
 }
 
@@ -288,7 +369,8 @@ using namespace tcavt;
 extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
                                   tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(gu_bf16 && g_act_bf16 && g_gu_bf16 && M > 0 && I > 0 && I % 16 == 0, "silu_mul_bwd: bad args (I %% 16 == 0)");
-  const long n = (long)M * I;
+  TCAVT_CHECK_ARG(aligned16(gu_bf16) && aligned16(g_act_bf16) && aligned16(g_gu_bf16), "silu_mul_bwd: 16-byte alignment required");
+  const long n = (long)M * (I / 16);
   hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(gu_bf16), static_cast<const bf16_t*>(g_act_bf16),
                      static_cast<bf16_t*>(g_gu_bf16), (long)M, I);
@@ -297,10 +379,13 @@ extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, v
 }
 
 extern "C" int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
-                                 float* gx, int accumulate, int M, int H, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(x && gamma && gy_bf16 && gx && M > 0 && H > 0, "rmsnorm_bwd: bad args");
+                                 float* gx, void* gx_bf16, int accumulate, int M, int H, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && gamma && gy_bf16 && gx && M > 0 && H > 0 && H % 8 == 0, "rmsnorm_bwd: bad args (H %% 8 == 0)");
+  TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(gy_bf16) && aligned16(gy2_bf16) && aligned16(gx) &&
+                      aligned16(gx_bf16), "rmsnorm_bwd: 16-byte alignment required");
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
-                     static_cast<const bf16_t*>(gy_bf16), static_cast<const bf16_t*>(gy2_bf16), eps, gx, accumulate, M, H);
+                     static_cast<const bf16_t*>(gy_bf16), static_cast<const bf16_t*>(gy2_bf16), eps, gx,
+                     static_cast<bf16_t*>(gx_bf16), accumulate, M, H);
   TCAVT_CHECK_LAUNCH("rmsnorm_bwd");
   return TCAVT_OK;
 }
@@ -343,7 +428,8 @@ extern "C" int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf
 extern "C" int tcavt_causal_softmax_bwd_rows(const float* S, const float* dP, void* P_bf16, void* dS_bf16,
                                              const int32_t* kv_len, int B, int T, int Tp, int nq, float scale,
                                              tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(S && dP && P_bf16 && dS_bf16 && kv_len && B > 0 && T > 0 && Tp >= T && nq > 0, "causal_softmax_bwd_rows: bad args");
+  TCAVT_CHECK_ARG(S && dP && P_bf16 && dS_bf16 && kv_len && B > 0 && T > 0 && Tp >= T && Tp % 4 == 0 && nq > 0, "causal_softmax_bwd_rows: bad args");
+  TCAVT_CHECK_ARG(aligned16(S) && aligned16(dP) && aligned16(P_bf16) && aligned16(dS_bf16), "causal_softmax_bwd_rows: 16-byte alignment required");
   const long rows = (long)B * nq * T;
   hipLaunchKernelGGL(causal_softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), S, dP, static_cast<bf16_t*>(P_bf16), static_cast<bf16_t*>(dS_bf16),

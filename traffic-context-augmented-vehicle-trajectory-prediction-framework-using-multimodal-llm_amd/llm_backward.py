@@ -140,19 +140,17 @@ class LoraBackward:
         dA = self._buf("dA", (64, H), torch.float32)
         dB = self._buf("dB", (nqkv, 64), torch.float32)
 
-        ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b)
+        ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b, gx_bf16=g_hb)
         for li in reversed(range(ll.layers)):
             d, dT, sv = P.layers[li], PT[li], tape.layers[li]
             # ---- MLP half: h_out = h_mid + (silu(gate) * up) W_d^T,  gate|up = rmsnorm(h_mid) W_gu^T
-            ops.cast_bf16(g_h, out=g_hb)
-            ops.gemm_bf16(g_hb, dT.w_d, out=g_act)
+            ops.gemm_bf16(g_hb, dT.w_d, out=g_act)  # g_hb: bf16 copy of g_h, written by the RMSNorm backward before
             ops.rmsnorm(sv.h_mid, d.g2, eps, out_bf16=xn)
             ops.gemm_bf16(xn, d.w_gu, out=gu)
             ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its gate / up pair before writing it
             ops.gemm_bf16(gu, dT.w_gu, out=g_xn)
-            ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True)
+            ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True, gx_bf16=g_hb)
             # ---- attention half: h_mid = h_in + att W_o^T
-            ops.cast_bf16(g_h, out=g_hb)
             ops.gemm_bf16(g_hb, dT.w_o, out=g_att)
             attn_bwd_composed(self._buf, sv.qkv_padded, g_att, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd), cos, sin,
                               g_qkv)
@@ -176,4 +174,4 @@ class LoraBackward:
             ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
             ops.dropout_(g_xl, sv.dspec)
             ops.gemm_bf16(g_qkv, dT.w_qkv, out=g_xn)
-            ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True)
+            ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True, gx_bf16=g_hb)

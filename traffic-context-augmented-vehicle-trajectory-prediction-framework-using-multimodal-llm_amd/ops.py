@@ -425,19 +425,20 @@ def silu_mul_bwd(gu, g_act, g_gu):
     check(lib().tcavt_silu_mul_bwd(ptr(gu), ptr(g_act), ptr(g_gu), M, I, stream_ptr()), "tcavt_silu_mul_bwd")
 
 
-def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False):
+def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None):
     M, H = x.shape
     _req(x, torch.float32, "rmsnorm_bwd.x")
     _req(gx, torch.float32, "rmsnorm_bwd.gx")
     _req(gamma, torch.float32, "rmsnorm_bwd.gamma")
     _need(gamma, H, "rmsnorm_bwd.gamma")
     _need(gx, M * H, "rmsnorm_bwd.gx")
-    for t, nm in ((gy, "gy"), (gy2, "gy2")):
+    for t, nm in ((gy, "gy"), (gy2, "gy2"), (gx_bf16, "gx_bf16")):
         if t is not None:
             _req(t, torch.bfloat16, "rmsnorm_bwd." + nm)
             _need(t, M * H, "rmsnorm_bwd." + nm)
     check(lib().tcavt_rmsnorm_bwd(ptr(x), ptr(gamma), ptr(gy), ptr(gy2) if gy2 is not None else None, eps, ptr(gx),
-                                  int(accumulate), M, H, stream_ptr()), "tcavt_rmsnorm_bwd")
+                                  ptr(gx_bf16) if gx_bf16 is not None else None, int(accumulate), M, H, stream_ptr()),
+          "tcavt_rmsnorm_bwd")
 
 
 def rope_bwd_pack(g32, out, cos, sin, rope_cols, L):
