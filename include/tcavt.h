@@ -124,6 +124,10 @@ typedef struct tcavt_gemm_args {
    * value head).  0 or 1: off. */
   int32_t batch_w_group;
   int32_t reserved0;
+  /* TCAVT_EPI_SILU_MUL only, optional: a bf16 copy of the gate|up pre-activations [M, N] (interleaved layout, leading
+   * dimension ld_preact) next to the activated output -- what the backward of silu(gate)*up needs (tcavt_silu_mul_bwd) */
+  void* silu_preact;
+  int64_t ld_preact;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);

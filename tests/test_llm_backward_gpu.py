@@ -259,3 +259,22 @@ def test_attn_bwd_composed_matches_autograd_and_scalar_kernel(gpu, B, T, nq, nkv
     for name, lo, hi in (("dq", 0, nq * 64), ("dk", nq * 64, (nq + nkv) * 64), ("dv", (nq + nkv) * 64, ncols)):
         e = rel_err(out[:, lo:hi].float().cpu(), want[:, lo:hi].float().cpu())
         assert e < 1e-2, (name, e)  # P and dS pass through bf16 on their way into the MFMA products
+
+
+@pytest.mark.parametrize("M,N,K", [(120, 1024, 256), (512, 1024, 256), (8192, 16384, 2048)])
+def test_silu_epilogue_saves_preactivations(gpu, M, N, K):
+    """tcavt_gemm_args.silu_preact: the SiLU epilogue's bf16 copy of gate|up = the plain GEMM's output, and the activated
+    output is bit-identical to the call without it (small-launch kernels, 4-wave kernel, persistent 4-wave kernel)."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    ref_act = ops.gemm_bf16(a, w, silu_mul=True)
+    plain = ops.gemm_bf16(a, w)
+    pre = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    act = ops.gemm_bf16(a, w, silu_mul=True, silu_preact=pre)
+    torch.cuda.synchronize()
+    assert torch.equal(act, ref_act)
+    assert rel_err(pre.float().cpu(), plain.float().cpu()) < 1e-3  # same products; tile forms may order the K sum differently

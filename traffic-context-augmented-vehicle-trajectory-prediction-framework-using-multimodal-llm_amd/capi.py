@@ -46,6 +46,7 @@ class GemmArgs(ctypes.Structure):
         ("sAo", c_int64), ("sAi", c_int64), ("sWo", c_int64), ("sWi", c_int64), ("sCo", c_int64), ("sCi", c_int64),
         ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
         ("batch_w_group", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("silu_preact", c_void_p), ("ld_preact", c_int64),
     ]
 
 

@@ -43,6 +43,8 @@ struct GemmP {
   int tiles_m, tiles_n;
   float acc_scale;
   int batch_inner;
+  bf16_t* aux;  // EPI_SILU_SAVE: gate|up pre-activations [M, N] bf16
+  long ldaux;
   int w_group;  // >= 1: the inner batch index is divided by this for W (grouped-query heads share one W)
   long sAo, sAi, sWo, sWi, sCo, sCi;
   int xcd_gx;  // XCD partition of the tile grid (block_to_tile)
@@ -53,7 +55,9 @@ struct GemmP {
 
 // EPI_DROP = EPI_GENERIC + Philox dropout.  A separate instantiation: with the mask code inside the generic
 // epilogue the 256x256 kernel spilled its accumulators (528 B/lane of scratch, 3x slower).
-enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3 };
+// EPI_SILU_SAVE = EPI_SILU + a bf16 copy of the gate|up pre-activations (LoRA-trainable variant: the backward of
+// silu(gate)*up needs them); its own instantiation so that the production SiLU kernel keeps its register allocation.
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -128,7 +132,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       return;
     }
   }
-  if constexpr (EPI == EPI_SILU) {
+  if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE) {
     if (whole && p.out_kind == TCAVT_BF16) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
@@ -137,6 +141,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
         for (int i = 0; i < TN; i += 2) {
           const f32x4 g = acc[i][j], u = acc[i + 1][j];
+          if constexpr (EPI == EPI_SILU_SAVE) {
+            bf16_t* arow = p.aux + m * p.ldaux + n_base + i * 16 + nq;
+            *reinterpret_cast<u32x2*>(arow) = u32x2{pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+            *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+          }
           *reinterpret_cast<u32x2*>(crow + (i >> 1) * 16) =
               u32x2{pack_bf16x2(silu_mul(g[0], u[0]), silu_mul(g[1], u[1])),
                     pack_bf16x2(silu_mul(g[2], u[2]), silu_mul(g[3], u[3]))};
@@ -214,7 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         store_quad(p, m, n, v);
       }
     }
-  } else if constexpr (EPI == EPI_SILU) {
+  } else if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m_base + j * 16 + ml;
@@ -224,6 +233,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         if (n_base + i * 16 >= p.N) continue;  // partial last tile column
         const int n = ((n_base) >> 1) + (i >> 1) * 16 + nq;
         const f32x4 g = acc[i][j], u = acc[i + 1][j];
+        if constexpr (EPI == EPI_SILU_SAVE) {
+          bf16_t* arow = p.aux + (long)m * p.ldaux + n_base + i * 16 + nq;
+          *reinterpret_cast<u32x2*>(arow) = u32x2{pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
+          *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+        }
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu_mul(g[e], u[e]);
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   static_assert(ROWS % (8 * NW) == 0, "staging rounds must be whole");
   static_assert(BM % 16 == 0 && BN % 16 == 0, "tile rows");
   static_assert(EPI != EPI_ROPE || WTN % 64 == 0, "RoPE needs whole heads per wave");
-  static_assert(EPI != EPI_SILU || WTN % 32 == 0, "SiLU needs gate/up pairs per wave");
+  static_assert((EPI != EPI_SILU && EPI != EPI_SILU_SAVE) || WTN % 32 == 0, "SiLU needs gate/up pairs per wave");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1273,7 +1287,16 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     }
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (epi & TCAVT_EPI_SILU_MUL) return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
+  if (epi & TCAVT_EPI_SILU_MUL) {
+    if (a->silu_preact) {
+      TCAVT_CHECK_ARG(aligned16(a->silu_preact) && a->ld_preact >= a->N && a->ld_preact % 4 == 0,
+                      "gemm_bf16: silu_preact needs 16-byte alignment and ld_preact >= N, %% 4 == 0");
+      p.aux = static_cast<bf16_t*>(a->silu_preact);
+      p.ldaux = a->ld_preact;
+      return dispatch_tile<EPI_SILU_SAVE, false>(p, tile, 1, s);
+    }
+    return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
+  }
   if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
   if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
     TCAVT_CHECK_ARG(!f16, "gemm_bf16: dropout needs bf16 operands");

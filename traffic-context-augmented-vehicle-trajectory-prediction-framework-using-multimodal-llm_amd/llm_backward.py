@@ -13,8 +13,9 @@ adapter gradients:
         LoRA:  g_t = s * g(q|k|v) B_ext ;  dB = g(q|k|v)^T t ;  dA = g_t^T dropout(xn) ;  g_xl = mask * (g_t A_cat)
         q|k|v^T (dgrad GEMM)  ->  RMSNorm backward                                                    (attention half)
 
-The dgrad GEMMs are the forward's MFMA kernel on transposed copies of the frozen weights (prepared_T); gate|up
-pre-activations and the normed rows are recomputed (the forward's fused SiLU epilogue never stores them).
+The dgrad GEMMs are the forward's MFMA kernel on transposed copies of the frozen weights (prepared_T); the gate|up
+pre-activations come from the forward (its SiLU epilogue writes a bf16 copy in this mode: tcavt_gemm_args.silu_preact), the
+normed rows feeding the adapters are recomputed.
 Layer 0's input gradient is not formed: nothing below it is trainable.
 """
 import math
@@ -133,7 +134,6 @@ class LoraBackward:
         g_xn = self._buf("g_xn", (M, H))
         g_xl = self._buf("g_xl", (M, H))
         g_act = self._buf("g_act", (M, I))
-        gu = self._buf("gu", (M, 2 * I))
         g_att = self._buf("g_att", (M, nq * hd))
         g_qkv = self._buf("g_qkv", (M, nqkv))
         g_t = self._buf("g_t", (M, 64))
@@ -145,9 +145,8 @@ class LoraBackward:
             d, dT, sv = P.layers[li], PT[li], tape.layers[li]
             # ---- MLP half: h_out = h_mid + (silu(gate) * up) W_d^T,  gate|up = rmsnorm(h_mid) W_gu^T
             ops.gemm_bf16(g_hb, dT.w_d, out=g_act)  # g_hb: bf16 copy of g_h, written by the RMSNorm backward before
-            ops.rmsnorm(sv.h_mid, d.g2, eps, out_bf16=xn)
-            ops.gemm_bf16(xn, d.w_gu, out=gu)
-            ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its gate / up pair before writing it
+            gu = sv.gu  # gate|up pre-activations, saved by the forward's SiLU epilogue (silu_preact)
+            ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its block of gate / up before writing it
             ops.gemm_bf16(gu, dT.w_gu, out=g_xn)
             ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True, gx_bf16=g_hb)
             # ---- attention half: h_mid = h_in + att W_o^T

@@ -548,6 +548,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                                      h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
                                      h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
                                      qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), torch.bfloat16, dev, zero=True),
+                                     gu=ws.get(f"ll.sv.gu{li}", (M, 2 * ll.inter), torch.bfloat16, dev),
                                      t=ws.get(f"ll.sv.t{li}", (M, 64), torch.bfloat16, dev) if self.use_lora else None)
                 sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
@@ -576,7 +577,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             done("o")
             ops.rmsnorm(h_mid, d.g2, ll.rms_eps, out_bf16=xn)
             mark("gateup")
-            ops.gemm_bf16(xn, d.w_gu, out=act, silu_mul=True, tile=tile)
+            ops.gemm_bf16(xn, d.w_gu, out=act, silu_mul=True, tile=tile, silu_preact=sv.gu if tape is not None else None)
             done("gateup")
             mark("down")
             ops.gemm_bf16(act, d.w_d, out=h_out, residual=h_mid, tile=tile)

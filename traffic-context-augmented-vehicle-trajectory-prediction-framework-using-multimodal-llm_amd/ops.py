@@ -46,8 +46,10 @@ def _drop(d):
 
 
 def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False, residual=None, a2=None,
-              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None):
+              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None, silu_preact=None):
     """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K] bf16, w [N,K] bf16.
+
+    silu_preact (with silu_mul): bf16 [M, N] buffer that receives the gate|up pre-activations (for silu_mul_bwd).
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
     """
@@ -83,6 +85,11 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
         epi |= EPI_RESIDUAL
     if silu_mul:
         epi |= EPI_SILU_MUL
+        if silu_preact is not None:
+            _req(silu_preact, torch.bfloat16, "gemm_bf16.silu_preact")
+            if silu_preact.shape[0] < M or silu_preact.shape[1] < N:
+                raise capi.TcavtError("gemm_bf16.silu_preact: smaller than (M, N)")
+            args.silu_preact, args.ld_preact = silu_preact.data_ptr(), silu_preact.stride(0)
     if rope is not None:
         cos, sin, cols = rope
         _req(cos, torch.float32, "gemm_bf16.rope_cos")
