@@ -349,6 +349,11 @@ int tcavt_attn_causal_gqa_bwd(const void* qkv_bf16, const void* dO_bf16, float* 
    P = causal softmax (keys < min(i+1, kv_len[b])), dS = scale * P * (dP - sum P dP); both bf16 [.., Tp], zero-filled */
 int tcavt_causal_softmax_bwd_rows(const float* S, const float* dP, void* P_bf16, void* dS_bf16, const int32_t* kv_len,
                                   int B, int T, int Tp, int nq, float scale, tcavt_stream_t stream);
+/* the same arithmetic, tiled (the production form): writes dS row-major [B*nq*T, Tp] and the transposed P^T, dS^T
+   [B*nq*Tp, Tp] (rows = keys, columns = queries) directly; Tp = T rounded up to 64.  All three outputs must be
+   ZERO-INITIALISED once by the caller: key blocks above the causal diagonal are never written */
+int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf16, void* PT_bf16, void* dST_bf16,
+                                   const int32_t* kv_len, int B, int T, int Tp, int nq, float scale, tcavt_stream_t stream);
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);

@@ -319,6 +319,86 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_rows_kernel(const floa
   }
 }
 
+
+// The same row arithmetic, tiled: one workgroup per (sample, query head, block of 64 queries) writes dS (row-major, for
+// dQ = dS K) and the TRANSPOSED tiles P^T, dS^T (for dV = P^T dO, dK = dS^T q) through LDS, so that no separate
+// transposition pass (and no row-major P) is needed.  Key blocks above the causal diagonal are never touched: the
+// three outputs must be zero-initialised once by the caller and stay zero there whatever kv_len is.
+__global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const float* __restrict__ S, const float* __restrict__ dP,
+                                                                       bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
+                                                                       bf16_t* __restrict__ dST, const int* __restrict__ kv_len,
+                                                                       int T, int Tp, int nq, float scale) {
+  __shared__ float st_m[64], st_inv[64], st_dot[64];
+  __shared__ int st_nv[64];
+  __shared__ bf16_t tP[64][66], tD[64][66];
+  const int nqb = Tp >> 6;
+  const int qb = blockIdx.x % nqb;
+  const long bh = blockIdx.x / nqb;
+  const int b = (int)(bh / nq);
+  const int klen = min(kv_len[b], T);
+  const int q0 = qb * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int rr = 0; rr < 16; ++rr) {  // row statistics: a wave per row
+    const int r = wave * 16 + rr, i = q0 + r;
+    const int nv = i < T ? min(i + 1, klen) : 0;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(S + (bh * T + i) * Tp);
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dP + (bh * T + i) * Tp);
+    const int nv4 = (nv + 3) >> 2;
+    float m = -1e30f;
+    for (int q = lane; q < nv4; q += 64) {
+      const f32x4 v = s4[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < nv) m = fmaxf(m, v[e]);
+    }
+    m = wave_max(m);
+    float sum = 0.f, dot = 0.f;
+    for (int q = lane; q < nv4; q += 64) {
+      const f32x4 v = s4[q], dd = d4[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * q + e < nv) {
+          const float ex = __expf(v[e] - m);
+          sum += ex;
+          dot = fmaf(ex, dd[e], dot);
+        }
+    }
+    sum = wave_sum(sum);
+    dot = wave_sum(dot);
+    if (lane == 0) {
+      const float inv = sum > 0.f ? 1.f / sum : 0.f;
+      st_m[r] = m;
+      st_inv[r] = inv;
+      st_dot[r] = dot * inv;
+      st_nv[r] = nv;
+    }
+  }
+  __syncthreads();
+  for (int kb = 0; kb <= qb; ++kb) {
+    const int c = kb * 64 + lane;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = wave * 16 + rr, i = q0 + r;
+      float pv = 0.f, dv = 0.f;
+      if (c < st_nv[r]) {
+        const long o = (bh * T + i) * Tp + c;
+        pv = __expf(S[o] - st_m[r]) * st_inv[r];
+        dv = scale * pv * (dP[o] - st_dot[r]);
+      }
+      const bf16_t db = f32_to_bf16(dv);
+      if (i < T) dS[(bh * T + i) * Tp + c] = db;
+      tP[r][lane] = f32_to_bf16(pv);
+      tD[r][lane] = db;
+    }
+    __syncthreads();
+    for (int cc = wave * 16; cc < wave * 16 + 16; ++cc) {  // transposed tiles: key row kb*64 + cc, 64 queries across the lanes
+      const long o = (bh * Tp + kb * 64 + cc) * Tp + q0 + lane;
+      PT[o] = tP[lane][cc];
+      dST[o] = tD[lane][cc];
+    }
+    __syncthreads();
+  }
+}
+
 // G3 fp32 [M, 3 * nq * 64] = dQ | dK per QUERY head | dV per QUERY head  ->  bf16 [M, (nq + 2 nkv) * 64]: the query heads of
 // a group are summed into their key / value head, q and k get the transposed RoPE rotation (rope_bwd_pack_kernel).
 __global__ __launch_bounds__(256) void gqa_rope_bwd_pack_kernel(const float* __restrict__ G3, bf16_t* __restrict__ out,
@@ -446,5 +526,18 @@ extern "C" int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const fl
   hipLaunchKernelGGL(gqa_rope_bwd_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      G3, static_cast<bf16_t*>(out_bf16), rope_cos, rope_sin, (long)M, nq, nkv, L);
   TCAVT_CHECK_LAUNCH("gqa_rope_bwd_pack");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf16, void* PT_bf16, void* dST_bf16,
+                                              const int32_t* kv_len, int B, int T, int Tp, int nq, float scale,
+                                              tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(S && dP && dS_bf16 && PT_bf16 && dST_bf16 && kv_len && B > 0 && T > 0 && nq > 0, "causal_softmax_bwd_tiles: bad args");
+  TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "causal_softmax_bwd_tiles: Tp must be T rounded up to a multiple of 64");
+  TCAVT_CHECK_ARG(aligned16(S) && aligned16(dP), "causal_softmax_bwd_tiles: 16-byte alignment required");
+  hipLaunchKernelGGL(causal_softmax_bwd_tiles_kernel, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), S, dP, static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16),
+                     static_cast<bf16_t*>(dST_bf16), kv_len, T, Tp, nq, scale);
+  TCAVT_CHECK_LAUNCH("causal_softmax_bwd_tiles");
   return TCAVT_OK;
 }

@@ -46,10 +46,11 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     """Backward of the causal grouped-query attention as five batched MFMA products around one row kernel.
     qkv: the forward's rotated q|k|v, bf16, rows B*T (+ >= 63 readable pad rows: the score products address keys up to
     the next multiple of 64); dO bf16 [B*T, nq*64]; g_qkv (out) bf16 [B*T, (nq+2nkv)*64] = gradient of the
-    projections' outputs (RoPE undone).  buf(name, shape, dtype) hands out reusable scratch.
+    projections' outputs (RoPE undone).  buf(name, shape, dtype, zero=False) hands out reusable scratch (zero: zero-filled
+    when first allocated).
 
         S = scale q K^T, dP = dO V^T                      per (sample, query head); the heads of a group share K / V
-        P, dS = causal softmax backward rows               (ops.causal_softmax_bwd_rows)
+        dS, P^T, dS^T = causal softmax backward tiles     (ops.causal_softmax_bwd_tiles)
         dQ = dS K,  dK_h = dS^T q,  dV_h = P^T dO          per query head; contraction over keys resp. queries
         g(q|k|v) = RoPE^T(dQ | sum_group dK_h) | sum_group dV_h
     """
@@ -58,8 +59,9 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
     f32, b16 = torch.float32, torch.bfloat16
     S, dP = buf("at.S", (BH * T, Tp), f32), buf("at.dP", (BH * T, Tp), f32)
-    P, dS = buf("at.P", (BH * T, Tp), b16), buf("at.dS", (BH * T, Tp), b16)
-    PT, dST = buf("at.PT", (BH * Tp, Tp), b16), buf("at.dST", (BH * Tp, Tp), b16)
+    # zero-initialised once: the tile kernel never writes the key blocks above the causal diagonal
+    dS = buf("at.dS", (BH * T, Tp), b16, True)
+    PT, dST = buf("at.PT", (BH * Tp, Tp), b16, True), buf("at.dST", (BH * Tp, Tp), b16, True)
     kT = buf("at.kT", (nkv * hd, B * Tp), b16)
     qT = buf("at.qT", (nq * hd, B * Tp), b16)
     gT = buf("at.gT", (nq * hd, B * Tp), b16)
@@ -69,19 +71,17 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
                      sA=(T * nqkv, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), acc_scale=scale, w_group=grp)
     ops.gemm_batched(dO, v, dP, M=T, N=Tp, K=hd, lda=nq * hd, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
                      sA=(T * nq * hd, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), w_group=grp)
-    ops.causal_softmax_bwd_rows(S, dP, P, dS, kv_len, B, T, Tp, nq, scale)
-    ops.transpose16(P, PT, T, Tp, Tp, ld_in=Tp, ld_out=Tp, batch=BH, s_in=T * Tp, s_out=Tp * Tp)
-    ops.transpose16(dS, dST, T, Tp, Tp, ld_in=Tp, ld_out=Tp, batch=BH, s_in=T * Tp, s_out=Tp * Tp)
+    ops.causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale)
     ops.transpose16(k, kT, T, nkv * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
     ops.transpose16(qkv, qT, T, nq * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
     ops.transpose16(dO, gT, T, nq * hd, Tp, ld_in=nq * hd, ld_out=B * Tp, batch=B, s_in=T * nq * hd, s_out=Tp)
     ld3 = 3 * nq * hd
     ops.gemm_batched(dS, kT, G3, M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
-                     sA=(nq * T * Tp, T * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), w_group=grp)
+                     sA=(nq * T * Tp, T * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), w_group=grp, tile=64)
     ops.gemm_batched(dST, qT, G3[:, nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
-                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd))
+                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), tile=64)
     ops.gemm_batched(PT, gT, G3[:, 2 * nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
-                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd))
+                     sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), tile=64)
     ops.gqa_rope_bwd_pack(G3, g_qkv, cos, sin, nq, nkv, T)
     return g_qkv
 

@@ -483,6 +483,20 @@ def causal_softmax_bwd_rows(S, dP, P, dS, kv_len, B, T, Tp, nq, scale):
                                               stream_ptr()), "tcavt_causal_softmax_bwd_rows")
 
 
+def causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale):
+    """Tiled form of causal_softmax_bwd_rows: dS row-major plus P^T, dS^T; the outputs must have been zero-initialised
+    once (blocks above the causal diagonal are never written)."""
+    rows = B * nq * T
+    for t, dt, n, nm in ((S, torch.float32, rows * Tp, "S"), (dP, torch.float32, rows * Tp, "dP"),
+                         (dS, torch.bfloat16, rows * Tp, "dS"), (PT, torch.bfloat16, B * nq * Tp * Tp, "PT"),
+                         (dST, torch.bfloat16, B * nq * Tp * Tp, "dST")):
+        _req(t, dt, "causal_softmax_bwd_tiles." + nm)
+        _need(t, n, "causal_softmax_bwd_tiles." + nm)
+    _need(kv_len, B, "causal_softmax_bwd_tiles.kv_len")
+    check(lib().tcavt_causal_softmax_bwd_tiles(ptr(S), ptr(dP), ptr(dS), ptr(PT), ptr(dST), ptr(kv_len), B, T, Tp, nq, scale,
+                                               stream_ptr()), "tcavt_causal_softmax_bwd_tiles")
+
+
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
     M = G3.shape[0]
     _req(G3, torch.float32, "gqa_rope_bwd_pack.G3")
