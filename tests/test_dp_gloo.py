@@ -34,7 +34,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lora=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -48,13 +48,16 @@ def _worker(rank, world, port, q):
         ops._ALLOW_CPU = True
         cfg = config.tiny()
         m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(make_weights(cfg, 0)).eval()
-        tr = training.Trainer(m)
+        tr = training.Trainer(m, lora_trainable=lora)
         assert tr.world == world and tr.comm_stream is None
         n = tr.book.total
+        assert (tr.n_base < n) if lora else (tr.n_base == n)
         base = torch.arange(n, dtype=torch.float32) % 97
         tr.book.grads.copy_(base * (rank + 1))
         tr._allreduce_bucket(0, tr.n_ltsf)
-        tr._allreduce_bucket(tr.n_ltsf, n)
+        tr._allreduce_bucket(tr.n_ltsf, tr.n_base)
+        if lora:  # third bucket: the adapter gradients, ready last (modify_scripts/modify_train.py:512-528)
+            tr._allreduce_bucket(tr.n_base, n)
         tr._wait_comm()
         expect = base * sum(r + 1 for r in range(world))
         ok_sum = torch.equal(tr.book.grads, expect)
@@ -64,7 +67,11 @@ def _worker(rank, world, port, q):
         # trainable set == everything outside mllm (train.py:1140-1145), flat order: ltsf then polygon encoder
         names = tr.book.names
         ok_names = all(k.startswith("ltsf.") for k in names[: sum(k.startswith("ltsf.") for k in names)]) and \
-            set(names) == {k for k, _ in m.named_parameters() if not k.startswith("mllm.")}
+            set(names) == {k for k, _ in m.named_parameters() if not k.startswith("mllm.") or (lora and ".lora_" in k)}
+        if lora:  # adapters sit behind the train.py set, and only they have requires_grad inside the MLLM
+            first_lora = min(i for i, k in enumerate(names) if ".lora_" in k)
+            ok_names = ok_names and all(".lora_" in k for k in names[first_lora:]) and \
+                all(p.requires_grad == (".lora_" in k) for k, p in m.mllm.named_parameters())
         q.put((rank, ok_sum, abs(grad_scale - 1.0 / world) < 1e-9, ok_names, 0 < tr.n_ltsf < n))
         dist.barrier()
         dist.destroy_process_group()
@@ -74,12 +81,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gradient_exchange_gloo():
+@pytest.mark.parametrize("lora", [False, True])
+def test_two_rank_gradient_exchange_gloo(lora):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, lora)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
