@@ -201,9 +201,10 @@ def lora_scale(cfg):
     return cfg.lora_alpha / cfg.lora_r
 
 
-def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None):
+def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
     """embeds [B,L,H] fp32, attn_mask [B,L] (1 = valid, right padded) -> post-final-norm hidden
-    states = outputs.hidden_states[-1] (train.py:553)."""
+    states = outputs.hidden_states[-1] (train.py:553).  drop: LoRA dropout on the adapter branch's input (PEFT:
+    lora_B(lora_A(dropout(x))); one site per layer, shared by q_proj and v_proj as in the HIP path, DropTape)."""
     ll = cfg.llama
     B, L, H = embeds.shape
     nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
@@ -221,8 +222,9 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None):
         v = xn @ r(W[P + "self_attn.v_proj.weight"]).T
         if cfg.use_lora:
             s = lora_scale(cfg)
-            tq = r(s * (xn @ r(W[P + "self_attn.q_proj.lora_A.weight"]).T))
-            tv = r(s * (xn @ r(W[P + "self_attn.v_proj.lora_A.weight"]).T))
+            xl = xn if drop is _ident else r(drop(xn))
+            tq = r(s * (xl @ r(W[P + "self_attn.q_proj.lora_A.weight"]).T))
+            tv = r(s * (xl @ r(W[P + "self_attn.v_proj.lora_A.weight"]).T))
             q = q + tq @ r(W[P + "self_attn.q_proj.lora_B.weight"]).T
             v = v + tv @ r(W[P + "self_attn.v_proj.lora_B.weight"]).T
         q = q.view(B, L, nq, hd)

@@ -123,8 +123,8 @@ def _lora_keys(weights):
     return [k for k in weights if ".lora_A." in k or ".lora_B." in k]
 
 
-@pytest.mark.parametrize("ragged", [False, True])
-def test_decoder_backward_lora_grads_match_autograd(gpu, ragged):
+@pytest.mark.parametrize("ragged,lora_drop", [(False, False), (True, False), (True, True)])
+def test_decoder_backward_lora_grads_match_autograd(gpu, ragged, lora_drop):
     """Stage-level: identical decoder input and an arbitrary gradient of the final hidden states; the adapter gradients of
     LoraBackward vs torch autograd through the oracle's decoder (bf16 contract, straight-through casts)."""
     from oracle import forward as O
@@ -148,15 +148,21 @@ def test_decoder_backward_lora_grads_match_autograd(gpu, ragged):
     assert len(keys) == 4 * ll.layers
     for k in keys:
         W[k].requires_grad_(True)
-    out = O.llama_decoder(W, cfg, embeds, mask, O._rounder("bf16"))
+    # train mode: LoRA dropout with the HIP path's Philox masks (block 2 of the model's site numbering, one site per layer)
+    seed = 0xD0C
+    drop = O.DropTape(seed, cfg.lora_dropout, first_site=(2 << 16) + 1) if lora_drop else O._ident
+    out = O.llama_decoder(W, cfg, embeds, mask, O._rounder("bf16"), drop=drop)
     (out * G.float()).sum().backward()
 
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
     tr = training.Trainer(m, lora_trainable=True)
     lw = m.mllm.llama_wrapper
     with torch.no_grad():
+        lw.dctx = model.DropoutCtx(seed).sub(2) if lora_drop else None
         res = lw(embeds.to(dev), mask.to(dev)).last_hidden_state
+        lw.dctx = None
         assert rel_err(res.cpu(), out.detach()) < 2e-2
+        assert (lw.tape.layers[0].dspec is not None) == lora_drop
         tr.lbw.run(G.reshape(B * L, H).contiguous().to(dev))
     torch.cuda.synchronize()
     worst = 0.0
@@ -167,7 +173,7 @@ def test_decoder_backward_lora_grads_match_autograd(gpu, ragged):
         e = rel_err(got, ref)
         worst = max(worst, e)
         assert e < 3e-2, (k, e)  # bf16 gradient chain through the layers vs fp32 autograd of the bf16-contract graph
-    print(f"[lora grads ragged={ragged}] worst relative error {worst:.2e}")
+    print(f"[lora grads ragged={ragged} lora_dropout={lora_drop}] worst relative error {worst:.2e}")
 
 
 def test_lora_trainable_step(gpu):
