@@ -229,8 +229,10 @@ def test_lora_trainable_step(gpu):
     assert l1.item() < l0.item()
 
 
-@pytest.mark.parametrize("B,T,nq,nkv,lens", [(2, 40, 4, 1, [40, 23]), (3, 64, 8, 2, [64, 1, 33]), (2, 256, 32, 8, [256, 170])])
-def test_attn_bwd_composed_matches_autograd_and_scalar_kernel(gpu, B, T, nq, nkv, lens):
+@pytest.mark.parametrize("scores", ["fused", "gemm"])
+@pytest.mark.parametrize("B,T,nq,nkv,lens", [(2, 40, 4, 1, [40, 23]), (3, 64, 8, 2, [64, 1, 33]), (2, 256, 32, 8, [256, 170]),
+                                             (1, 300, 4, 2, [211])])
+def test_attn_bwd_composed_matches_autograd_and_scalar_kernel(gpu, B, T, nq, nkv, lens, scores):
     """The production attention backward (batched MFMA products + row kernel) vs fp32 autograd of the same bf16 inputs,
     and vs the scalar cross-check kernel."""
     from tcavt_amd import ops
@@ -256,14 +258,16 @@ def test_attn_bwd_composed_matches_autograd_and_scalar_kernel(gpu, B, T, nq, nkv
 
     out = torch.empty(M, ncols, dtype=torch.bfloat16, device=dev)
     # a first call with full-length samples leaves its values in the scratch; the real call (shorter samples) must not see them
-    attn_bwd_composed(buf, qkv_p, dO, torch.full((B,), T, dtype=torch.int32, device=dev), B, T, nq, nkv, 0.125, cos, sin, out)
-    attn_bwd_composed(buf, qkv_p, dO, kv_len, B, T, nq, nkv, 0.125, cos, sin, out)
+    attn_bwd_composed(buf, qkv_p, dO, torch.full((B,), T, dtype=torch.int32, device=dev), B, T, nq, nkv, 0.125, cos, sin, out,
+                      scores=scores)
+    attn_bwd_composed(buf, qkv_p, dO, kv_len, B, T, nq, nkv, 0.125, cos, sin, out, scores=scores)
     want32 = _attn_ref(qkv_p[:M], dO, kv_len, B, T, nq, nkv)
     want = torch.empty_like(out)
     ops.rope_bwd_pack(want32.contiguous(), want, cos, sin, (nq + nkv) * 64, T)  # (tested above against autograd)
-    g32 = torch.zeros(M, ncols, dtype=torch.float32, device=dev)
-    ops.attn_causal_gqa_bwd(qkv_p[:M], dO, g32, kv_len, B, T, nq, nkv, 0.125)
-    assert rel_err(g32.cpu(), want32.cpu()) < 2e-5
+    if T <= 280:  # (the scalar cross-check kernel keeps a whole score block in LDS)
+        g32 = torch.zeros(M, ncols, dtype=torch.float32, device=dev)
+        ops.attn_causal_gqa_bwd(qkv_p[:M], dO, g32, kv_len, B, T, nq, nkv, 0.125)
+        assert rel_err(g32.cpu(), want32.cpu()) < 2e-5
     for name, lo, hi in (("dq", 0, nq * 64), ("dk", nq * 64, (nq + nkv) * 64), ("dv", (nq + nkv) * 64, ncols)):
         e = rel_err(out[:, lo:hi].float().cpu(), want[:, lo:hi].float().cpu())
         assert e < 1e-2, (name, e)  # P and dS pass through bf16 on their way into the MFMA products

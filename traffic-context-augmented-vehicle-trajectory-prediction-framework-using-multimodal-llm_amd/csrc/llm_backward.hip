@@ -399,6 +399,185 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Scores on the matrix cores, fused with the softmax backward (the production form of the middle of the attention
+// backward): one workgroup per (sample, query head, block of 64 queries); wave w owns 16 query rows and computes its
+// 16 x 64 tiles of  S = q K^T  and  dP = dO V^T  with v_mfma_f32_16x16x32_bf16 (q, dO rows are the A fragments, held in
+// registers; K / V blocks are staged through LDS one block ahead and give the B fragments), in three sweeps over the key blocks at
+// or below the diagonal: row maxima; row sums and sum(P dP); then P and dS, which leave through LDS tiles as dS row-major
+// and P^T, dS^T (as causal_softmax_bwd_tiles_kernel).  S and dP never exist in memory.
+// D[m][n] of the MFMA sits in lane l as m = 4 (l >> 4) + e, n = l & 15.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                              bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
+                                                              bf16_t* __restrict__ dST, const int* __restrict__ kv_len, int T,
+                                                              int Tp, int nq, int nkv, float scale) {
+  __shared__ bf16_t tP[64][66], tD[64][66];
+  const int nqb = Tp >> 6;
+  const int qb = blockIdx.x % nqb;
+  const long bh = blockIdx.x / nqb;
+  const int b = (int)(bh / nq), h = (int)(bh % nq);
+  const int j = h / (nq / nkv);
+  const int klen = min(kv_len[b], T);
+  const int q0 = qb * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long nqkv = (long)(nq + 2 * nkv) * 64;
+  const long row0 = (long)b * T;
+  bf16x8 qf[2], gf[2];
+  {
+    const long ar = row0 + min(q0 + wave * 16 + l15, T - 1);  // rows >= T: clamped load, masked below (nv = 0)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + h * 64 + kk * 32 + l4 * 8);
+      gf[kk] = *reinterpret_cast<const bf16x8*>(dO + ar * (long)(nq * 64) + h * 64 + kk * 32 + l4 * 8);
+    }
+  }
+  int nv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = q0 + wave * 16 + l4 * 4 + e;
+    nv[e] = i < T ? min(i + 1, klen) : 0;
+  }
+  // K / V key blocks go global -> registers -> LDS with whole 128-byte rows per 8 lanes (coalesced), one block ahead of the
+  // compute; the B fragments are then 16-byte LDS reads (rows padded to 144 bytes).  Loading the fragments straight from
+  // global memory put every lane on its own cache line: 64 address cycles per load, 372 us per launch.
+  __shared__ bf16_t ks[64][72], vs[64][72];
+  const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 16;
+  const bf16_t* kbase = qkv + (nq + j) * 64 + sch;
+  const bf16_t* vbase = qkv + (nq + nkv + j) * 64 + sch;
+  u32x4 kreg[2], vreg[2];
+  auto fetch = [&](int kb, bool want_v) {
+    const long kr = row0 + min(kb * 64 + srow, T - 1);  // keys >= T: clamped load, masked (>= nv)
+    kreg[0] = *reinterpret_cast<const u32x4*>(kbase + kr * nqkv);
+    kreg[1] = *reinterpret_cast<const u32x4*>(kbase + kr * nqkv + 8);
+    if (want_v) {
+      vreg[0] = *reinterpret_cast<const u32x4*>(vbase + kr * nqkv);
+      vreg[1] = *reinterpret_cast<const u32x4*>(vbase + kr * nqkv + 8);
+    }
+  };
+  auto stage = [&](bool want_v) {
+    *reinterpret_cast<u32x4*>(&ks[srow][sch]) = kreg[0];
+    *reinterpret_cast<u32x4*>(&ks[srow][sch + 8]) = kreg[1];
+    if (want_v) {
+      *reinterpret_cast<u32x4*>(&vs[srow][sch]) = vreg[0];
+      *reinterpret_cast<u32x4*>(&vs[srow][sch + 8]) = vreg[1];
+    }
+  };
+  auto scores = [&](f32x4 (&sa)[4], f32x4 (&da)[4], bool want_d) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&ks[t * 16 + l15][kk * 32 + l4 * 8]);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, sacc, 0, 0, 0);
+        if (want_d) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&vs[t * 16 + l15][kk * 32 + l4 * 8]);
+          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk], vf, dacc, 0, 0, 0);
+        }
+      }
+      sa[t] = sacc * scale;
+      da[t] = dacc;
+    }
+  };
+  // one sweep over the key blocks 0..qb: body(kb, S tiles, dP tiles) runs with block kb staged and block kb + 1 in flight
+  auto sweep = [&](bool want_v, auto&& body) {
+    fetch(0, want_v);
+    for (int kb = 0; kb <= qb; ++kb) {
+      __syncthreads();  // everyone is done with the previous block (and with the output tiles of the previous body)
+      stage(want_v);
+      __syncthreads();
+      if (kb < qb) fetch(kb + 1, want_v);
+      f32x4 sa[4], da[4];
+      scores(sa, da, want_v);
+      body(kb, sa, da);
+    }
+  };
+  auto group16 = [&](float v, bool is_max) {  // reduce over the 16 lanes that share l >> 4 (one query row each e)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const float w = __shfl_xor(v, o, 64);
+      v = is_max ? fmaxf(v, w) : v + w;
+    }
+    return v;
+  };
+  float m[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+  sweep(false, [&](int kb, f32x4 (&sa)[4], f32x4 (&)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int key = kb * 64 + t * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (key < nv[e]) m[e] = fmaxf(m[e], sa[t][e]);
+    }
+  });
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = group16(m[e], true);
+  float sum[4] = {0.f, 0.f, 0.f, 0.f}, dot[4] = {0.f, 0.f, 0.f, 0.f};
+  sweep(true, [&](int kb, f32x4 (&sa)[4], f32x4 (&da)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int key = kb * 64 + t * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (key < nv[e]) {
+          const float ex = __expf(sa[t][e] - m[e]);
+          sum[e] += ex;
+          dot[e] = fmaf(ex, da[t][e], dot[e]);
+        }
+    }
+  });
+  float inv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sum[e] = group16(sum[e], false);
+    dot[e] = group16(dot[e], false);
+    inv[e] = sum[e] > 0.f ? 1.f / sum[e] : 0.f;
+    dot[e] *= inv[e];
+  }
+  sweep(true, [&](int kb, f32x4 (&sa)[4], f32x4 (&da)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int cl = t * 16 + l15;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv = 0.f, dv = 0.f;
+        if (kb * 64 + cl < nv[e]) {
+          pv = __expf(sa[t][e] - m[e]) * inv[e];
+          dv = scale * pv * (da[t][e] - dot[e]);
+        }
+        const int r = wave * 16 + l4 * 4 + e;
+        tP[r][cl] = f32_to_bf16(pv);
+        tD[r][cl] = f32_to_bf16(dv);
+      }
+    }
+    __syncthreads();
+    // 8-byte stores: one instruction covers 4 rows x 16 lanes x 4 elements (2-byte stores, one row per instruction, cost
+    // 48 store instructions per wave and block; these are 12)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // dS row-major: query row r, key quad l15
+      const int r = wave * 16 + it * 4 + l4, i = q0 + r;
+      const unsigned int* src = reinterpret_cast<const unsigned int*>(&tD[r][l15 * 4]);
+      const u32x2 v = {src[0], src[1]};
+      if (i < T) *reinterpret_cast<u32x2*>(dS + (bh * T + i) * Tp + kb * 64 + l15 * 4) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // transposed tiles: key row cc, query quad l15
+      const int cc = wave * 16 + it * 4 + l4, qs = l15 * 4;
+      const u32x2 pv = {(unsigned int)tP[qs][cc] | ((unsigned int)tP[qs + 1][cc] << 16),
+                        (unsigned int)tP[qs + 2][cc] | ((unsigned int)tP[qs + 3][cc] << 16)};
+      const u32x2 dv = {(unsigned int)tD[qs][cc] | ((unsigned int)tD[qs + 1][cc] << 16),
+                        (unsigned int)tD[qs + 2][cc] | ((unsigned int)tD[qs + 3][cc] << 16)};
+      const long o = (bh * Tp + kb * 64 + cc) * Tp + q0 + qs;
+      *reinterpret_cast<u32x2*>(PT + o) = pv;
+      *reinterpret_cast<u32x2*>(dST + o) = dv;
+    }
+    // (the sweep's barrier before the next stage() also covers these tile reads)
+  });
+}
+
 // G3 fp32 [M, 3 * nq * 64] = dQ | dK per QUERY head | dV per QUERY head  ->  bf16 [M, (nq + 2 nkv) * 64]: the query heads of
 // a group are summed into their key / value head, q and k get the transposed RoPE rotation (rope_bwd_pack_kernel).
 __global__ __launch_bounds__(256) void gqa_rope_bwd_pack_kernel(const float* __restrict__ G3, bf16_t* __restrict__ out,
@@ -539,5 +718,20 @@ extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, v
                      static_cast<hipStream_t>(stream), S, dP, static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16),
                      static_cast<bf16_t*>(dST_bf16), kv_len, T, Tp, nq, scale);
   TCAVT_CHECK_LAUNCH("causal_softmax_bwd_tiles");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
+                                     const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv, int head_dim, float scale,
+                                     tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && dS_bf16 && PT_bf16 && dST_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+  TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_scores: head_dim 64 and nq %% nkv == 0 required");
+  TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_scores: Tp must be T rounded up to a multiple of 64");
+  TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16), "attn_bwd_scores: 16-byte alignment required");
+  hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
+                     static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), kv_len, T, Tp,
+                     nq, nkv, scale);
+  TCAVT_CHECK_LAUNCH("attn_bwd_scores");
   return TCAVT_OK;
 }

@@ -42,7 +42,7 @@ def lora_named_parameters(model):
     return out
 
 
-def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv):
+def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv, scores="fused"):
     """Backward of the causal grouped-query attention as five batched MFMA products around one row kernel.
     qkv: the forward's rotated q|k|v, bf16, rows B*T (+ >= 63 readable pad rows: the score products address keys up to
     the next multiple of 64); dO bf16 [B*T, nq*64]; g_qkv (out) bf16 [B*T, (nq+2nkv)*64] = gradient of the
@@ -58,7 +58,6 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     Tp = _rup(T, 64)
     nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
     f32, b16 = torch.float32, torch.bfloat16
-    S, dP = buf("at.S", (BH * T, Tp), f32), buf("at.dP", (BH * T, Tp), f32)
     # zero-initialised once: the tile kernel never writes the key blocks above the causal diagonal
     dS = buf("at.dS", (BH * T, Tp), b16, True)
     PT, dST = buf("at.PT", (BH * Tp, Tp), b16, True), buf("at.dST", (BH * Tp, Tp), b16, True)
@@ -67,11 +66,15 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     gT = buf("at.gT", (nq * hd, B * Tp), b16)
     G3 = buf("at.G3", (B * T, 3 * nq * hd), f32)
     k, v = qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:]
-    ops.gemm_batched(qkv, k, S, M=T, N=Tp, K=hd, lda=nqkv, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
-                     sA=(T * nqkv, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), acc_scale=scale, w_group=grp)
-    ops.gemm_batched(dO, v, dP, M=T, N=Tp, K=hd, lda=nq * hd, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
-                     sA=(T * nq * hd, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), w_group=grp)
-    ops.causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale)
+    if scores == "fused":  # S and dP on the matrix cores inside the softmax-backward kernel, never stored
+        ops.attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale)
+    else:  # "gemm": two batched products into fp32 scratch + the tile kernel (the cross-check of the fused kernel)
+        S, dP = buf("at.S", (BH * T, Tp), f32), buf("at.dP", (BH * T, Tp), f32)
+        ops.gemm_batched(qkv, k, S, M=T, N=Tp, K=hd, lda=nqkv, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
+                         sA=(T * nqkv, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), acc_scale=scale, w_group=grp)
+        ops.gemm_batched(dO, v, dP, M=T, N=Tp, K=hd, lda=nq * hd, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
+                         sA=(T * nq * hd, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), w_group=grp)
+        ops.causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale)
     ops.transpose16(k, kT, T, nkv * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
     ops.transpose16(qkv, qT, T, nq * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
     ops.transpose16(dO, gT, T, nq * hd, Tp, ld_in=nq * hd, ld_out=B * Tp, batch=B, s_in=T * nq * hd, s_out=Tp)

@@ -497,6 +497,20 @@ def causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale):
                                                stream_ptr()), "tcavt_causal_softmax_bwd_tiles")
 
 
+def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale):
+    """Scores + softmax backward in one kernel (MFMA inside): dS row-major, P^T, dS^T; outputs zero-initialised once."""
+    rows, ncols = B * nq * T, (nq + 2 * nkv) * 64
+    for t, n, nm in ((qkv, B * T * ncols, "qkv"), (dO, B * T * nq * 64, "dO"), (dS, rows * Tp, "dS"),
+                     (PT, B * nq * Tp * Tp, "PT"), (dST, B * nq * Tp * Tp, "dST")):
+        if t.dtype != torch.bfloat16 or (not t.is_cuda and not _ALLOW_CPU):
+            raise capi.TcavtError(f"attn_bwd_scores.{nm}: bf16 GPU tensor required")
+        if _avail(t) < n:
+            raise capi.TcavtError(f"attn_bwd_scores.{nm}: buffer too small")
+    _need(kv_len, B, "attn_bwd_scores.kv_len")
+    check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), ptr(dS), ptr(PT), ptr(dST), ptr(kv_len), B, T, Tp, nq, nkv, 64, scale,
+                                      stream_ptr()), "tcavt_attn_bwd_scores")
+
+
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
     M = G3.shape[0]
     _req(G3, torch.float32, "gqa_rope_bwd_pack.G3")
