@@ -19,10 +19,11 @@ normed rows feeding the adapters are recomputed.
 Layer 0's input gradient is not formed: nothing below it is trainable.
 """
 import math
+import os
 
 import torch
 
-from . import ops
+from . import ops, streams
 
 
 def _rup(x, m):
@@ -138,8 +139,14 @@ class LoraBackward:
         g_xl = self._buf("g_xl", (M, H))
         g_act = self._buf("g_act", (M, I))
         g_att = self._buf("g_att", (M, nq * hd))
-        g_qkv = self._buf("g_qkv", (M, nqkv))
-        g_t = self._buf("g_t", (M, 64))
+        # the adapters' weight gradients are leaf work (nothing downstream reads them): they run on a side stream while the
+        # main stream walks on to the next layer; what they read alternates between two buffers (layer parity), and a
+        # buffer is rewritten only after the leaf that read it has finished
+        multi = dev.type == "cuda" and os.environ.get("TCAVT_BW_SERIAL", "0") != "1"
+        leaf = streams.side_stream(dev, 2) if multi else None
+        leaf_done = [None, None]
+        g_qkv2 = [self._buf(f"g_qkv{i}", (M, nqkv)) for i in range(2)]
+        g_t2 = [self._buf(f"g_t{i}", (M, 64)) for i in range(2)]
         dA = self._buf("dA", (64, H), torch.float32)
         dB = self._buf("dB", (nqkv, 64), torch.float32)
 
@@ -154,26 +161,45 @@ class LoraBackward:
             ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True, gx_bf16=g_hb)
             # ---- attention half: h_mid = h_in + att W_o^T
             ops.gemm_bf16(g_hb, dT.w_o, out=g_att)
+            par = li & 1
+            g_qkv, g_t = g_qkv2[par], g_t2[par]
+            if leaf_done[par] is not None:
+                torch.cuda.current_stream().wait_event(leaf_done[par])  # the leaf of layer li + 2 has read them
             attn_bwd_composed(self._buf, sv.qkv_padded, g_att, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd), cos, sin,
                               g_qkv)
             # ---- adapters: q|k|v += t B_ext^T,  t = bf16(s * dropout(xn) A_cat^T)
-            if sv.dspec is not None:
-                ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec)
-                x_lora = xl
-            else:
-                ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
-                x_lora = xn
             ops.gemm_bf16(g_qkv, dT.b_ext, out=g_t, acc_scale=s)
-            self._wgrad("dB", g_qkv, sv.t, dB)
-            self._wgrad("dA", g_t, x_lora, dA)
-            p = f"{pre}{li}.self_attn."
-            G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
-            G[p + "v_proj.lora_A.weight"].copy_(dA[r:2 * r])
-            G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
-            G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, r:2 * r])
+
+            def adapter_grads(li=li, d=d, sv=sv, g_qkv=g_qkv, g_t=g_t):
+                if sv.dspec is not None:  # the adapter branch's input, recomputed with the forward's mask
+                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec)
+                    x_lora = xl
+                else:
+                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
+                    x_lora = xn
+                self._wgrad("dB", g_qkv, sv.t, dB)
+                self._wgrad("dA", g_t, x_lora, dA)
+                p = f"{pre}{li}.self_attn."
+                G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
+                G[p + "v_proj.lora_A.weight"].copy_(dA[r:2 * r])
+                G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
+                G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, r:2 * r])
+
+            if leaf is None:
+                adapter_grads()
+            else:
+                ready = torch.cuda.Event()
+                ready.record()
+                leaf.wait_event(ready)
+                with torch.cuda.stream(leaf):  # (xn, xl, dA, dB and the transposed copies are touched by this stream only)
+                    adapter_grads()
+                    leaf_done[par] = torch.cuda.Event()
+                    leaf_done[par].record(leaf)
             if li == 0:
                 break
             ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
             ops.dropout_(g_xl, sv.dspec)
             ops.gemm_bf16(g_qkv, dT.w_qkv, out=g_xn)
             ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True, gx_bf16=g_hb)
+        if leaf is not None:
+            torch.cuda.current_stream().wait_stream(leaf)
