@@ -67,3 +67,26 @@ def test_guard_catches_short_buffer(dry):
     ops.embed_fuse(table, ids, img, torch.zeros(64), torch.zeros(64), h_ok, flag)
     with pytest.raises(capi.TcavtError, match="kernel needs"):
         ops.embed_fuse(table, ids, img, torch.zeros(64), torch.zeros(64), torch.zeros(2 * 7, 64), flag)
+
+
+@pytest.mark.parametrize("lora_trainable", [False, True])
+def test_training_step_call_sequence_passes_host_guards(dry, lora_trainable):
+    """train.py step (and its LoRA-trainable variant, modify_scripts/modify_train.py:512-528) end to end against the stub:
+    every wrapper's host-side guard sees the real buffer shapes of forward, both backwards and the optimizer."""
+    from tcavt_amd import model, training
+
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights).eval()
+    tr = training.Trainer(m, lora_trainable=lora_trainable, max_grad_norm=1.0 if lora_trainable else None)
+    loss, decoded = tr.step(t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"], t["target_traj"],
+                            t["norm_stat"], t["input_ids"], t["attention_mask"], t["labels"])
+    assert decoded.shape == (t["traj_emb"].shape[0], 2, cfg.out_len)
+    L = cfg.llama.layers
+    assert dry.calls.count("tcavt_adamw") == 1
+    assert dry.calls.count("tcavt_attn_bwd_scores") == (L if lora_trainable else 0)
+    assert dry.calls.count("tcavt_silu_mul_bwd") == (L if lora_trainable else 0)
+    assert dry.calls.count("tcavt_gqa_rope_bwd_pack") == (L if lora_trainable else 0)
+    assert dry.calls.count("tcavt_rmsnorm_bwd") == (2 * L if lora_trainable else 0)  # final norm + two per layer, none below layer 0
+    if lora_trainable:
+        assert m.mllm.llama_wrapper.tape is not None and len(m.mllm.llama_wrapper.tape.layers) == L
