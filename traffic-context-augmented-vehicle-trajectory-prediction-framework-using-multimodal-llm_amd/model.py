@@ -454,27 +454,32 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         layers = []
         rnd = lambda t: t.detach().to(torch.bfloat16).to(torch.float32).contiguous()  # bf16-valued fp32 (gamma)
-        for lyr in self.llama_model.model.layers:
+        nL = len(self.llama_model.model.layers)
+        a_all = b_all = None
+        for li, lyr in enumerate(self.llama_model.model.layers):
             a = lyr.self_attn
             d = SimpleNamespace()
             d.w_qkv = _bf16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
             if self.use_lora:
                 r = self.lora_r
                 H = ll.hidden
-                acat = torch.zeros(64, H, dtype=torch.float32, device=d.w_qkv.device)
-                acat[:r] = a.q_proj.lora_A.weight.detach()
-                acat[r:2 * r] = a.v_proj.lora_A.weight.detach()
-                bext = torch.zeros((nq + 2 * nkv) * hd, 64, dtype=torch.float32, device=d.w_qkv.device)
-                bext[: nq * hd, :r] = a.q_proj.lora_B.weight.detach()
-                bext[(nq + nkv) * hd:, r:2 * r] = a.v_proj.lora_B.weight.detach()
-                d.a_cat, d.b_ext = _bf16(acat), _bf16(bext)
+                if a_all is None:
+                    # all layers' packed adapters in two tensors, LAST layer first (the order of the trainer's flat
+                    # parameter vector): refresh_lora() then re-packs every layer with a handful of strided copies
+                    a_all = torch.zeros(nL, 64, H, dtype=torch.bfloat16, device=d.w_qkv.device)
+                    b_all = torch.zeros(nL, (nq + 2 * nkv) * hd, 64, dtype=torch.bfloat16, device=d.w_qkv.device)
+                d.a_cat, d.b_ext = a_all[nL - 1 - li], b_all[nL - 1 - li]
+                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
+                d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
             d.w_o = _bf16(a.o_proj.weight)
             d.w_gu = _bf16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()))
             d.w_d = _bf16(lyr.mlp.down_proj.weight)
             d.g1, d.g2 = rnd(lyr.input_layernorm.weight), rnd(lyr.post_attention_layernorm.weight)
             layers.append(d)
         return SimpleNamespace(layers=layers, g_final=rnd(self.llama_model.model.norm.weight),
-                               table=_bf16(self.llama_model.model.embed_tokens.weight))
+                               table=_bf16(self.llama_model.model.embed_tokens.weight), a_all=a_all, b_all=b_all)
 
     def prepared_T(self):
         """Transposed bf16 copies of the frozen weights: the `w` operands of the backward's dgrad GEMMs
@@ -483,32 +488,47 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         if self._prep_T is None:
             P = self._prepared()
             tr = lambda w: w.t().contiguous()
+            nL = len(P.layers)
+            at_all = P.a_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), H, 64]
+            bt_all = P.b_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), 64, nqkv]
             self._prep_T = [SimpleNamespace(w_qkv=tr(d.w_qkv), w_o=tr(d.w_o), w_gu=tr(d.w_gu), w_d=tr(d.w_d),
-                                            a_cat=tr(d.a_cat) if self.use_lora else None,
-                                            b_ext=tr(d.b_ext) if self.use_lora else None) for d in P.layers]
+                                            a_cat=at_all[nL - 1 - li] if self.use_lora else None,
+                                            b_ext=bt_all[nL - 1 - li] if self.use_lora else None)
+                            for li, d in enumerate(P.layers)]
+            self._prep_T_all = (at_all, bt_all)
         return self._prep_T
 
     def _invalidate(self):
         self._prep_T = None
         _Prepared._invalidate(self)
 
-    def refresh_lora(self):
+    def refresh_lora(self, stacked=None):
         """Re-pack the adapter matrices (a_cat, b_ext and their transposes) from the lora_A / lora_B parameters after
-        an optimizer step; the frozen base weights are left alone."""
+        an optimizer step; the frozen base weights are left alone.  stacked = (A_q, B_q, A_v, B_v): views of ALL layers'
+        parameters, last layer first ([layers, r, H] / [layers, out, r]; training.Trainer builds them over its flat
+        parameter vector) -- then the whole re-pack is six strided copies instead of six per layer."""
         if not self.use_lora or self._prep is None:
             return
         ll, r = self.shape, self.lora_r
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         P = self._prepared()
-        for li, lyr in enumerate(self.llama_model.model.layers):
-            a, d = lyr.self_attn, P.layers[li]
-            d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
-            d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
-            d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
-            d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
-            if self._prep_T is not None:
-                self._prep_T[li].a_cat.copy_(d.a_cat.t())
-                self._prep_T[li].b_ext.copy_(d.b_ext.t())
+        if stacked is not None:
+            aq, bq, av, bv = stacked
+            P.a_all[:, :r].copy_(aq)
+            P.a_all[:, r:2 * r].copy_(av)
+            P.b_all[:, : nq * hd, :r].copy_(bq)
+            P.b_all[:, (nq + nkv) * hd:, r:2 * r].copy_(bv)
+        else:
+            for li, lyr in enumerate(self.llama_model.model.layers):
+                a, d = lyr.self_attn, P.layers[li]
+                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
+                d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
+        if self._prep_T is not None:
+            at_all, bt_all = self._prep_T_all
+            at_all.copy_(P.a_all.transpose(1, 2))
+            bt_all.copy_(P.b_all.transpose(1, 2))
 
     def _rope_tables(self, L, dev):
         key = (L, str(dev))

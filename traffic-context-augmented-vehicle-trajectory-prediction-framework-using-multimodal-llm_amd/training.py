@@ -58,6 +58,7 @@ class Trainer:
         if self.lora_trainable:
             self.lbw = LoraBackward(model, self.book)
             model.mllm.llama_wrapper.save_for_backward = True
+            self._lora_stacked = self._stacked_lora_views(lora)
         model.lane_polygon_encoder.save_for_backward = True
         model.ltsf.save_for_backward = True
         self.pg = process_group
@@ -111,6 +112,23 @@ class Trainer:
             self._wait_comm()
         return loss, decoded
 
+    def _stacked_lora_views(self, lora):
+        """(A_q, B_q, A_v, B_v) of all layers as strided views of the flat parameter vector (lora_named_parameters puts
+        the layers last-first, four matrices each, so consecutive layers are one constant stride apart)."""
+        offs = [self.book.offsets[n] for n, _ in lora]
+        nL = len(lora) // 4
+        if nL == 1:
+            stride = 0
+        else:
+            stride = offs[4][0] - offs[0][0]
+            if any(offs[4 * i + k][0] - offs[k][0] != i * stride for i in range(nL) for k in range(4)):
+                return None  # (not a uniform layout: refresh_lora falls back to per-layer copies)
+        views = []
+        for k in range(4):
+            off, _, shape = offs[k]
+            views.append(self.book.params.as_strided((nL,) + tuple(shape), (stride, shape[1], 1), off))
+        return tuple(views)
+
     def _lora_backward(self, B, L):
         """Gradient of the decoder's final hidden states = what flows back through the cross-attention's key and value
         in-projections (k = fh W_k^T + b_k, v = fh W_v^T + b_v; the LTSF backward left dL/dk, dL/dv behind), then the
@@ -147,7 +165,7 @@ class Trainer:
             # bf16 shadows / stacked copies of the trainable weights are stale now
             m.ltsf._invalidate()
             if self.lora_trainable:
-                m.mllm.llama_wrapper.refresh_lora()
+                m.mllm.llama_wrapper.refresh_lora(self._lora_stacked)
 
     def prefetch(self, vision_embs, ready=None):
         """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
