@@ -284,7 +284,8 @@ def main():
         if not torch.isfinite(loss).item():
             raise SystemExit("non-finite loss in warm-up")
         setup_s = time.time() - t0
-        log(f"setup + first step done in {setup_s:.1f} s; loss {loss.item():.3f}")
+        first_loss = float(loss.item())
+        log(f"setup + first step done in {setup_s:.1f} s; loss {first_loss:.3f}")
 
         graph = None
         if args.launch == "graph" and not args.no_graph and world == 1:  # multi-rank: RCCL all-reduces are launched eagerly
@@ -301,14 +302,16 @@ def main():
 
         prefetch = graph is None and not args.no_prefetch
 
+        last = {"loss": loss}
+
         def run_step():
             if graph is not None:
                 graph.replay()
             else:
                 if trainer is not None:  # batch i+1's Q-Former goes to a side stream and runs under step i's decoder
-                    step(g["vision_emb"] if prefetch else None)
+                    last["loss"] = step(g["vision_emb"] if prefetch else None)[0]
                 else:
-                    step()
+                    last["loss"] = step()[0]
                     if prefetch:
                         m.prefetch(g["vision_emb"])
 
@@ -405,6 +408,9 @@ def main():
             },
             "kernels": kernels,
             "setup_s": round(setup_s, 1),
+            # the synthetic batch is the same every step: in train mode the loss must fall as the optimizer fits it
+            "loss_first_step": round(first_loss, 3), "loss_last_timed_step": round(float(last["loss"].item()), 3),
+            "peak_device_memory_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         }
         if not args.no_cpu_baseline and world >= 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args, gpu_decoded=parity_dec, W=W_cpu) if args.gpus == 1 or world == 1 else None
