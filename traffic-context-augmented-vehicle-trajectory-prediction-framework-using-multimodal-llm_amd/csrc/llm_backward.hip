@@ -2,7 +2,9 @@
 // modify_scripts/modify_train.py:512-528 trains lora_A / lora_B of q_proj, v_proj while every base weight stays frozen):
 // the activation gradient walks back through all layers -- dgrad GEMMs against transposed copies of the frozen
 // weights (gemm_bf16.hip), and the pointwise / row / attention pieces here.
-// First correct form: the attention backward is a scalar-FMA kernel with the score block in LDS (no MFMA yet).
+// Attention backward: attn_bwd_scores_kernel (scores on the matrix cores + softmax backward, writes dS, P^T, dS^T) followed by
+// three batched MFMA products (llm_backward.attn_bwd_composed); attn_causal_gqa_bwd_kernel below is the scalar-FMA
+// cross-check of that composition, not a product path.
 #include "common.hpp"
 #include "philox.hpp"
 
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------
-// Causal GQA attention backward, head_dim 64.  One workgroup per (sample, query head, block of QB = 32 query rows).
+// (cross-check kernel) Causal GQA attention backward, head_dim 64.  One workgroup per (sample, query head, block of QB = 32 query rows).
 //   P = softmax(scale * q K^T) over keys c < min(i + 1, kv_len[b]);   dP = dO V^T;   dS = scale * P * (dP - rowsum(P dP))
 //   dQ_i = sum_c dS_ic K_c  (written);   dK_c += sum_i dS_ic q_i,  dV_c += sum_i P_ic dO_i  (float atomics: the four
 //   query heads of a group and the query blocks all add into the same key rows).
