@@ -356,10 +356,12 @@ int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf1
                                    const int32_t* kv_len, int B, int T, int Tp, int nq, float scale, tcavt_stream_t stream);
 /* production form of the middle of the attention backward: S = scale q K^T and dP = dO V^T on the matrix cores inside
    the kernel (never stored), softmax backward, outputs as tcavt_causal_softmax_bwd_tiles (dS, P^T, dS^T; ZERO-INITIALISED
-   once by the caller).  qkv = the forward's rotated q|k|v [B*T, (nq+2nkv)*64] bf16, dO [B*T, nq*64] bf16 */
+   once by the caller).  qkv = the forward's rotated q|k|v [B*T, (nq+2nkv)*64] bf16, dO [B*T, nq*64] bf16.
+   dQ (optional): fp32 [B*T, ld_dq], head h at columns 64 h, receives dQ = dS K computed in the same kernel; dS_bf16
+   (optional) is the row-major dS for an external product; at least one of the two */
 int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
-                          const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv, int head_dim, float scale,
-                          tcavt_stream_t stream);
+                          float* dQ, int64_t ld_dq, const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv,
+                          int head_dim, float scale, tcavt_stream_t stream);
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);

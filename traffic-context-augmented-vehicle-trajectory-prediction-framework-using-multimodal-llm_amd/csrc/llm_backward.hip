@@ -413,9 +413,14 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
-                                                              bf16_t* __restrict__ dST, const int* __restrict__ kv_len, int T,
-                                                              int Tp, int nq, int nkv, float scale) {
+                                                              bf16_t* __restrict__ dST, float* __restrict__ dQ, long ld_dq,
+                                                              const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
+                                                              float scale) {
+  // dQ (optional, fp32 [B*T, ld_dq], head h at columns 64 h): dQ = dS K accumulated over the key blocks inside the third
+  // sweep (A = the dS tile in LDS, B = a transposed copy of the K block); dS (optional): the row-major copy for an
+  // external dQ product.
   __shared__ bf16_t tP[64][66], tD[64][66];
+  __shared__ __attribute__((aligned(16))) bf16_t ksT[64][72];  // K block transposed [d][key] (third sweep, dQ only)
   const int nqb = Tp >> 6;
   const int qb = blockIdx.x % nqb;
   const long bh = blockIdx.x / nqb;
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
   // K / V key blocks go global -> registers -> LDS with whole 128-byte rows per 8 lanes (coalesced), one block ahead of the
   // compute; the B fragments are then 16-byte LDS reads (rows padded to 144 bytes).  Loading the fragments straight from
   // global memory put every lane on its own cache line: 64 address cycles per load, 372 us per launch.
-  __shared__ bf16_t ks[64][72], vs[64][72];
+  __shared__ __attribute__((aligned(16))) bf16_t ks[64][72], vs[64][72];
   const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 16;
   const bf16_t* kbase = qkv + (nq + j) * 64 + sch;
   const bf16_t* vbase = qkv + (nq + nkv + j) * 64 + sch;
@@ -459,9 +464,19 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
       vreg[1] = *reinterpret_cast<const u32x4*>(vbase + kr * nqkv + 8);
     }
   };
+  bool want_t = false;
   auto stage = [&](bool want_v) {
     *reinterpret_cast<u32x4*>(&ks[srow][sch]) = kreg[0];
     *reinterpret_cast<u32x4*>(&ks[srow][sch + 8]) = kreg[1];
+    if (want_t) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ksT[sch + c * 8 + 2 * e][srow] = (bf16_t)(kreg[c][e] & 0xffffu);
+          ksT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(kreg[c][e] >> 16);
+        }
+    }
     if (want_v) {
       *reinterpret_cast<u32x4*>(&vs[srow][sch]) = vreg[0];
       *reinterpret_cast<u32x4*>(&vs[srow][sch + 8]) = vreg[1];
@@ -539,6 +554,10 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
     inv[e] = sum[e] > 0.f ? 1.f / sum[e] : 0.f;
     dot[e] *= inv[e];
   }
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  want_t = dQ != nullptr;
   sweep(true, [&](int kb, f32x4 (&sa)[4], f32x4 (&da)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -563,7 +582,20 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
       const int r = wave * 16 + it * 4 + l4, i = q0 + r;
       const unsigned int* src = reinterpret_cast<const unsigned int*>(&tD[r][l15 * 4]);
       const u32x2 v = {src[0], src[1]};
-      if (i < T) *reinterpret_cast<u32x2*>(dS + (bh * T + i) * Tp + kb * 64 + l15 * 4) = v;
+      if (dS && i < T) *reinterpret_cast<u32x2*>(dS + (bh * T + i) * Tp + kb * 64 + l15 * 4) = v;
+    }
+    if (dQ) {  // dQ[16 rows of this wave][64] += dS tile [16 x 64 keys] . K block [64 keys x 64]
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const unsigned int* ap = reinterpret_cast<const unsigned int*>(&tD[wave * 16 + l15][kk * 32 + l4 * 8]);
+        const u32x4 av = {ap[0], ap[1], ap[2], ap[3]};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&ksT[dt * 16 + l15][kk * 32 + l4 * 8]);
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, dq[dt], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {  // transposed tiles: key row cc, query quad l15
@@ -578,6 +610,15 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
     }
     // (the sweep's barrier before the next stage() also covers these tile reads)
   });
+  if (dQ) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = q0 + wave * 16 + l4 * 4 + e;
+        if (i < T) dQ[(row0 + i) * ld_dq + h * 64 + dt * 16 + l15] = dq[dt][e];
+      }
+  }
 }
 
 // G3 fp32 [M, 3 * nq * 64] = dQ | dK per QUERY head | dV per QUERY head  ->  bf16 [M, (nq + 2 nkv) * 64]: the query heads of
@@ -724,16 +765,18 @@ extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, v
 }
 
 extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
-                                     const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv, int head_dim, float scale,
-                                     tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && dS_bf16 && PT_bf16 && dST_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+                                     float* dQ, int64_t ld_dq, const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv,
+                                     int head_dim, float scale, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && PT_bf16 && dST_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+  TCAVT_CHECK_ARG(dS_bf16 || dQ, "attn_bwd_scores: give dQ (computed here) or dS (for an external dQ product), or both");
+  TCAVT_CHECK_ARG(!dQ || ld_dq >= (int64_t)nq * 64, "attn_bwd_scores: ld_dq must cover nq * 64 columns");
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_scores: head_dim 64 and nq %% nkv == 0 required");
   TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_scores: Tp must be T rounded up to a multiple of 64");
   TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16), "attn_bwd_scores: 16-byte alignment required");
   hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
-                     static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), kv_len, T, Tp,
-                     nq, nkv, scale);
+                     static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), dQ, (long)ld_dq,
+                     kv_len, T, Tp, nq, nkv, scale);
   TCAVT_CHECK_LAUNCH("attn_bwd_scores");
   return TCAVT_OK;
 }

@@ -51,37 +51,37 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     when first allocated).
 
         S = scale q K^T, dP = dO V^T                      per (sample, query head); the heads of a group share K / V
-        dS, P^T, dS^T = causal softmax backward tiles     (ops.causal_softmax_bwd_tiles)
-        dQ = dS K,  dK_h = dS^T q,  dV_h = P^T dO          per query head; contraction over keys resp. queries
+        P^T, dS^T, dQ = dS K: all of the above in one kernel (ops.attn_bwd_scores; S, dP, dS never reach memory)
+        dK_h = dS^T q,  dV_h = P^T dO                      per query head on the batched GEMM; contraction over queries
         g(q|k|v) = RoPE^T(dQ | sum_group dK_h) | sum_group dV_h
     """
     hd = 64
     Tp = _rup(T, 64)
     nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
     f32, b16 = torch.float32, torch.bfloat16
-    # zero-initialised once: the tile kernel never writes the key blocks above the causal diagonal
-    dS = buf("at.dS", (BH * T, Tp), b16, True)
+    # zero-initialised once: the kernels never write the key blocks above the causal diagonal
     PT, dST = buf("at.PT", (BH * Tp, Tp), b16, True), buf("at.dST", (BH * Tp, Tp), b16, True)
-    kT = buf("at.kT", (nkv * hd, B * Tp), b16)
     qT = buf("at.qT", (nq * hd, B * Tp), b16)
     gT = buf("at.gT", (nq * hd, B * Tp), b16)
     G3 = buf("at.G3", (B * T, 3 * nq * hd), f32)
     k, v = qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:]
-    if scores == "fused":  # S and dP on the matrix cores inside the softmax-backward kernel, never stored
-        ops.attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale)
-    else:  # "gemm": two batched products into fp32 scratch + the tile kernel (the cross-check of the fused kernel)
+    ld3 = 3 * nq * hd
+    if scores == "fused":  # S, dP and dQ = dS K on the matrix cores inside the softmax-backward kernel; S, dP, dS never stored
+        ops.attn_bwd_scores(qkv, dO, None, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=G3)
+    else:  # "gemm": every product on the batched GEMM, fp32 S / dP scratch + the tile kernel (cross-check of the fused kernel)
+        dS = buf("at.dS", (BH * T, Tp), b16, True)
+        kT = buf("at.kT", (nkv * hd, B * Tp), b16)
         S, dP = buf("at.S", (BH * T, Tp), f32), buf("at.dP", (BH * T, Tp), f32)
         ops.gemm_batched(qkv, k, S, M=T, N=Tp, K=hd, lda=nqkv, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
                          sA=(T * nqkv, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), acc_scale=scale, w_group=grp)
         ops.gemm_batched(dO, v, dP, M=T, N=Tp, K=hd, lda=nq * hd, ldw=nqkv, ldc=Tp, batch=BH, inner=nq,
                          sA=(T * nq * hd, hd), sW=(T * nqkv, hd), sC=(nq * T * Tp, T * Tp), w_group=grp)
         ops.causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale)
-    ops.transpose16(k, kT, T, nkv * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
+        ops.transpose16(k, kT, T, nkv * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
+        ops.gemm_batched(dS, kT, G3, M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
+                         sA=(nq * T * Tp, T * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), w_group=grp, tile=64)
     ops.transpose16(qkv, qT, T, nq * hd, Tp, ld_in=nqkv, ld_out=B * Tp, batch=B, s_in=T * nqkv, s_out=Tp)
     ops.transpose16(dO, gT, T, nq * hd, Tp, ld_in=nq * hd, ld_out=B * Tp, batch=B, s_in=T * nq * hd, s_out=Tp)
-    ld3 = 3 * nq * hd
-    ops.gemm_batched(dS, kT, G3, M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
-                     sA=(nq * T * Tp, T * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), w_group=grp, tile=64)
     ops.gemm_batched(dST, qT, G3[:, nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,
                      sA=(nq * Tp * Tp, Tp * Tp), sW=(Tp, hd * B * Tp), sC=(T * ld3, hd), tile=64)
     ops.gemm_batched(PT, gT, G3[:, 2 * nq * hd:], M=T, N=hd, K=Tp, lda=Tp, ldw=B * Tp, ldc=ld3, batch=BH, inner=nq,

@@ -497,18 +497,25 @@ def causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale):
                                                stream_ptr()), "tcavt_causal_softmax_bwd_tiles")
 
 
-def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale):
-    """Scores + softmax backward in one kernel (MFMA inside): dS row-major, P^T, dS^T; outputs zero-initialised once."""
+def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None):
+    """Scores + softmax backward in one kernel (MFMA inside): P^T, dS^T (zero-initialised once), plus dQ = dS K (fp32
+    [B*T, >= nq*64], any leading dimension) computed in place and / or the row-major dS for an external dQ product."""
     rows, ncols = B * nq * T, (nq + 2 * nkv) * 64
+    if dQ is not None:
+        if dQ.dtype != torch.float32 or dQ.stride(-1) != 1 or _avail(dQ) < (B * T - 1) * dQ.stride(0) + nq * 64:
+            raise capi.TcavtError("attn_bwd_scores.dQ: fp32 [B*T, >= nq*64] required")
     for t, n, nm in ((qkv, B * T * ncols, "qkv"), (dO, B * T * nq * 64, "dO"), (dS, rows * Tp, "dS"),
                      (PT, B * nq * Tp * Tp, "PT"), (dST, B * nq * Tp * Tp, "dST")):
+        if t is None and nm == "dS" and dQ is not None:
+            continue
         if t.dtype != torch.bfloat16 or (not t.is_cuda and not _ALLOW_CPU):
             raise capi.TcavtError(f"attn_bwd_scores.{nm}: bf16 GPU tensor required")
         if _avail(t) < n:
             raise capi.TcavtError(f"attn_bwd_scores.{nm}: buffer too small")
     _need(kv_len, B, "attn_bwd_scores.kv_len")
-    check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), ptr(dS), ptr(PT), ptr(dST), ptr(kv_len), B, T, Tp, nq, nkv, 64, scale,
-                                      stream_ptr()), "tcavt_attn_bwd_scores")
+    check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), ptr(dS) if dS is not None else None, ptr(PT), ptr(dST),
+                                      ptr(dQ) if dQ is not None else None, dQ.stride(0) if dQ is not None else 0, ptr(kv_len),
+                                      B, T, Tp, nq, nkv, 64, scale, stream_ptr()), "tcavt_attn_bwd_scores")
 
 
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
