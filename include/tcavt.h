@@ -358,10 +358,17 @@ int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf1
    the kernel (never stored), softmax backward, outputs as tcavt_causal_softmax_bwd_tiles (dS, P^T, dS^T; ZERO-INITIALISED
    once by the caller).  qkv = the forward's rotated q|k|v [B*T, (nq+2nkv)*64] bf16, dO [B*T, nq*64] bf16.
    dQ (optional): fp32 [B*T, ld_dq], head h at columns 64 h, receives dQ = dS K computed in the same kernel; dS_bf16
-   (optional) is the row-major dS for an external product; at least one of the two */
+   (optional) is the row-major dS for an external product; at least one of the two.  PT / dST are optional (both or
+   neither; the GEMM form of dK, dV); stats (optional; required without PT/dST): fp32 [B*nq*T, 4] = row maximum of the
+   scaled scores, 1 / row sum, sum(P dP), 0 -- the input of tcavt_attn_bwd_dkv */
 int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
-                          float* dQ, int64_t ld_dq, const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv,
-                          int head_dim, float scale, tcavt_stream_t stream);
+                          float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp, int nq,
+                          int nkv, int head_dim, float scale, tcavt_stream_t stream);
+/* dK, dV of the attention backward, key-major on the matrix cores (one workgroup per sample, key/value head and 64 keys;
+   P^T, dS^T rebuilt from `stats`, the query heads of the group summed in registers): writes the k and v columns of
+   g32 [B*T, (nq+2nkv)*64] fp32 (every row; no zero-initialisation needed) */
+int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* stats, float* g32, const int32_t* kv_len,
+                       int B, int T, int Tp, int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream);
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);

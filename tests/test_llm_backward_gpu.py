@@ -240,7 +240,7 @@ def test_lora_trainable_step(gpu):
     assert l1.item() < l0.item()
 
 
-@pytest.mark.parametrize("scores", ["fused", "gemm"])
+@pytest.mark.parametrize("scores", ["fused", "scores+gemm", "gemm"])
 @pytest.mark.parametrize("B,T,nq,nkv,lens", [(2, 40, 4, 1, [40, 23]), (3, 64, 8, 2, [64, 1, 33]), (2, 256, 32, 8, [256, 170]),
                                              (1, 300, 4, 2, [211])])
 def test_attn_bwd_composed_matches_autograd_and_scalar_kernel(gpu, B, T, nq, nkv, lens, scores):

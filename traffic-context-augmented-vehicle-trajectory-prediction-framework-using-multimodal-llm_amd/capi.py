@@ -97,8 +97,10 @@ _SIGNATURES = {
                                       c_void_p],
     "tcavt_causal_softmax_bwd_tiles": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_float, c_void_p],
-    "tcavt_attn_bwd_scores": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
-                              c_int, c_int, c_int, c_float, c_void_p],
+    "tcavt_attn_bwd_scores": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                           c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

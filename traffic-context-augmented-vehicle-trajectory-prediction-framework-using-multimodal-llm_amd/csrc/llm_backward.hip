@@ -414,8 +414,10 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
 __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
                                                               bf16_t* __restrict__ dST, float* __restrict__ dQ, long ld_dq,
-                                                              const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
-                                                              float scale) {
+                                                              float* __restrict__ stats, const int* __restrict__ kv_len, int T,
+                                                              int Tp, int nq, int nkv, float scale) {
+  // stats (optional, fp32 [B*nq*T, 4]): row maximum of the scaled scores, 1 / row sum, sum(P dP) -- what
+  // attn_bwd_dkv_kernel needs to rebuild P and dS for its key block.  PT / dST (optional): only for the GEMM form of dK, dV.
   // dQ (optional, fp32 [B*T, ld_dq], head h at columns 64 h): dQ = dS K accumulated over the key blocks inside the third
   // sweep (A = the dS tile in LDS, B = a transposed copy of the K block); dS (optional): the row-major copy for an
   // external dQ product.
@@ -553,6 +555,8 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
     dot[e] = group16(dot[e], false);
     inv[e] = sum[e] > 0.f ? 1.f / sum[e] : 0.f;
     dot[e] *= inv[e];
+    const int i = q0 + wave * 16 + l4 * 4 + e;
+    if (stats && l15 == 0 && i < T) *reinterpret_cast<f32x4*>(stats + (bh * T + i) * 4) = f32x4{m[e], inv[e], dot[e], 0.f};
   }
   f32x4 dq[4];
 #pragma unroll
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
       }
     }
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {  // transposed tiles: key row cc, query quad l15
+    for (int it = 0; it < 4 && PT != nullptr; ++it) {  // transposed tiles: key row cc, query quad l15
       const int cc = wave * 16 + it * 4 + l4, qs = l15 * 4;
       const u32x2 pv = {(unsigned int)tP[qs][cc] | ((unsigned int)tP[qs + 1][cc] << 16),
                         (unsigned int)tP[qs + 2][cc] | ((unsigned int)tP[qs + 3][cc] << 16)};
@@ -619,6 +623,138 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
         if (i < T) dQ[(row0 + i) * ld_dq + h * 64 + dt * 16 + l15] = dq[dt][e];
       }
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// dK, dV of the attention backward, key-major: one workgroup per (sample, key/value head, block of 64 keys); wave w owns
+// 16 keys, whose K and V rows are its A fragments for the whole kernel.  For every query head of the group and every
+// query block at or below the diagonal, the Q and dO blocks are staged in LDS (row-major for the score products,
+// transposed for the gradient products), the tiles  S^T = K q^T  and  dP^T = V dO^T  are rebuilt on the matrix cores,
+// P^T and dS^T follow from the per-query statistics attn_bwd_scores_kernel left behind, pass through a wave-private LDS
+// tile (accumulator layout -> A-fragment layout), and  dV += P^T dO,  dK += dS^T q  accumulate in registers over all of
+// it -- the group sum included.  Written once, fp32, into the k / v columns of the q|k|v-layout gradient.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                           const float* __restrict__ stats, float* __restrict__ g32,
+                                                           const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
+                                                           float scale) {
+  __shared__ __attribute__((aligned(16))) bf16_t qs[64][72], gs[64][72], qsT[64][72], gsT[64][72], tP[64][72], tD[64][72];
+  __shared__ float st_m[64], st_inv[64], st_dot[64];
+  __shared__ int st_nv[64];
+  const int nkb = Tp >> 6;
+  const int kb = blockIdx.x % nkb;
+  const int bj = blockIdx.x / nkb;
+  const int b = bj / nkv, j = bj % nkv;
+  const int grp = nq / nkv;
+  const int klen = min(kv_len[b], T);
+  const int k0 = kb * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long nqkv = (long)(nq + 2 * nkv) * 64;
+  const long row0 = (long)b * T;
+  bf16x8 kf[2], vf[2];
+  {
+    const long ar = row0 + min(k0 + wave * 16 + l15, T - 1);  // keys >= T: clamped load; they are >= nv of every query
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + (nq + j) * 64 + kk * 32 + l4 * 8);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + (nq + nkv + j) * 64 + kk * 32 + l4 * 8);
+    }
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 16;
+  const int nit = grp * (nkb - kb);
+  u32x4 qreg[2], greg[2];
+  auto fetch = [&](int it) {
+    const int h = j * grp + it / (nkb - kb), qb = kb + it % (nkb - kb);
+    const long qr = row0 + min(qb * 64 + srow, T - 1);
+    qreg[0] = *reinterpret_cast<const u32x4*>(qkv + qr * nqkv + h * 64 + sch);
+    qreg[1] = *reinterpret_cast<const u32x4*>(qkv + qr * nqkv + h * 64 + sch + 8);
+    greg[0] = *reinterpret_cast<const u32x4*>(dO + qr * (long)(nq * 64) + h * 64 + sch);
+    greg[1] = *reinterpret_cast<const u32x4*>(dO + qr * (long)(nq * 64) + h * 64 + sch + 8);
+  };
+  fetch(0);
+  for (int it = 0; it < nit; ++it) {
+    const int h = j * grp + it / (nkb - kb), qb = kb + it % (nkb - kb);
+    const int q0 = qb * 64;
+    __syncthreads();  // the previous iteration is done with the staged blocks and the tiles
+    *reinterpret_cast<u32x4*>(&qs[srow][sch]) = qreg[0];
+    *reinterpret_cast<u32x4*>(&qs[srow][sch + 8]) = qreg[1];
+    *reinterpret_cast<u32x4*>(&gs[srow][sch]) = greg[0];
+    *reinterpret_cast<u32x4*>(&gs[srow][sch + 8]) = greg[1];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qsT[sch + c * 8 + 2 * e][srow] = (bf16_t)(qreg[c][e] & 0xffffu);
+        qsT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(qreg[c][e] >> 16);
+        gsT[sch + c * 8 + 2 * e][srow] = (bf16_t)(greg[c][e] & 0xffffu);
+        gsT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(greg[c][e] >> 16);
+      }
+    if (threadIdx.x < 64) {
+      const int i = q0 + threadIdx.x;
+      float m = 0.f, inv = 0.f, dot = 0.f;
+      int nv = 0;
+      if (i < T) {
+        const f32x4 st = *reinterpret_cast<const f32x4*>(stats + (((long)b * nq + h) * T + i) * 4);
+        m = st[0]; inv = st[1]; dot = st[2];
+        nv = min(i + 1, klen);
+      }
+      st_m[threadIdx.x] = m; st_inv[threadIdx.x] = inv; st_dot[threadIdx.x] = dot; st_nv[threadIdx.x] = nv;
+    }
+    __syncthreads();
+    if (it + 1 < nit) fetch(it + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {  // 16 keys of this wave x 16 queries
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&qs[t * 16 + l15][kk * 32 + l4 * 8]);
+        const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&gs[t * 16 + l15][kk * 32 + l4 * 8]);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf, sacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kk], gf, dacc, 0, 0, 0);
+      }
+      const int qi = t * 16 + l15;  // D[m][n]: m = key 4 l4 + e of the wave's 16, n = query qi
+      const float qm = st_m[qi], qinv = st_inv[qi], qdot = st_dot[qi];
+      const int qnv = st_nv[qi];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pv = 0.f, dsv = 0.f;
+        if (k0 + wave * 16 + l4 * 4 + e < qnv) {
+          pv = __expf(sacc[e] * scale - qm) * qinv;
+          dsv = scale * pv * (dacc[e] - qdot);
+        }
+        tP[wave * 16 + l4 * 4 + e][qi] = f32_to_bf16(pv);
+        tD[wave * 16 + l4 * 4 + e][qi] = f32_to_bf16(dsv);
+      }
+    }
+    __syncthreads();  // (the tile rows of a wave are private to it; the barrier only orders its own writes and reads)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // contraction over the 64 queries of the block
+      const bf16x8 pf = *reinterpret_cast<const bf16x8*>(&tP[wave * 16 + l15][kk * 32 + l4 * 8]);
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(&tD[wave * 16 + l15][kk * 32 + l4 * 8]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 gT = *reinterpret_cast<const bf16x8*>(&gsT[dt * 16 + l15][kk * 32 + l4 * 8]);
+        const bf16x8 qT = *reinterpret_cast<const bf16x8*>(&qsT[dt * 16 + l15][kk * 32 + l4 * 8]);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, gT, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, qT, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = k0 + wave * 16 + l4 * 4 + e;
+      if (key < T) {
+        g32[(row0 + key) * nqkv + (nq + j) * 64 + dt * 16 + l15] = dk[dt][e];
+        g32[(row0 + key) * nqkv + (nq + nkv + j) * 64 + dt * 16 + l15] = dv[dt][e];
+      }
+    }
 }
 
 // G3 fp32 [M, 3 * nq * 64] = dQ | dK per QUERY head | dV per QUERY head  ->  bf16 [M, (nq + 2 nkv) * 64]: the query heads of
@@ -765,9 +901,12 @@ extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, v
 }
 
 extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
-                                     float* dQ, int64_t ld_dq, const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv,
-                                     int head_dim, float scale, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && PT_bf16 && dST_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+                                     float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp,
+                                     int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+  TCAVT_CHECK_ARG((PT_bf16 != nullptr) == (dST_bf16 != nullptr), "attn_bwd_scores: PT and dST come together");
+  TCAVT_CHECK_ARG(PT_bf16 || stats, "attn_bwd_scores: give PT/dST (GEMM form of dK, dV) or stats (tcavt_attn_bwd_dkv)");
+  TCAVT_CHECK_ARG(aligned16(stats), "attn_bwd_scores: stats must be 16-byte aligned");
   TCAVT_CHECK_ARG(dS_bf16 || dQ, "attn_bwd_scores: give dQ (computed here) or dS (for an external dQ product), or both");
   TCAVT_CHECK_ARG(!dQ || ld_dq >= (int64_t)nq * 64, "attn_bwd_scores: ld_dq must cover nq * 64 columns");
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_scores: head_dim 64 and nq %% nkv == 0 required");
@@ -776,7 +915,21 @@ extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, 
   hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), dQ, (long)ld_dq,
-                     kv_len, T, Tp, nq, nkv, scale);
+                     stats, kv_len, T, Tp, nq, nkv, scale);
   TCAVT_CHECK_LAUNCH("attn_bwd_scores");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* stats, float* g32,
+                                  const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv, int head_dim, float scale,
+                                  tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && stats && g32 && kv_len && B > 0 && T > 0, "attn_bwd_dkv: bad args");
+  TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_dkv: head_dim 64 and nq %% nkv == 0 required");
+  TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_dkv: Tp must be T rounded up to a multiple of 64");
+  TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16) && aligned16(stats), "attn_bwd_dkv: 16-byte alignment required");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((long)B * nkv * (Tp / 64))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
+                     stats, g32, kv_len, T, Tp, nq, nkv, scale);
+  TCAVT_CHECK_LAUNCH("attn_bwd_dkv");
   return TCAVT_OK;
 }

@@ -59,6 +59,15 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     Tp = _rup(T, 64)
     nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
     f32, b16 = torch.float32, torch.bfloat16
+    if scores == "fused":
+        # two MFMA kernels and the pack: query-major (row statistics, dQ), key-major (dK, dV; group sum in registers);
+        # S, dP, P, dS never reach memory
+        g32 = buf("at.g32", (B * T, nqkv), f32)
+        stats = buf("at.stats", (BH * T, 4), f32)
+        ops.attn_bwd_scores(qkv, dO, None, None, None, kv_len, B, T, Tp, nq, nkv, scale, dQ=g32, stats=stats)
+        ops.attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale)
+        ops.rope_bwd_pack(g32, g_qkv, cos, sin, (nq + nkv) * hd, T)
+        return g_qkv
     # zero-initialised once: the kernels never write the key blocks above the causal diagonal
     PT, dST = buf("at.PT", (BH * Tp, Tp), b16, True), buf("at.dST", (BH * Tp, Tp), b16, True)
     qT = buf("at.qT", (nq * hd, B * Tp), b16)
@@ -66,7 +75,7 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     G3 = buf("at.G3", (B * T, 3 * nq * hd), f32)
     k, v = qkv[:, nq * hd:], qkv[:, (nq + nkv) * hd:]
     ld3 = 3 * nq * hd
-    if scores == "fused":  # S, dP and dQ = dS K on the matrix cores inside the softmax-backward kernel; S, dP, dS never stored
+    if scores == "scores+gemm":  # scores kernel (S, dP, dQ inside), dK / dV on the batched GEMM from its P^T, dS^T
         ops.attn_bwd_scores(qkv, dO, None, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=G3)
     else:  # "gemm": every product on the batched GEMM, fp32 S / dP scratch + the tile kernel (cross-check of the fused kernel)
         dS = buf("at.dS", (BH * T, Tp), b16, True)

@@ -497,7 +497,19 @@ def causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale):
                                                stream_ptr()), "tcavt_causal_softmax_bwd_tiles")
 
 
-def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None):
+def attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale):
+    """dK, dV of the causal GQA attention (key-major MFMA kernel) into the k / v columns of g32 (fp32, q|k|v layout)."""
+    ncols = (nq + 2 * nkv) * 64
+    for t, dt, n, nm in ((qkv, torch.bfloat16, B * T * ncols, "qkv"), (dO, torch.bfloat16, B * T * nq * 64, "dO"),
+                         (stats, torch.float32, B * nq * T * 4, "stats"), (g32, torch.float32, B * T * ncols, "g32")):
+        if t.dtype != dt or (not t.is_cuda and not _ALLOW_CPU) or _avail(t) < n:
+            raise capi.TcavtError(f"attn_bwd_dkv.{nm}: {dt} GPU buffer with {n} elements required")
+    _need(kv_len, B, "attn_bwd_dkv.kv_len")
+    check(lib().tcavt_attn_bwd_dkv(ptr(qkv), ptr(dO), ptr(stats), ptr(g32), ptr(kv_len), B, T, Tp, nq, nkv, 64, scale,
+                                   stream_ptr()), "tcavt_attn_bwd_dkv")
+
+
+def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None, stats=None):
     """Scores + softmax backward in one kernel (MFMA inside): P^T, dS^T (zero-initialised once), plus dQ = dS K (fp32
     [B*T, >= nq*64], any leading dimension) computed in place and / or the row-major dS for an external dQ product."""
     rows, ncols = B * nq * T, (nq + 2 * nkv) * 64
@@ -506,16 +518,20 @@ def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=N
             raise capi.TcavtError("attn_bwd_scores.dQ: fp32 [B*T, >= nq*64] required")
     for t, n, nm in ((qkv, B * T * ncols, "qkv"), (dO, B * T * nq * 64, "dO"), (dS, rows * Tp, "dS"),
                      (PT, B * nq * Tp * Tp, "PT"), (dST, B * nq * Tp * Tp, "dST")):
-        if t is None and nm == "dS" and dQ is not None:
+        if t is None and ((nm == "dS" and dQ is not None) or (nm in ("PT", "dST") and stats is not None)):
             continue
         if t.dtype != torch.bfloat16 or (not t.is_cuda and not _ALLOW_CPU):
             raise capi.TcavtError(f"attn_bwd_scores.{nm}: bf16 GPU tensor required")
         if _avail(t) < n:
             raise capi.TcavtError(f"attn_bwd_scores.{nm}: buffer too small")
     _need(kv_len, B, "attn_bwd_scores.kv_len")
-    check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), ptr(dS) if dS is not None else None, ptr(PT), ptr(dST),
-                                      ptr(dQ) if dQ is not None else None, dQ.stride(0) if dQ is not None else 0, ptr(kv_len),
-                                      B, T, Tp, nq, nkv, 64, scale, stream_ptr()), "tcavt_attn_bwd_scores")
+    if stats is not None:
+        _req(stats, torch.float32, "attn_bwd_scores.stats")
+        _need(stats, rows * 4, "attn_bwd_scores.stats")
+    opt = lambda t: ptr(t) if t is not None else None
+    check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), opt(dS), opt(PT), opt(dST), opt(dQ),
+                                      dQ.stride(0) if dQ is not None else 0, opt(stats), ptr(kv_len), B, T, Tp, nq, nkv, 64,
+                                      scale, stream_ptr()), "tcavt_attn_bwd_scores")
 
 
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
