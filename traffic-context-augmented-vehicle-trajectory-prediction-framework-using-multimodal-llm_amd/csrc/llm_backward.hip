@@ -2,9 +2,9 @@
 // modify_scripts/modify_train.py:512-528 trains lora_A / lora_B of q_proj, v_proj while every base weight stays frozen):
 // the activation gradient walks back through all layers -- dgrad GEMMs against transposed copies of the frozen
 // weights (gemm_bf16.hip), and the pointwise / row / attention pieces here.
-// Attention backward: attn_bwd_scores_kernel (scores on the matrix cores + softmax backward, writes dS, P^T, dS^T) followed by
-// three batched MFMA products (llm_backward.attn_bwd_composed); attn_causal_gqa_bwd_kernel below is the scalar-FMA
-// cross-check of that composition, not a product path.
+// Attention backward: attn_bwd_scores_kernel (query-major: row statistics, dQ) + attn_bwd_dkv_kernel (key-major: dK, dV),
+// both on the matrix cores, nothing of S / P / dS stored; the GEMM-composed forms (llm_backward.attn_bwd_composed) and the
+// scalar-FMA attn_causal_gqa_bwd_kernel are cross-checks, not product paths.
 #include "common.hpp"
 #include "philox.hpp"
 

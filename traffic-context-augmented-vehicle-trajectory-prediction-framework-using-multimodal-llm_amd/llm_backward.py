@@ -44,7 +44,9 @@ def lora_named_parameters(model):
 
 
 def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv, scores="fused"):
-    """Backward of the causal grouped-query attention as five batched MFMA products around one row kernel.
+    """Backward of the causal grouped-query attention.  scores="fused" (the product path): two MFMA kernels + the RoPE
+    pack; "scores+gemm" / "gemm": the same mathematics with dK, dV (or all five products) on the batched MFMA GEMM around
+    a row kernel -- kept as cross-checks.
     qkv: the forward's rotated q|k|v, bf16, rows B*T (+ >= 63 readable pad rows: the score products address keys up to
     the next multiple of 64); dO bf16 [B*T, nq*64]; g_qkv (out) bf16 [B*T, (nq+2nkv)*64] = gradient of the
     projections' outputs (RoPE undone).  buf(name, shape, dtype, zero=False) hands out reusable scratch (zero: zero-filled
