@@ -86,7 +86,8 @@ def test_training_step_call_sequence_passes_host_guards(dry, lora_trainable):
     assert dry.calls.count("tcavt_adamw") == 1
     assert dry.calls.count("tcavt_attn_bwd_scores") == (L if lora_trainable else 0)
     assert dry.calls.count("tcavt_silu_mul_bwd") == (L if lora_trainable else 0)
-    assert dry.calls.count("tcavt_gqa_rope_bwd_pack") == (L if lora_trainable else 0)
+    assert dry.calls.count("tcavt_attn_bwd_dkv") == (L if lora_trainable else 0)
+    assert dry.calls.count("tcavt_rope_bwd_pack") == (L if lora_trainable else 0)
     assert dry.calls.count("tcavt_rmsnorm_bwd") == (2 * L if lora_trainable else 0)  # final norm + two per layer, none below layer 0
     if lora_trainable:
         assert m.mllm.llama_wrapper.tape is not None and len(m.mllm.llama_wrapper.tape.layers) == L
