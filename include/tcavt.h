@@ -372,6 +372,9 @@ int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* s
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);
+/* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192): g *= min(1, max_norm / (||g|| + 1e-6)),
+   fixed summation order, no host synchronisation; scratch: >= 1026 floats (scratch[1024] = the factor, [1025] = the norm) */
+int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float* scratch, tcavt_stream_t stream);
 /* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
 int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
                         float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);

@@ -301,3 +301,26 @@ def test_silu_epilogue_saves_preactivations(gpu, M, N, K):
     torch.cuda.synchronize()
     assert torch.equal(act, ref_act)
     assert rel_err(pre.float().cpu(), plain.float().cpu()) < 1e-3  # same products; tile forms may order the K sum differently
+
+
+@pytest.mark.parametrize("scale", [1e-3, 3.0])
+def test_clip_grad_norm(gpu, scale):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(9)
+    v = (torch.randn(1_234_567, generator=g) * scale / 1000.0)
+    p = torch.nn.Parameter(torch.zeros_like(v))
+    p.grad = v.clone()
+    norm = torch.nn.utils.clip_grad_norm_([p], 1.0)
+    gd = v.to(dev)
+    scratch = torch.zeros(1026, dtype=torch.float32, device=dev)
+    ops.clip_grad_norm(gd, 1.0, scratch)
+    norm64 = v.double().norm().item()  # (fp32 sums of 1.2 M squares differ by ~1e-5 between any two orders)
+    assert abs(scratch[1025].item() - norm64) / norm64 < 2e-5 and abs(norm.item() - norm64) / norm64 < 1e-4
+    assert rel_err(gd.cpu(), p.grad) < 1e-4
+    want = v.double() * min(1.0, 1.0 / (norm64 + 1e-6))
+    assert rel_err(gd.cpu().double(), want) < 2e-5
+    again = v.to(dev)
+    ops.clip_grad_norm(again, 1.0, scratch)
+    assert torch.equal(again, gd)  # fixed summation order: bit-reproducible

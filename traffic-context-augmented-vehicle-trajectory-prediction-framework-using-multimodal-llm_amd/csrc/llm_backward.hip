@@ -796,6 +796,40 @@ __global__ __launch_bounds__(256) void gqa_rope_bwd_pack_kernel(const float* __r
   out[row * (heads * 64L) + oh * 64 + w + 32] = f32_to_bf16(o2);
 }
 
+
+// ---------------------------------------------------------------------------
+// torch.nn.utils.clip_grad_norm_(params, max_norm) on the flat gradient vector (modify_scripts/modify_train.py:1192), without
+// a host round trip and with a fixed summation order: 1024 block partials of sum(g^2), one block adds them in index order
+// and leaves  min(1, max_norm / (norm + 1e-6))  in scratch[1024] (norm in scratch[1025]), a third launch scales g.
+// ---------------------------------------------------------------------------
+constexpr int CLIP_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const long per = (n + CLIP_BLOCKS - 1) / CLIP_BLOCKS;
+  const long lo = (long)blockIdx.x * per, hi = min(lo + per, n);
+  float a = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) a = fmaf(g[i], g[i], a);
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void clip_scale_kernel(float* __restrict__ part, float max_norm) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 64) a += part[i];  // lane l: partials l, l + 64, ... in order
+  a = wave_sum(a);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(a);
+    part[CLIP_BLOCKS] = fminf(1.f, max_norm / (norm + 1e-6f));
+    part[CLIP_BLOCKS + 1] = norm;
+  }
+}
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ g, long n, const float* __restrict__ scale) {
+  const float sc = *scale;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= sc;
+}
+
 static size_t attn_bwd_lds(int T) {
   return (size_t)2 * AB_QB * T * 4 + (size_t)2 * AB_QB * (AB_HD + 1) * 4 + (size_t)2 * T * AB_LDK * 2;
 }
@@ -931,5 +965,17 @@ extern "C" int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, con
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      stats, g32, kv_len, T, Tp, nq, nkv, scale);
   TCAVT_CHECK_LAUNCH("attn_bwd_dkv");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float* scratch, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(g && scratch && n > 0 && max_norm > 0.f, "clip_grad_norm: bad args");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, st, g, (long)n, scratch);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, st, scratch, max_norm);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, (long)n, scratch + CLIP_BLOCKS);
+  TCAVT_CHECK_LAUNCH("clip_grad_norm");
   return TCAVT_OK;
 }

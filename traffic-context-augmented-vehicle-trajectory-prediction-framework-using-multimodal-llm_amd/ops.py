@@ -624,6 +624,15 @@ def masked_mean_bwd(gemb, lens, genc, B, P, D):
     check(lib().tcavt_masked_mean_bwd(ptr(gemb), ptr(lens), ptr(genc), B, P, D, stream_ptr()), "tcavt_masked_mean_bwd")
 
 
+def clip_grad_norm(g, max_norm, scratch):
+    """In-place clip of the flat gradient vector to max_norm (torch.nn.utils.clip_grad_norm_ semantics); scratch: fp32,
+    >= 1026 elements; afterwards scratch[1025] holds the norm before clipping, scratch[1024] the factor applied."""
+    _req(g, torch.float32, "clip_grad_norm.g")
+    _req(scratch, torch.float32, "clip_grad_norm.scratch")
+    _need(scratch, 1026, "clip_grad_norm.scratch")
+    check(lib().tcavt_clip_grad_norm(ptr(g), g.numel(), float(max_norm), ptr(scratch), stream_ptr()), "tcavt_clip_grad_norm")
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     n = p.numel()
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):

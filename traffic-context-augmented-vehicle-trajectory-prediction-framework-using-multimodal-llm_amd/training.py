@@ -149,10 +149,10 @@ class Trainer:
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_(trainable, max_norm) (modify_train.py:1192) on the flat gradient vector,
         without a host synchronisation."""
-        g = self.book.grads
-        norm = torch.linalg.vector_norm(g)
-        g.mul_(torch.clamp(max_norm / (norm + 1e-6), max=1.0))
-        return norm
+        if getattr(self, "_clip_scratch", None) is None:
+            self._clip_scratch = torch.zeros(1026, dtype=torch.float32, device=self.book.grads.device)
+        ops.clip_grad_norm(self.book.grads, max_norm, self._clip_scratch)
+        return self._clip_scratch[1025]  # the norm before clipping (device scalar)
 
     def optimizer_step(self):
         m = self.model
