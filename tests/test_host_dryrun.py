@@ -91,3 +91,12 @@ def test_training_step_call_sequence_passes_host_guards(dry, lora_trainable):
     assert dry.calls.count("tcavt_rmsnorm_bwd") == (2 * L if lora_trainable else 0)  # final norm + two per layer, none below layer 0
     if lora_trainable:
         assert m.mllm.llama_wrapper.tape is not None and len(m.mllm.llama_wrapper.tape.layers) == L
+
+
+def test_lora_trainable_needs_adapters(dry):
+    from tcavt_amd import model, training
+
+    cfg, weights, _ = load_case("tiny_18_30_nolora_ragged")
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights).eval()
+    with pytest.raises(ValueError, match="no LoRA adapters"):
+        training.Trainer(m, lora_trainable=True)

@@ -42,6 +42,8 @@ class Trainer:
         self.max_grad_norm = max_grad_norm
         n_frozen_variant = len(named)
         if self.lora_trainable:
+            if not model.mllm.llama_wrapper.use_lora:
+                raise ValueError("Trainer(lora_trainable=True): the model has no LoRA adapters (use_lora=False)")
             lora = lora_named_parameters(model)
             for _, p in lora:
                 p.requires_grad_(True)
