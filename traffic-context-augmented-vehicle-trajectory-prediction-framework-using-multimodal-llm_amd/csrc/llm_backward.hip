@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
 // Scores on the matrix cores, fused with the softmax backward (the production form of the middle of the attention
 // backward): one workgroup per (sample, query head, block of 64 queries); wave w owns 16 query rows and computes its
 // 16 x 64 tiles of  S = q K^T  and  dP = dO V^T  with v_mfma_f32_16x16x32_bf16 (q, dO rows are the A fragments, held in
-// registers; K / V blocks are staged through LDS one block ahead and give the B fragments), in three sweeps over the key blocks at
-// or below the diagonal: row maxima; row sums and sum(P dP); then P and dS, which leave through LDS tiles as dS row-major
+// registers; K / V blocks are staged through LDS one block ahead and give the B fragments), in two sweeps over the key blocks at
+// or below the diagonal: row maxima, row sums and sum(P dP) (online softmax); then P and dS, which leave through LDS tiles as dS row-major
 // and P^T, dS^T (as causal_softmax_bwd_tiles_kernel).  S and dP never exist in memory.
 // D[m][n] of the MFMA sits in lane l as m = 4 (l >> 4) + e, n = l & 15.
 // ---------------------------------------------------------------------------
@@ -418,11 +418,11 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
                                                               int Tp, int nq, int nkv, float scale) {
   // stats (optional, fp32 [B*nq*T, 4]): row maximum of the scaled scores, 1 / row sum, sum(P dP) -- what
   // attn_bwd_dkv_kernel needs to rebuild P and dS for its key block.  PT / dST (optional): only for the GEMM form of dK, dV.
-  // dQ (optional, fp32 [B*T, ld_dq], head h at columns 64 h): dQ = dS K accumulated over the key blocks inside the third
+  // dQ (optional, fp32 [B*T, ld_dq], head h at columns 64 h): dQ = dS K accumulated over the key blocks inside the last
   // sweep (A = the dS tile in LDS, B = a transposed copy of the K block); dS (optional): the row-major copy for an
   // external dQ product.
   __shared__ bf16_t tP[64][66], tD[64][66];
-  __shared__ __attribute__((aligned(16))) bf16_t ksT[64][72];  // K block transposed [d][key] (third sweep, dQ only)
+  __shared__ __attribute__((aligned(16))) bf16_t ksT[64][72];  // K block transposed [d][key] (last sweep, dQ only)
   const int nqb = Tp >> 6;
   const int qb = blockIdx.x % nqb;
   const long bh = blockIdx.x / nqb;
@@ -522,32 +522,38 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
     }
     return v;
   };
+  // first sweep: row maximum, row sum and sum(P dP) in ONE pass -- every lane runs an online softmax over the keys it sees
+  // (its own running maximum; sums rescaled when it moves), the 16 lanes of a row are merged afterwards
   float m[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
-  sweep(false, [&](int kb, f32x4 (&sa)[4], f32x4 (&)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int key = kb * 64 + t * 16 + l15;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (key < nv[e]) m[e] = fmaxf(m[e], sa[t][e]);
-    }
-  });
-#pragma unroll
-  for (int e = 0; e < 4; ++e) m[e] = group16(m[e], true);
   float sum[4] = {0.f, 0.f, 0.f, 0.f}, dot[4] = {0.f, 0.f, 0.f, 0.f};
   sweep(true, [&](int kb, f32x4 (&sa)[4], f32x4 (&da)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int key = kb * 64 + t * 16 + l15;
+    for (int e = 0; e < 4; ++e) {
+      float tm = m[e];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (key < nv[e]) {
-          const float ex = __expf(sa[t][e] - m[e]);
+      for (int t = 0; t < 4; ++t)
+        if (kb * 64 + t * 16 + l15 < nv[e]) tm = fmaxf(tm, sa[t][e]);
+      const float resc = __expf(m[e] - tm);  // 1 when the maximum did not move; 0 * 0 on the first valid key
+      sum[e] *= resc;
+      dot[e] *= resc;
+      m[e] = tm;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (kb * 64 + t * 16 + l15 < nv[e]) {
+          const float ex = __expf(sa[t][e] - tm);
           sum[e] += ex;
           dot[e] = fmaf(ex, da[t][e], dot[e]);
         }
     }
   });
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float mr = group16(m[e], true);
+    const float resc = __expf(m[e] - mr);
+    sum[e] *= resc;
+    dot[e] *= resc;
+    m[e] = mr;
+  }
   float inv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
