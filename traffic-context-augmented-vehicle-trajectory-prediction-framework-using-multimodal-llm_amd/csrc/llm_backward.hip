@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
   // global memory put every lane on its own cache line: 64 address cycles per load, 372 us per launch.
   __shared__ __attribute__((aligned(16))) bf16_t ks[64][72], vs[64][72];
   const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 16;
+  // transposed staging: the four threads of a source row write rows 16 apart, i.e. the same bank; the 16-byte column
+  // chunk is therefore XOR-ed with the row's 16-block (= threadIdx.x & 3 for the writer, dt for the reader)
+  const int tcol = (((srow >> 3) ^ (threadIdx.x & 3)) << 3) | (srow & 7);
   const bf16_t* kbase = qkv + (nq + j) * 64 + sch;
   const bf16_t* vbase = qkv + (nq + nkv + j) * 64 + sch;
   u32x4 kreg[2], vreg[2];
@@ -475,8 +478,8 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          ksT[sch + c * 8 + 2 * e][srow] = (bf16_t)(kreg[c][e] & 0xffffu);
-          ksT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(kreg[c][e] >> 16);
+          ksT[sch + c * 8 + 2 * e][tcol] = (bf16_t)(kreg[c][e] & 0xffffu);
+          ksT[sch + c * 8 + 2 * e + 1][tcol] = (bf16_t)(kreg[c][e] >> 16);
         }
     }
     if (want_v) {
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
         const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&ksT[dt * 16 + l15][kk * 32 + l4 * 8]);
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&ksT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
           dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, dq[dt], 0, 0, 0);
         }
       }
@@ -672,6 +675,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 16;
+  const int tcol = (((srow >> 3) ^ (threadIdx.x & 3)) << 3) | (srow & 7);  // XOR-swizzled column of the transposed copies
   const int nit = grp * (nkb - kb);
   u32x4 qreg[2], greg[2];
   auto fetch = [&](int it) {
@@ -695,10 +699,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        qsT[sch + c * 8 + 2 * e][srow] = (bf16_t)(qreg[c][e] & 0xffffu);
-        qsT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(qreg[c][e] >> 16);
-        gsT[sch + c * 8 + 2 * e][srow] = (bf16_t)(greg[c][e] & 0xffffu);
-        gsT[sch + c * 8 + 2 * e + 1][srow] = (bf16_t)(greg[c][e] >> 16);
+        qsT[sch + c * 8 + 2 * e][tcol] = (bf16_t)(qreg[c][e] & 0xffffu);
+        qsT[sch + c * 8 + 2 * e + 1][tcol] = (bf16_t)(qreg[c][e] >> 16);
+        gsT[sch + c * 8 + 2 * e][tcol] = (bf16_t)(greg[c][e] & 0xffffu);
+        gsT[sch + c * 8 + 2 * e + 1][tcol] = (bf16_t)(greg[c][e] >> 16);
       }
     if (threadIdx.x < 64) {
       const int i = q0 + threadIdx.x;
@@ -744,8 +748,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const bf16x8 df = *reinterpret_cast<const bf16x8*>(&tD[wave * 16 + l15][kk * 32 + l4 * 8]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 gT = *reinterpret_cast<const bf16x8*>(&gsT[dt * 16 + l15][kk * 32 + l4 * 8]);
-        const bf16x8 qT = *reinterpret_cast<const bf16x8*>(&qsT[dt * 16 + l15][kk * 32 + l4 * 8]);
+        const bf16x8 gT = *reinterpret_cast<const bf16x8*>(&gsT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
+        const bf16x8 qT = *reinterpret_cast<const bf16x8*>(&qsT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
         dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, gT, dv[dt], 0, 0, 0);
         dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, qT, dk[dt], 0, 0, 0);
       }
