@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
 // and P^T, dS^T (as causal_softmax_bwd_tiles_kernel).  S and dP never exist in memory.
 // D[m][n] of the MFMA sits in lane l as m = 4 (l >> 4) + e, n = l & 15.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
                                                               bf16_t* __restrict__ dST, float* __restrict__ dQ, long ld_dq,
                                                               float* __restrict__ stats, const int* __restrict__ kv_len, int T,
@@ -644,11 +644,15 @@ __global__ __launch_bounds__(256) void attn_bwd_scores_kernel(const bf16_t* __re
 // tile (accumulator layout -> A-fragment layout), and  dV += P^T dO,  dK += dS^T q  accumulate in registers over all of
 // it -- the group sum included.  Written once, fp32, into the k / v columns of the q|k|v-layout gradient.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ stats, float* __restrict__ g32,
                                                            const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
                                                            float scale) {
-  __shared__ __attribute__((aligned(16))) bf16_t qs[64][72], gs[64][72], qsT[64][72], gsT[64][72], tP[64][72], tD[64][72];
+  // (tP / tD, the P^T / dS^T tiles, reuse the storage of the row-major Q / dO blocks: one more barrier per iteration, 37 KB
+  //  instead of 55 KB of LDS, three workgroups per CU instead of two)
+  __shared__ __attribute__((aligned(16))) bf16_t qs[64][72], gs[64][72], qsT[64][72], gsT[64][72];
+  bf16_t (*tP)[72] = qs;
+  bf16_t (*tD)[72] = gs;
   __shared__ float st_m[64], st_inv[64], st_dot[64];
   __shared__ int st_nv[64];
   const int nkb = Tp >> 6;
@@ -717,6 +721,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     }
     __syncthreads();
     if (it + 1 < nit) fetch(it + 1);
+    f32x4 sT[4], dT[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {  // 16 keys of this wave x 16 queries
       f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
@@ -727,6 +732,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf, sacc, 0, 0, 0);
         dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kk], gf, dacc, 0, 0, 0);
       }
+      sT[t] = sacc;
+      dT[t] = dacc;
+    }
+    __syncthreads();  // every wave has read the row-major Q / dO blocks: their storage becomes the P^T / dS^T tiles
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 sacc = sT[t], dacc = dT[t];
       const int qi = t * 16 + l15;  // D[m][n]: m = key 4 l4 + e of the wave's 16, n = query qi
       const float qm = st_m[qi], qinv = st_inv[qi], qdot = st_dot[qi];
       const int qnv = st_nv[qi];
