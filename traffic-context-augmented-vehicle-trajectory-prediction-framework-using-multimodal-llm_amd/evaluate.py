@@ -102,6 +102,8 @@ def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_drop
     from . import ops
 
     was_training = model.training
+    lw = model.mllm.llama_wrapper
+    was_saving, lw.save_for_backward = lw.save_for_backward, False  # (LoRA-trainable training keeps a decoder tape; evaluation needs none)
     model.train(bool(mc_dropout))
     dev = next(model.parameters()).device
     sums = torch.zeros(5, dtype=torch.float32, device=dev)
@@ -129,6 +131,7 @@ def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_drop
                 n += B
     finally:  # also on errors: leave the caller's train/eval mode and no stale MLLM cache behind
         model._llm_cache = None
+        lw.save_for_backward = was_saving
         model.train(was_training)
     stats = torch.cat([sums[2:5].double(), torch.tensor([float(n)], dtype=torch.float64, device=dev)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
