@@ -1,6 +1,6 @@
-"""Full-size parity of the LoRA-trainable backward (Llama-3.2-1B shape, L = 256): the HIP path's adapter gradients for a few
+"""Full-size gradient parity (train.py parameter set and the LoRA adapters of the LoRA-trainable variant) (Llama-3.2-1B shape, L = 256): the HIP path's adapter gradients for a few
 synthetic samples against torch autograd through the oracle (bf16 contract and fp32), same host-generated weights.
-Prints one JSON object; the numbers are quoted in DESIGN.md.   usage: tools/parity_lora_full.py [samples=2]"""
+Prints one JSON object; the numbers are quoted in DESIGN.md.   usage: tools/parity_grads_full.py [samples=2]"""
 import json
 import os
 import sys
@@ -35,11 +35,13 @@ loss, _ = tr.forward_backward(g["traj_emb"], g["vision_emb"], g["lane_polygon"],
                               g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"])
 torch.cuda.synchronize()
 keys = [k for k in W if ".lora_A." in k or ".lora_B." in k]
-got = {k: tr.book.g[k].detach().float().cpu() for k in keys}
-res = {"samples": B, "L": cfg.q_num_query_tokens + 240, "hip_loss": float(loss.item()), "adapter_tensors": len(keys)}
+base = [k for k in W if not k.startswith("mllm.")]  # the train.py trainable set (LTSF + lane-polygon encoder)
+got = {k: tr.book.g[k].detach().float().cpu() for k in keys + base}
+res = {"samples": B, "L": cfg.q_num_query_tokens + 240, "hip_loss": float(loss.item()), "adapter_tensors": len(keys),
+       "train_py_tensors": len(base)}
 for contract in ("bf16", "fp32"):
     Wc = {k: v.detach().clone() for k, v in W.items()}
-    for k in keys:
+    for k in keys + base:
         Wc[k].requires_grad_(True)
     t1 = time.time()
     ref_loss, _ = O.model_forward(Wc, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
@@ -47,11 +49,15 @@ for contract in ("bf16", "fp32"):
                                   contract=contract)
     ref_loss.backward()
     print(f"[parity] oracle ({contract}) forward + backward in {time.time() - t1:.1f} s", file=sys.stderr, flush=True)
-    fr = torch.cat([Wc[k].grad.reshape(-1).double() for k in keys])
-    fg = torch.cat([got[k].reshape(-1).double() for k in keys])
-    per = sorted(((got[k].double() - Wc[k].grad.double()).norm() / Wc[k].grad.double().norm()).item() for k in keys)
-    res[contract] = {"oracle_loss": float(ref_loss.item()), "flat_rel_err": ((fg - fr).norm() / fr.norm()).item(),
-                     "cosine": (fg @ fr / (fg.norm() * fr.norm())).item(), "per_tensor_rel_err_median": per[len(per) // 2],
-                     "per_tensor_rel_err_max": per[-1], "grad_norm": fr.norm().item()}
+    res[contract] = {"oracle_loss": float(ref_loss.item())}
+    for name, ks in (("adapters", keys), ("train_py_set", base)):
+        ks = [k for k in ks if Wc[k].grad is not None and Wc[k].grad.abs().max() > 0]
+        fr = torch.cat([Wc[k].grad.reshape(-1).double() for k in ks])
+        fg = torch.cat([got[k].reshape(-1).double() for k in ks])
+        per = sorted(((got[k].double() - Wc[k].grad.double()).norm() / Wc[k].grad.double().norm()).item() for k in ks)
+        res[contract][name] = {"flat_rel_err": ((fg - fr).norm() / fr.norm()).item(),
+                               "cosine": (fg @ fr / (fg.norm() * fr.norm())).item(),
+                               "per_tensor_rel_err_median": per[len(per) // 2], "per_tensor_rel_err_max": per[-1],
+                               "grad_norm": fr.norm().item(), "tensors": len(ks)}
     del Wc
 print(json.dumps(res, indent=1))
