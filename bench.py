@@ -62,7 +62,14 @@ def parse():
     ap.add_argument("--no-lora", action="store_true")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8,
+                    help="samples in the CPU-baseline pass (SURVEY 8d asks for 32 or the largest that fits; 8 keeps the default "
+                         "run within a few minutes -- the B=32 figure is recorded in DESIGN.md)")
+    ap.add_argument("--cpu-warm", type=int, default=3)
+    ap.add_argument("--cpu-timed", type=int, default=5)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercises the rank plumbing only (process group, barrier, max-over-ranks, JSON line); "
+                         "use with --backend gloo on a CPU box")
     ap.add_argument("--launch", choices=["eager", "graph"], default="eager",
                     help="eager (default): the host enqueues every step; it runs a whole decoder (15 ms) ahead of the "
                          "GPU, and the side streams of the forward / backward overlap as written.  graph: replay of a "
@@ -150,7 +157,8 @@ def cpu_baseline(cfg, args, gpu_decoded=None, W=None):
             return loss
 
     def timed(labels, n):
-        run(labels)  # warm
+        for _ in range(max(1, args.cpu_warm)):
+            run(labels)  # warm
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
@@ -160,8 +168,8 @@ def cpu_baseline(cfg, args, gpu_decoded=None, W=None):
         ts.sort()
         return ts[len(ts) // 2]
 
-    same_work = timed(None, 3)
-    faithful = timed(t["labels"], 2)
+    same_work = timed(None, max(1, args.cpu_timed))
+    faithful = timed(t["labels"], max(1, args.cpu_timed))
     parity = None
     if gpu_decoded is not None:
         with torch.no_grad():
@@ -193,20 +201,62 @@ def cpu_baseline(cfg, args, gpu_decoded=None, W=None):
         "value": round(args.cpu_batch / same_work, 4), "unit": "trajectories/sec", "cores": cores, "kind": "port",
         "sample": f"{args.cpu_batch} samples of the same workload (L={16 + args.text_len}, fp32, torch CPU ops"
                   f"{', forward + autograd backward of the trainable part' if train else ''}), "
-                  f"median of 3 after 1 warm-up; same work as the GPU path (no lm_head/CE, no optimizer step)",
+                  f"median of {max(1, args.cpu_timed)} timed passes after {max(1, args.cpu_warm)} warm-up passes (SURVEY 8d protocol); "
+                  f"same work as the GPU path (no lm_head/CE, no optimizer step)",
         "reference_faithful_value": round(args.cpu_batch / faithful, 4),
         "reference_faithful_note": "adds the lm_head + cross-entropy the reference computes and discards (train.py:547-554)",
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a torchrun environment: start N fresh ranks (one process per GPU, reference
+    scripts/train.py:1044-1049 `mp.spawn(train_ddp, nprocs=world_size)`) as children of this process, which has not
+    touched the GPU, and pass rank 0's JSON line through.  Never re-exec: the children are new interpreters."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"spawning {args.gpus} ranks: {' '.join(cmd)}")
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+def dry_run(args, rank, world):
+    """Rank plumbing without a GPU: barrier, a timed region, MAX over ranks, one JSON line from rank 0."""
+    dist.barrier() if world > 1 else None
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "trajectories/sec", "value": None, "unit": "trajectories/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                          "max_rank_elapsed_s": round(el.item(), 4),
+                          "config": {"per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                                     "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     ndev = torch.cuda.device_count()

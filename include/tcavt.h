@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* tcavt_stream_t; /* hipStream_t */
 
-#define TCAVT_ABI_VERSION 1
+#define TCAVT_ABI_VERSION 2
 
 #define TCAVT_OK 0
 #define TCAVT_ERR_ARG 1  /* shape / alignment / null-pointer contract violated */
@@ -99,10 +99,9 @@ typedef struct tcavt_gemm_args {
   int32_t tile;                  /* 0 = auto (recommended).  Forcing a kernel form (all forms give bit-identical results):
                                     64 / 128 = small-launch kernels (4-stage pipeline), 256 = 8-wave 256x256,
                                     257 = 4-wave 256x256 (whole tiles only), 271 = 4-wave 256x192 (N % 192 == 0),
-                                    272 = 4-wave two-barrier deep-prefetch form (long K); other codes in [124,127] and
-                                    [250,270] are measured-and-rejected variants kept for A/B runs (csrc/gemm_bf16.hip);
-                                    261-267 are timing-only experiments and are refused unless
-                                    TCAVT_GEMM_TIMING_EXPERIMENTS is set */
+                                    272 = 4-wave two-barrier deep-prefetch form (long K).  Any other code is refused by
+                                    the product library (measured-and-rejected variants and timing experiments live in
+                                    the -DTCAVT_EXPERIMENTS build that tools/ makes for itself) */
   float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */
   int32_t in_dtype;              /* operand type of A/W/A2/W2: 0 or TCAVT_BF16, or TCAVT_F16 (generic epilogue only) */
   /* Batched form (generic epilogue only): batch > 1 runs `batch` independent products; product i uses
@@ -372,9 +371,12 @@ int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* s
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);
-/* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192): g *= min(1, max_norm / (||g|| + 1e-6)),
-   fixed summation order, no host synchronisation; scratch: >= 1026 floats (scratch[1024] = the factor, [1025] = the norm) */
-int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float* scratch, tcavt_stream_t stream);
+/* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192):
+     g *= grad_scale;  g *= min(1, max_norm / (||g|| + 1e-6))
+   grad_scale = 1 / world turns a SUM-all-reduced data-parallel gradient into the DDP-averaged one the reference clips
+   (pass grad_scale = 1 to tcavt_adamw afterwards).  Fixed summation order, no host synchronisation; scratch: >= 1026
+   floats (scratch[1024] = the total factor applied, [1025] = the norm of the scaled gradient before clipping) */
+int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float grad_scale, float* scratch, tcavt_stream_t stream);
 /* nn.LayerNorm backward; x is the LayerNorm input; ggamma / gbeta are ACCUMULATED (zero them first) */
 int tcavt_layernorm_bwd(const float* x, const float* gamma, const float* gy, float eps, float* gx,
                         float* ggamma, float* gbeta, int M, int D, tcavt_stream_t stream);
@@ -410,6 +412,16 @@ int tcavt_masked_mean_bwd(const float* gemb, const int32_t* len, float* genc, in
 /* torch.optim.AdamW step over a flat fp32 vector; grad_scale multiplies g first (1/world for DP mean) */
 int tcavt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, float grad_scale, tcavt_stream_t stream);
+
+/* tcavt_adamw gated on a finite loss, as the LoRA-trainable loop does (modify_scripts/modify_train.py:1190-1196:
+ * `if torch.isfinite(loss): clip; optimizer.step()  else: skip`), decided on the device: the update is skipped when
+ * *loss (device fp32 scalar) is not finite -- or, if grad_norm != NULL (e.g. scratch + 1025 of tcavt_clip_grad_norm),
+ * when the exchanged gradient's norm is not finite, which keeps data-parallel ranks in step where the reference's
+ * rank-local test would not.  The optimizer's step count lives on the device: ctl int32[8], zero-initialised by the
+ * caller once; ctl[0] = applied updates so far, ctl[1] = skipped updates, ctl[2] = 1 if this call was skipped. */
+int tcavt_adamw_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float grad_scale, const float* loss, const float* grad_norm,
+                      int32_t* ctl, tcavt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -83,7 +83,9 @@ def test_training_step_call_sequence_passes_host_guards(dry, lora_trainable):
                             t["norm_stat"], t["input_ids"], t["attention_mask"], t["labels"])
     assert decoded.shape == (t["traj_emb"].shape[0], 2, cfg.out_len)
     L = cfg.llama.layers
-    assert dry.calls.count("tcavt_adamw") == 1
+    # the LoRA-trainable loop gates the update on a finite loss on the device (modify_train.py:1190-1196)
+    assert dry.calls.count("tcavt_adamw_gated" if lora_trainable else "tcavt_adamw") == 1
+    assert dry.calls.count("tcavt_adamw" if lora_trainable else "tcavt_adamw_gated") == 0
     assert dry.calls.count("tcavt_attn_bwd_scores") == (L if lora_trainable else 0)
     assert dry.calls.count("tcavt_silu_mul_bwd") == (L if lora_trainable else 0)
     assert dry.calls.count("tcavt_attn_bwd_dkv") == (L if lora_trainable else 0)

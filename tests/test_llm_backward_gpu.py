@@ -324,3 +324,56 @@ def test_clip_grad_norm(gpu, scale):
     again = v.to(dev)
     ops.clip_grad_norm(again, 1.0, scratch)
     assert torch.equal(again, gd)  # fixed summation order: bit-reproducible
+
+
+def test_clip_grad_norm_of_the_dp_mean(gpu):
+    """Data parallel: buckets are SUM-all-reduced, the reference clips DDP's MEAN (modify_train.py:1192 after the averaging
+    all-reduce).  clip(grad_scale = 1 / world) on the summed gradient == clip_grad_norm_ on the mean."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(11)
+    world = 4
+    mean = torch.randn(500_000, generator=g) * 3e-3  # norm ~ 2.1 > 1: clipped; the SUM's norm is 4x that
+    p = torch.nn.Parameter(torch.zeros_like(mean))
+    p.grad = mean.clone()
+    torch.nn.utils.clip_grad_norm_([p], 1.0)
+    summed = (mean * world).to(dev)
+    scratch = torch.zeros(1026, dtype=torch.float32, device=dev)
+    ops.clip_grad_norm(summed, 1.0, scratch, grad_scale=1.0 / world)
+    assert rel_err(summed.cpu(), p.grad) < 1e-4
+    assert abs(scratch[1025].item() - mean.double().norm().item()) < 1e-4
+
+
+def test_adamw_gated_skips_nonfinite_loss(gpu):
+    """modify_scripts/modify_train.py:1190-1196: step only `if torch.isfinite(loss)`; decided on the device, and the
+    bias corrections follow the number of APPLIED updates (torch.optim.AdamW's step count does not advance on a skip)."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(12)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=5e-4, weight_decay=1e-4)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    ctl = torch.zeros(8, dtype=torch.int32, device=dev)
+    losses = [1.0, float("nan"), 2.0, float("inf"), 3.0]
+    for i, lv in enumerate(losses):
+        grad = torch.randn(n, generator=g)
+        loss = torch.tensor([lv], dtype=torch.float32, device=dev)
+        before = p.clone()
+        ops.adamw_gated(p, grad.to(dev), m, v, 5e-4, 0.9, 0.999, 1e-8, 1e-4, loss, ctl)
+        if lv == lv and abs(lv) != float("inf"):
+            ref.grad = grad.clone()
+            opt.step()
+        else:
+            assert torch.equal(p, before)  # skipped: parameters untouched
+    torch.cuda.synchronize()
+    assert ctl[:3].tolist() == [3, 2, 0]
+    assert rel_err(p.cpu(), ref.detach()) < 1e-6
+    # a non-finite gradient norm skips as well (keeps data-parallel ranks in step)
+    before = p.clone()
+    ops.adamw_gated(p, torch.ones(n, device=dev), m, v, 5e-4, 0.9, 0.999, 1e-8, 1e-4,
+                    torch.ones(1, device=dev), ctl, grad_norm=torch.full((1,), float("nan"), device=dev))
+    assert torch.equal(p, before) and ctl[:3].tolist() == [3, 3, 1]

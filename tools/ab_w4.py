@@ -3,6 +3,7 @@ the results on every epilogue, then timing on the decoder shapes with rotating (
 import os
 import sys
 
+os.environ.setdefault("TCAVT_LIB", "exp")  # the -DTCAVT_EXPERIMENTS build: python -m tcavt_amd.build --experiments
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tcavt_amd import capi, ops, rope as rope_mod

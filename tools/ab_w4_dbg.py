@@ -1,6 +1,7 @@
 """Timing-only elimination experiments on the 4-wave gate|up GEMM (codes 261-267 give wrong results by design)."""
 import os, sys
 os.environ["TCAVT_GEMM_TIMING_EXPERIMENTS"] = "1"  # codes 261-267 refuse to run without it
+os.environ.setdefault("TCAVT_LIB", "exp")  # the -DTCAVT_EXPERIMENTS build: python -m tcavt_amd.build --experiments
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tcavt_amd import capi, ops

@@ -39,21 +39,33 @@ def is_current():
         return f.read().strip() == _digest()
 
 
-def build_library(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link the shared library."""
-    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    extra = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in sources)
-    sources += extra
+EXP_LIB_PATH = os.path.join(HERE, "libtcavt_hip_exp.so")
+
+
+def build_library(force=False, verbose=True, experiments=False):
+    """Compile every HIP source for gfx950 and link the shared library.
+
+    experiments=True builds libtcavt_hip_exp.so with -DTCAVT_EXPERIMENTS instead: the product library plus the
+    measured-and-rejected GEMM variants and the timing-only elimination experiments (which compute wrong results).
+    Only tools/ load it (TCAVT_LIB=exp); tests, bench.py and smoke() never do."""
+    if experiments:
+        return _build(EXP_LIB_PATH, FLAGS + ["-DTCAVT_EXPERIMENTS"], "build_exp", verbose, stamp=False)
     if not force and is_current():
         if verbose:
             print(f"[tcavt build] {LIB_NAME} up to date")
         return LIB_PATH
-    objdir = os.path.join(HERE, "build")
+    return _build(LIB_PATH, FLAGS, "build", verbose, stamp=True)
+
+
+def _build(lib_path, flags, objsub, verbose, stamp):
+    sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    sources += sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in sources)
+    objdir = os.path.join(HERE, objsub)
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
@@ -63,16 +75,17 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
-    with open(LIB_PATH + ".sha256", "w") as f:
-        f.write(_digest())
+    if stamp:
+        with open(lib_path + ".sha256", "w") as f:
+            f.write(_digest())
     if verbose:
-        print(f"[tcavt build] built {LIB_PATH}")
-    return LIB_PATH
+        print(f"[tcavt build] built {lib_path}")
+    return lib_path
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_library(force="--force" in sys.argv, experiments="--experiments" in sys.argv)

@@ -15,7 +15,10 @@ import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtcavt_hip.so")
+if os.environ.get("TCAVT_LIB") == "exp":  # tools/ only: the -DTCAVT_EXPERIMENTS build (python -m tcavt_amd.build --experiments)
+    LIB_PATH = os.path.join(_HERE, "libtcavt_hip_exp.so")
 
+ABI_VERSION = 2  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
@@ -102,7 +105,7 @@ _SIGNATURES = {
     "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
-    "tcavt_clip_grad_norm": [c_void_p, c_int64, c_float, c_void_p, c_void_p],
+    "tcavt_clip_grad_norm": [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                       c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint64,
@@ -119,6 +122,8 @@ _SIGNATURES = {
     "tcavt_masked_mean_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                     c_int, c_float, c_void_p],
+    "tcavt_adamw_gated": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                          c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"tcavt_last_error": ctypes.c_char_p}
 
@@ -148,7 +153,7 @@ def lib():
         fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
-    if handle.tcavt_abi_version() != 1:
+    if handle.tcavt_abi_version() != ABI_VERSION:
         raise TcavtError("libtcavt_hip.so ABI version mismatch")
     _lib = handle
     return handle

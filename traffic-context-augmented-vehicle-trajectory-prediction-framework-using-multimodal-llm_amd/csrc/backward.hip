@@ -551,6 +551,43 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// Gated form (modify_scripts/modify_train.py:1190-1196: clip + step only `if torch.isfinite(loss)`, otherwise the update
+// is skipped) without a host round trip: one thread decides from the device-resident loss (and, optionally, the
+// exchanged gradient's norm) and keeps the optimizer's step count on the device, so that the bias corrections of a
+// later step are those of torch.optim.AdamW after the same number of APPLIED updates.
+//   ctl[0] = applied steps, ctl[1] = skipped steps, ctl[2] = 1 if this call is skipped, ctl[4], ctl[5] = bc1, bc2 (float bits)
+__global__ void adamw_gate_kernel(const float* __restrict__ loss, const float* __restrict__ norm, int* __restrict__ ctl,
+                                  float b1, float b2) {
+  const bool ok = isfinite(*loss) && (norm == nullptr || isfinite(*norm));
+  if (ok) {
+    const int step = ++ctl[0];
+    ctl[2] = 0;
+    ctl[4] = __float_as_int(1.f - powf(b1, (float)step));
+    ctl[5] = __float_as_int(1.f - powf(b2, (float)step));
+  } else {
+    ++ctl[1];
+    ctl[2] = 1;
+  }
+}
+__global__ void adamw_gated_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                                   const int* __restrict__ ctl, float grad_scale) {
+  if (ctl[2]) return;  // (uniform) non-finite loss: parameters and moments stay as they are
+  const float bc1 = __int_as_float(ctl[4]), bc2 = __int_as_float(ctl[5]);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float mh = mi / bc1, vh = vi / bc2;
+    pi -= lr * mh / (sqrtf(vh) + eps);
+    p[i] = pi;
+  }
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -732,5 +769,18 @@ extern "C" int tcavt_adamw(float* p, const float* g, float* m, float* v, int64_t
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, S_(stream), p, g, m, v, (long)n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2, grad_scale);
   TCAVT_CHECK_LAUNCH("adamw");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_adamw_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, float grad_scale, const float* loss,
+                                 const float* grad_norm, int32_t* ctl, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(p && g && m && v && n > 0 && loss && ctl, "adamw_gated: bad args");
+  hipLaunchKernelGGL(adamw_gate_kernel, dim3(1), dim3(1), 0, S_(stream), loss, grad_norm, ctl, beta1, beta2);
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adamw_gated_kernel, dim3((unsigned)blocks), dim3(256), 0, S_(stream), p, g, m, v, (long)n, lr,
+                     beta1, beta2, eps, weight_decay, ctl, grad_scale);
+  TCAVT_CHECK_LAUNCH("adamw_gated");
   return TCAVT_OK;
 }

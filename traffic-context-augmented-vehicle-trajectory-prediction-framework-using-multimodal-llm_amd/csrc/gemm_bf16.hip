@@ -563,6 +563,7 @@ static int launch(const GemmP& p0, int batch, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+#ifdef TCAVT_EXPERIMENTS  // measured-and-rejected form: only in the experiments build (tools/), never in the product library
 // ===========================================================================
 // Main-loop variant 2 ("ring", 256x256 tile only): the K dimension is cut into 32-deep slabs that
 // live in a 4-slot LDS ring (4 x 32 KiB).  Up to three slabs of LDS-DMA stay in flight ACROSS the
@@ -685,6 +686,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
   }
   gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
+
+#endif  // TCAVT_EXPERIMENTS
 
 // ===========================================================================
 // Main-loop variant 3 ("w4", 256x256 tile, whole tiles only): FOUR waves, one per SIMD, each owning a
@@ -1061,6 +1064,7 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+#ifdef TCAVT_EXPERIMENTS
 template <int EPI, bool F16>
 static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
   GemmP p = p0;
@@ -1084,6 +1088,7 @@ static int launch_ring(const GemmP& p0, int batch, hipStream_t stream) {
   TCAVT_CHECK_LAUNCH("gemm_bf16(ring)");
   return TCAVT_OK;
 }
+#endif  // TCAVT_EXPERIMENTS
 
 // Launches below one wave of 256x256 tiles (tile = 128, 64 or 0 = pick).
 template <int EPI, bool F16>
@@ -1104,10 +1109,11 @@ static int launch_small(const GemmP& p, int tile, int batch, hipStream_t stream)
   return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
 }
 
-// tile codes (tcavt_gemm_args.tile): 0 auto | 256, 128 the production variants |
-// A/B variants kept reachable: 255 = 256x256 with burst DMA issue, 253 / 252 = 255 with static / no wave
-// priority, 250 = 256x256 32-deep ring pipeline, 127 = 128x128 with MFMA-cluster priority,
-// 126 = 128x128 with burst DMA issue.
+// tile codes (tcavt_gemm_args.tile): 0 auto | 64, 128, 256 (8-wave), 257 (4-wave 256x256), 271 (4-wave 256x192),
+// 272 (4-wave two-barrier form): the production variants, all bit-identical in results.
+// Only with -DTCAVT_EXPERIMENTS (libtcavt_hip_exp.so, built and used by tools/ alone): the measured-and-rejected A/B
+// variants 255 / 253 / 252 (burst DMA issue, static / no wave priority), 250 (32-deep ring), 258 / 259 / 268 / 269 / 270,
+// 124-127, and the timing-only elimination experiments 261-267, which compute WRONG results.
 template <int EPI, bool F16>
 static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream) {
   GemmP q = p;
@@ -1115,10 +1121,12 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 256:  // DMA pieces interleaved with the MFMAs + s_setprio(1) around MFMA clusters (fastest measured)
       q.prio = 2;
       return launch<256, 256, 2, 4, EPI, F16, 1>(q, batch, stream);
+#ifdef TCAVT_EXPERIMENTS
     case 255: q.prio = 2; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 253: q.prio = 1; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 252: q.prio = 0; return launch<256, 256, 2, 4, EPI, F16, 0>(q, batch, stream);
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
+#endif
     case 271:  // 256 x 192 tiles (N % 192 == 0)
       if constexpr (!F16) {
         if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 192 == 0 &&
@@ -1127,25 +1135,31 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
       }
       set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs bf16 operands, M %% 256 == 0, N %% 192 == 0, no batch");
       return TCAVT_ERR_ARG;
-    case 257: case 258: case 259: case 268: case 269: case 270: case 272:
+    case 257: case 272:
+#ifdef TCAVT_EXPERIMENTS
+    case 258: case 259: case 268: case 269: case 270:
+#endif
       if constexpr (!F16) {
         if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
             (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16)) {
           if (tile == 272) {
             if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 64>(q, stream);
           }
+#ifdef TCAVT_EXPERIMENTS
           if (tile == 270) {
             if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 0, true>(q, stream);
           }
           if (tile == 268) return launch_w4<EPI, 2, 16>(q, stream);
           if (tile == 269) return launch_w4<EPI, 2, 32>(q, stream);
-          if (tile == 257) return launch_w4<EPI, 2>(q, stream);
           if (tile == 258) return launch_w4<EPI, 3>(q, stream);
-          return launch_w4<EPI, 4>(q, stream);
+          if (tile == 259) return launch_w4<EPI, 4>(q, stream);
+#endif
+          return launch_w4<EPI, 2>(q, stream);
         }
       }
       set_error("gemm_bf16: tile %d (4-wave kernel) needs bf16 operands, whole 256x256 tiles, one K source, no batch", tile);
       return TCAVT_ERR_ARG;
+#ifdef TCAVT_EXPERIMENTS
     case 261: case 262: case 263: case 264: case 265: case 267: {  // timing experiments (wrong results)
       static const bool allow = getenv("TCAVT_GEMM_TIMING_EXPERIMENTS") != nullptr;
       if (!allow) {
@@ -1172,6 +1186,7 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 126: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 0>(q, batch, stream);
     case 125: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
     case 124: q.prio = 0; return launch<128, 128, 2, 2, EPI, F16, 1>(q, batch, stream);
+#endif  // TCAVT_EXPERIMENTS
     default: return launch_small<EPI, F16>(q, tile, batch, stream);  // 128 / 64 / 0 (auto)
   }
 }
@@ -1229,8 +1244,14 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
+#ifdef TCAVT_EXPERIMENTS
   TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 272 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
+#else
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || a->tile == 257 || a->tile == 271 || a->tile == 272,
+                  "gemm_bf16: tile must be 0 (auto), 64, 128, 256, 257, 271 or 272 (A/B and timing-experiment codes exist in the "
+                  "experiments build only: python -m tcavt_amd.build --experiments)");
+#endif
 
   GemmP p;
   p.A = static_cast<const bf16_t*>(a->A);

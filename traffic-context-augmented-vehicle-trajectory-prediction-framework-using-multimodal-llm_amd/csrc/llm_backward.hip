@@ -822,7 +822,10 @@ __global__ __launch_bounds__(256) void gqa_rope_bwd_pack_kernel(const float* __r
 // ---------------------------------------------------------------------------
 // torch.nn.utils.clip_grad_norm_(params, max_norm) on the flat gradient vector (modify_scripts/modify_train.py:1192), without
 // a host round trip and with a fixed summation order: 1024 block partials of sum(g^2), one block adds them in index order
-// and leaves  min(1, max_norm / (norm + 1e-6))  in scratch[1024] (norm in scratch[1025]), a third launch scales g.
+// and leaves  grad_scale * min(1, max_norm / (norm + 1e-6))  in scratch[1024] (norm = grad_scale * ||g|| in scratch[1025]),
+// a third launch scales g.  grad_scale = 1 / world turns the SUM-all-reduced gradient of a data-parallel step into the
+// DDP-averaged one FIRST, so that the threshold applies to the gradient the reference clips (modify_train.py:1192 clips
+// after DDP's averaging all-reduce).
 // ---------------------------------------------------------------------------
 constexpr int CLIP_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
@@ -836,13 +839,13 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ __launch_bounds__(64) void clip_scale_kernel(float* __restrict__ part, float max_norm) {
+__global__ __launch_bounds__(64) void clip_scale_kernel(float* __restrict__ part, float max_norm, float grad_scale) {
   float a = 0.f;
   for (int i = threadIdx.x; i < CLIP_BLOCKS; i += 64) a += part[i];  // lane l: partials l, l + 64, ... in order
   a = wave_sum(a);
   if (threadIdx.x == 0) {
-    const float norm = sqrtf(a);
-    part[CLIP_BLOCKS] = fminf(1.f, max_norm / (norm + 1e-6f));
+    const float norm = grad_scale * sqrtf(a);
+    part[CLIP_BLOCKS] = grad_scale * fminf(1.f, max_norm / (norm + 1e-6f));
     part[CLIP_BLOCKS + 1] = norm;
   }
 }
@@ -990,11 +993,12 @@ extern "C" int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, con
   return TCAVT_OK;
 }
 
-extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float* scratch, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(g && scratch && n > 0 && max_norm > 0.f, "clip_grad_norm: bad args");
+extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float grad_scale, float* scratch,
+                                    tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(g && scratch && n > 0 && max_norm > 0.f && grad_scale > 0.f, "clip_grad_norm: bad args");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(sumsq_partial_kernel, dim3(CLIP_BLOCKS), dim3(256), 0, st, g, (long)n, scratch);
-  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, st, scratch, max_norm);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, st, scratch, max_norm, grad_scale);
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, (long)n, scratch + CLIP_BLOCKS);

@@ -137,5 +137,6 @@ def evaluate_model(model, batches, num_candidates=1, process_group=None, mc_drop
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.all_reduce(stats, group=process_group)
     ade, fde, rmse, tot = stats.tolist()
+    model.mllm.check_flags()  # ids outside the vocabulary / masks that are not right-padded in ANY batch of the loop
     tot = max(tot, 1.0)
     return {"ADE": ade / tot, "FDE": fde / tot, "RMSE": rmse / tot, "n": int(tot)}

@@ -716,8 +716,9 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 torch.cuda.current_stream().wait_stream(self._pf_stream)
             img = self._image_tokens(vision_embs)
         h = ws.get("mm.h", (B * L, H), torch.float32, dev)
-        flags = ws.get("mm.flags", (2,), torch.int32, dev)
-        flags.zero_()
+        # error flags: the kernels only ever SET them, so they accumulate over forwards until check_flags() reads and
+        # clears them (evaluate_model and Trainer.check_flags do; one host sync, off the hot path)
+        flags = ws.get("mm.flags", (2,), torch.int32, dev, zero=True)
         ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1])
         if dev.type == "cuda" and self._pf_stream is not None:
             self._img_consumed = torch.cuda.Event()
@@ -735,8 +736,11 @@ class LlamaMultiModal(nn.Module, _Prepared):
         return final, Nq
 
     def check_flags(self):
-        """Host-side check of the device error flags of the last forward (one sync)."""
+        """Host-side check of the device error flags accumulated since the last check (one sync); clears them."""
+        if getattr(self, "_last_flags", None) is None:
+            return
         f = self._last_flags.tolist()
+        self._last_flags.zero_()
         if f[0]:
             raise ValueError("input_ids contains ids outside [0, vocab)")
         if f[1]:

@@ -624,13 +624,15 @@ def masked_mean_bwd(gemb, lens, genc, B, P, D):
     check(lib().tcavt_masked_mean_bwd(ptr(gemb), ptr(lens), ptr(genc), B, P, D, stream_ptr()), "tcavt_masked_mean_bwd")
 
 
-def clip_grad_norm(g, max_norm, scratch):
-    """In-place clip of the flat gradient vector to max_norm (torch.nn.utils.clip_grad_norm_ semantics); scratch: fp32,
-    >= 1026 elements; afterwards scratch[1025] holds the norm before clipping, scratch[1024] the factor applied."""
+def clip_grad_norm(g, max_norm, scratch, grad_scale=1.0):
+    """In-place g *= grad_scale, then clip of the flat gradient vector to max_norm (torch.nn.utils.clip_grad_norm_
+    semantics); scratch: fp32, >= 1026 elements; afterwards scratch[1025] holds the norm of the scaled gradient before
+    clipping, scratch[1024] the total factor applied.  grad_scale = 1 / world: clip the data-parallel MEAN gradient."""
     _req(g, torch.float32, "clip_grad_norm.g")
     _req(scratch, torch.float32, "clip_grad_norm.scratch")
     _need(scratch, 1026, "clip_grad_norm.scratch")
-    check(lib().tcavt_clip_grad_norm(ptr(g), g.numel(), float(max_norm), ptr(scratch), stream_ptr()), "tcavt_clip_grad_norm")
+    check(lib().tcavt_clip_grad_norm(ptr(g), g.numel(), float(max_norm), float(grad_scale), ptr(scratch), stream_ptr()),
+          "tcavt_clip_grad_norm")
 
 
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
@@ -640,3 +642,21 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0)
         _need(t, n, "adamw." + nm)
     check(lib().tcavt_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, weight_decay, int(step),
                             grad_scale, stream_ptr()), "tcavt_adamw")
+
+
+def adamw_gated(p, g, m, v, lr, beta1, beta2, eps, weight_decay, loss, ctl, grad_scale=1.0, grad_norm=None):
+    """AdamW update that the device skips when `loss` (device fp32 scalar) or `grad_norm` (optional device fp32 scalar)
+    is not finite (modify_scripts/modify_train.py:1190-1196); the step count lives in ctl (int32[8], device)."""
+    n = p.numel()
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _req(t, torch.float32, "adamw_gated." + nm)
+        _need(t, n, "adamw_gated." + nm)
+    _req(loss, torch.float32, "adamw_gated.loss")
+    _need(loss, 1, "adamw_gated.loss")
+    _req(ctl, torch.int32, "adamw_gated.ctl")
+    _need(ctl, 8, "adamw_gated.ctl")
+    if grad_norm is not None:
+        _req(grad_norm, torch.float32, "adamw_gated.grad_norm")
+        _need(grad_norm, 1, "adamw_gated.grad_norm")
+    check(lib().tcavt_adamw_gated(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                  ptr(loss), ptr(grad_norm), ptr(ctl), stream_ptr()), "tcavt_adamw_gated")

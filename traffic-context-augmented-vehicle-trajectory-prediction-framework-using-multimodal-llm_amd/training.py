@@ -27,12 +27,22 @@ def trainable_named_parameters(model):
 
 
 class Trainer:
-    """lora_trainable=False: scripts/train.py (whole MLLM frozen).  lora_trainable=True: the variant of
-    modify_scripts/modify_train.py:512-528,1192 -- lora_A / lora_B of q_proj, v_proj train as well (the backward walks
-    through the frozen decoder layers, llm_backward.LoraBackward) and gradients are clipped to max_grad_norm."""
+    """lora_trainable=False: scripts/train.py (whole MLLM frozen, :1140-1145).
+
+    lora_trainable=True: the **LoRA-only subset** of modify_scripts/modify_train.py -- lora_A / lora_B of q_proj, v_proj
+    train as well (:512-528; the backward walks through the frozen decoder layers, llm_backward.LoraBackward), gradients
+    are clipped to max_grad_norm (:1192) and an update is skipped when the loss is not finite (:1190-1196, decided on
+    the device).  NOT the whole of modify_train.py's trainable set: that script never freezes `mllm`, so its Q-Former,
+    mllm.q_proj and the two modality embeddings (54 M parameters) keep requires_grad there; here the backward stops at
+    the input of decoder layer 0 and those stay frozen ("LoRA-only subset").
+
+    Data parallel (world > 1): the constructor broadcasts rank 0's parameters to all ranks (what the reference's
+    DistributedDataParallel wrap does at construction, train.py:1127-1132); gradients are SUM-all-reduced in buckets and
+    turned into the mean before clipping (or inside AdamW when there is no clipping)."""
 
     def __init__(self, model, lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None,
-                 lora_trainable=False, max_grad_norm=None):
+                 lora_trainable=False, max_grad_norm=None, skip_nonfinite=None, sync_initial_state=True,
+                 check_flags_every=0):
         self.model = model
         dev = next(model.parameters()).device
         named = trainable_named_parameters(model)
@@ -40,6 +50,9 @@ class Trainer:
             p.requires_grad_(False)
         self.lora_trainable = bool(lora_trainable)
         self.max_grad_norm = max_grad_norm
+        # modify_train.py:1190-1196 skips clip + step on a non-finite loss; train.py has no such test
+        self.skip_nonfinite = self.lora_trainable if skip_nonfinite is None else bool(skip_nonfinite)
+        self.check_flags_every = int(check_flags_every)  # > 0: host check of the input error flags every N steps (one sync)
         n_frozen_variant = len(named)
         if self.lora_trainable:
             if not model.mllm.llama_wrapper.use_lora:
@@ -66,7 +79,24 @@ class Trainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        self._ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # device-side step counters of the gated optimizer
+        self._last_loss = None
+        if self.world > 1 and sync_initial_state:
+            self.broadcast_state()
         model.invalidate_prepared()
+
+    def broadcast_state(self, src=0):
+        """Rank `src`'s model parameters (frozen ones included) and optimizer moments to every rank: ranks that built or
+        loaded their weights differently would otherwise diverge silently, because only gradients are exchanged."""
+        with torch.no_grad():
+            dist.broadcast(self.book.params, src=src, group=self.pg)  # the trainable set (parameters are views into it)
+            in_book = set(self.book.names)
+            for n, p in self.model.named_parameters():
+                if n not in in_book:
+                    dist.broadcast(p.data, src=src, group=self.pg)
+            dist.broadcast(self.m, src=src, group=self.pg)
+            dist.broadcast(self.v, src=src, group=self.pg)
+        self.model.invalidate_prepared()
 
     # ---- gradient exchange ------------------------------------------------------------------
     def _allreduce_bucket(self, lo, hi):
@@ -112,6 +142,7 @@ class Trainer:
                 self._lora_backward(B, L)
                 self._allreduce_bucket(self.n_base, self.book.total)
             self._wait_comm()
+        self._last_loss = loss
         return loss, decoded
 
     def _stacked_lora_views(self, lora):
@@ -148,22 +179,32 @@ class Trainer:
             ops.gemm_bf16(g[: B * L], WT, out=out)
         self.lbw.run(gfa, gfb)
 
-    def clip_grad_norm_(self, max_norm):
+    def clip_grad_norm_(self, max_norm, grad_scale=1.0):
         """torch.nn.utils.clip_grad_norm_(trainable, max_norm) (modify_train.py:1192) on the flat gradient vector,
-        without a host synchronisation."""
+        without a host synchronisation.  grad_scale is applied to the gradient first (1 / world: the SUM-all-reduced
+        buckets become DDP's mean, which is what the reference clips)."""
         if getattr(self, "_clip_scratch", None) is None:
             self._clip_scratch = torch.zeros(1026, dtype=torch.float32, device=self.book.grads.device)
-        ops.clip_grad_norm(self.book.grads, max_norm, self._clip_scratch)
-        return self._clip_scratch[1025]  # the norm before clipping (device scalar)
+        ops.clip_grad_norm(self.book.grads, max_norm, self._clip_scratch, grad_scale=grad_scale)
+        return self._clip_scratch[1025:1026]  # the norm (of the scaled gradient) before clipping (device scalar)
 
     def optimizer_step(self):
         m = self.model
         with torch.no_grad():
+            grad_scale, norm = 1.0 / self.world, None
             if self.max_grad_norm is not None:
-                self.clip_grad_norm_(self.max_grad_norm)
+                norm = self.clip_grad_norm_(self.max_grad_norm, grad_scale=grad_scale)  # mean first, then clip
+                grad_scale = 1.0
             self.step_count += 1
-            ops.adamw(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.wd, self.step_count, grad_scale=1.0 / self.world)
+            if self.skip_nonfinite:
+                if self._last_loss is None:
+                    raise RuntimeError("optimizer_step(skip_nonfinite=True) needs the loss of forward_backward()")
+                ops.adamw_gated(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                                self.eps, self.wd, self._last_loss.reshape(1), self._ctl, grad_scale=grad_scale,
+                                grad_norm=norm)
+            else:
+                ops.adamw(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                          self.eps, self.wd, self.step_count, grad_scale=grad_scale)
             # bf16 shadows / stacked copies of the trainable weights are stale now
             m.ltsf._invalidate()
             if self.lora_trainable:
@@ -173,7 +214,19 @@ class Trainer:
         """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
         self.model.prefetch(vision_embs, ready=ready)
 
+    def optimizer_counters(self):
+        """(applied, skipped) updates of the gated optimizer (one host sync)."""
+        c = self._ctl.tolist()
+        return (c[0], c[1]) if self.skip_nonfinite else (self.step_count, 0)
+
+    def check_flags(self):
+        """Raise if any forward since the last check saw input_ids outside the vocabulary or a mask that is not a
+        right-padded prefix (the kernels only SET the device flags; one host sync here)."""
+        self.model.mllm.check_flags()
+
     def step(self, *args, **kw):
         out = self.forward_backward(*args, **kw)
         self.optimizer_step()
+        if self.check_flags_every > 0 and self.step_count % self.check_flags_every == 0:
+            self.check_flags()
         return out
