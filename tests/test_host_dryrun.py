@@ -69,6 +69,34 @@ def test_guard_catches_short_buffer(dry):
         ops.embed_fuse(table, ids, img, torch.zeros(64), torch.zeros(64), torch.zeros(2 * 7, 64), flag)
 
 
+def test_embed_fuse_extent_with_flattened_image_tokens(monkeypatch):
+    """The one GPU memory-access fault on record (round 1, gpurun_out/k2.log): ops.embed_fuse took Nq from img.shape[1]
+    while the model hands the image tokens over flattened as [B*Nq, H], so Nq became H and the kernel's grid covered
+    B*(H+Lt) rows of `h` (allocated B*(Nq+Lt)) and B*H rows of `img` (allocated B*Nq).  Nq must come from the element
+    count, and both extents are guarded on the host."""
+    from tcavt_amd import capi, ops
+
+    seen = []
+
+    class Stub:
+        def tcavt_embed_fuse(self, *a):
+            seen.append(a)
+            return 0
+
+    monkeypatch.setattr(ops, "lib", lambda: Stub())
+    monkeypatch.setattr(ops, "stream_ptr", lambda: None)
+    monkeypatch.setattr(ops, "_ALLOW_CPU", True)
+    B, Nq, Lt, H, V = 2, 16, 5, 64, 32
+    table, ids = torch.zeros(V, H, dtype=torch.bfloat16), torch.zeros(B, Lt, dtype=torch.int64)
+    mods, flag = torch.zeros(H), torch.zeros(1, dtype=torch.int32)
+    h = torch.zeros(B * (Nq + Lt), H)
+    for img in (torch.zeros(B * Nq, H), torch.zeros(B, Nq, H)):  # flattened (what the model passes) and 3-D
+        ops.embed_fuse(table, ids, img, mods, mods, h, flag)
+        assert seen[-1][6:11] == (B, Nq, Lt, H, V)  # B, Nq, Lt, H, V as the kernel sees them: Nq = 16, not H
+    with pytest.raises(capi.TcavtError, match="kernel needs"):  # h sized for fewer image tokens than img holds
+        ops.embed_fuse(table, ids, torch.zeros(B * Nq, H), mods, mods, torch.zeros(B * (Nq + Lt) - 1, H), flag)
+
+
 @pytest.mark.parametrize("lora_trainable", [False, True])
 def test_training_step_call_sequence_passes_host_guards(dry, lora_trainable):
     """train.py step (and its LoRA-trainable variant, modify_scripts/modify_train.py:512-528) end to end against the stub:
