@@ -16,7 +16,11 @@
  *     on `stream` (a hipStream_t passed as void*) and graph-capturable
  *   - return value 0 = ok; otherwise a TCAVT_ERR_* code, and
  *     tcavt_last_error() returns a thread-local message
- *   - "bf16" buffers are raw 16-bit brain-float (upper half of an IEEE f32)
+ *   - 16-bit buffers are raw uint16 storage of either IEEE half (TCAVT_F16: the forward path's default storage
+ *     type -- 11 significant bits keep the whole model within 1e-3 of the fp32 reference, profiles/
+ *     r02_error_budget_full_size.json) or brain-float (TCAVT_BF16: upper half of an IEEE f32; gradient-side tensors
+ *     and the LoRA-trainable variant).  Parameters still called "..._bf16" take either; the entry point's `dtype16`
+ *     / `in_dtype` / `out_dtype` argument says which.  fp32 accumulation everywhere.
  *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS
  */
 #ifndef TCAVT_H
@@ -103,7 +107,7 @@ typedef struct tcavt_gemm_args {
                                     the product library (measured-and-rejected variants and timing experiments live in
                                     the -DTCAVT_EXPERIMENTS build that tools/ makes for itself) */
   float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */
-  int32_t in_dtype;              /* operand type of A/W/A2/W2: 0 or TCAVT_BF16, or TCAVT_F16 (generic epilogue only) */
+  int32_t in_dtype;              /* operand type of A/W/A2/W2: 0 or TCAVT_BF16, or TCAVT_F16 (every epilogue and kernel form) */
   /* Batched form (generic epilogue only): batch > 1 runs `batch` independent products; product i uses
    * A + (i / batch_inner) * sAo + (i % batch_inner) * sAi, likewise W and C (strides in ELEMENTS,
    * every offset must keep 16-byte alignment).  bias / residual are shared by all products.
@@ -142,7 +146,8 @@ int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
  * ---------------------------------------------------------------------- */
 int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
                   float* out_f32, int M, int H, void* out_drop_bf16, float dropout_p,
-                  uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream);
+                  uint64_t dropout_seed, uint32_t dropout_site, int dtype16 /* of out_bf16 / out_drop_bf16 */,
+                  tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * nn.LayerNorm over the last dim with optional fused residual add:
@@ -153,26 +158,26 @@ int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
  * ---------------------------------------------------------------------- */
 int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
                     const float* beta, float eps, float* out_f32, void* out_bf16,
-                    int M, int D, tcavt_stream_t stream);
+                    int M, int D, int dtype16 /* of out_bf16 */, tcavt_stream_t stream);
 
-/* Elementwise train-mode dropout: out[i] = x[i] * keep(i) / (1-p), dtype TCAVT_F32 or TCAVT_BF16 (in place
+/* Elementwise train-mode dropout: out[i] = x[i] * keep(i) / (1-p), dtype TCAVT_F32, TCAVT_BF16 or TCAVT_F16 (in place
  * allowed).  Used for the LoRA branch input (lora_dropout, scripts/train.py:433-439). */
 int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
                   tcavt_stream_t stream);
 
-/* fp32 -> bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */
-int tcavt_cast_f32_bf16(const float* x, void* out_bf16, int64_t n, tcavt_stream_t stream);
+/* fp32 -> fp16 / bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */
+int tcavt_cast_f32_16(const float* x, void* out16, int64_t n, int dtype16, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused input embedding build (scripts/train.py:521-528):
  *   h[b][i]      = img[b][i] + vis_mod               i <  Nq   (img = q_proj output)
  *   h[b][Nq + j] = table[ids[b][j]] + txt_mod        j <  Lt
- * table bf16 [V][H]; ids int64 [B][Lt]; img fp32 [B][Nq][H]; h fp32 [B][Nq+Lt][H].
+ * table fp16 / bf16 (table_dtype) [V][H]; ids int64 [B][Lt]; img fp32 [B][Nq][H]; h fp32 [B][Nq+Lt][H].
  * Ids outside [0,V) are reported through *bad_id_flag (device int, set to 1).
  * ---------------------------------------------------------------------- */
 int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                      const float* vis_mod, const float* txt_mod, float* h, int B,
-                     int Nq, int Lt, int H, int V, int* bad_id_flag,
+                     int Nq, int Lt, int H, int V, int* bad_id_flag, int table_dtype,
                      tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
@@ -189,14 +194,14 @@ int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_
  * Causal grouped-query attention over the fused sequence
  * (modeling_llama.py:191-213 semantics = HF sdpa path with a causal AND
  * key-valid mask).
- *   qkv  bf16 [B*L][(nq + 2*nkv) * 64]   (q heads | k heads | v heads, RoPE applied)
- *   out  bf16 [B*L][nq * 64]
+ *   qkv  fp16 / bf16 (dtype16) [B*L][(nq + 2*nkv) * 64]   (q heads | k heads | v heads, RoPE applied)
+ *   out  same type [B*L][nq * 64]
  *   kv_len int32 [B]: keys j < kv_len[b] are valid (right padding); a query i
  *   attends keys j <= i with j < kv_len[b]; padded queries are still computed.
  * head_dim is 64; nq % nkv == 0; L <= 544.  softmax in fp32, scale given.
  * ---------------------------------------------------------------------- */
 int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B,
-                          int L, int nq, int nkv, float scale, tcavt_stream_t stream);
+                          int L, int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row softmax for the batched cross-attention: P[r][c] = softmax_c(S[r][c]) over c < n_valid,
@@ -215,7 +220,7 @@ int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t ldp, int ou
  *   k,v [B][Lk] rows of stride ldk / ldv
  *   key_len int32 [B] or NULL: keys j >= key_len[b] are masked (src_key_padding_mask)
  *   out [B][Lq][nh*dh], leading dim ldo
- * in_dtype/out_dtype: TCAVT_F32 or TCAVT_BF16 (q,k,v share in_dtype).
+ * in_dtype/out_dtype: TCAVT_F32, TCAVT_BF16 or TCAVT_F16 (q,k,v share in_dtype).
  * No causal mask.  Lk <= 544, Lq*Lk*4 bytes must fit 64 KiB.  dropout_p > 0: dropout on the attention
  * probabilities, flat index ((b*nh + h)*Lq + i)*Lk + j.
  * ---------------------------------------------------------------------- */
@@ -271,9 +276,9 @@ int tcavt_ltsf_decode(const float* e_tok, const float* dec_w, const float* dec_b
                       tcavt_stream_t stream);
 
 /* [B][C][To] -> [B][To][C] transpose (decoded.permute(0,2,1), train.py:793),
- * optional bf16 copy for the following bf16 contraction */
+ * optional 16-bit copy (dtype16) for the following 16-bit contraction */
 int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf16, int B, int C,
-                       int To, tcavt_stream_t stream);
+                       int To, int dtype16, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Final head (scripts/train.py:804-805, 941-943):
@@ -314,9 +319,11 @@ int tcavt_gemm_f32_strided(const float* A, int64_t rsA, int64_t csA, const float
  * ====================================================================== */
 
 /* out[c][r] = in[r][c] for 16-bit elements (bf16 / fp16), `batch` matrices s_in / s_out elements apart;
- * rows r in [rows, rows_pad) of the source are written as zeros (K-padding of the following GEMM). */
+ * rows r in [rows, rows_pad) of the source are written as zeros (K-padding of the following GEMM).
+ * f16_to_bf16 != 0: the source is fp16 (a forward activation) and the copy is converted to bf16 -- the other operand of
+ * a gradient-side contraction is a bf16 gradient, and the MFMA wants one type. */
 int tcavt_transpose16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
-                      int rows_pad, int batch, int64_t s_in, int64_t s_out, tcavt_stream_t stream);
+                      int rows_pad, int batch, int64_t s_in, int64_t s_out, int f16_to_bf16, tcavt_stream_t stream);
 /* fp32 [rows][cols] -> bf16 [cols][rows_pad], zero padded */
 int tcavt_transpose_f32_bf16(const float* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                              int cols, int rows_pad, tcavt_stream_t stream);

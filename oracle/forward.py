@@ -30,12 +30,47 @@ import torch.nn.functional as F
 LLAMA = "mllm.llama_wrapper.llama_model.model."
 
 
+_CASTS = {
+    "fp32": lambda t: t,
+    "bf16": lambda t: t.to(torch.bfloat16).to(torch.float32),
+    # fp16 storage as the HIP path does it: IEEE half, round to nearest even; beyond +-65504 -> inf (outside the contract)
+    "fp16": lambda t: t.to(torch.float16).to(torch.float32),
+}
+
+
+class Rounder:
+    """r(t, tag) rounds `t` to the storage type of the rounding point `tag`.  A contract is either one mode for every
+    point ("fp32" | "bf16" | "fp16") or a dict {tag or scope or "scope.tag": mode, "default": mode}; the stage functions
+    name their points (llama: w, xn, t, qkv, att, act; scopes: qf = Q-Former + q_proj, xa = LTSF cross-attention head,
+    emb = embedding table, fh = final hidden states handed to the head) -- tools/error_budget.py toggles them one by one."""
+
+    def __init__(self, contract, scope=None):
+        # Named contracts of the HIP path (model.set_storage): "fp16" = its default storage type, "bf16" = the round-1
+        # contract kept for the LoRA-trainable variant.  In both, attention probabilities are carried in fp16 (P in
+        # [0, 1]: csrc/attention.hip) and the RMSNorm gains stay fp32 (they are applied in fp32 inside the norm kernel).
+        named = {"bf16": {"default": "bf16", "p": "fp16", "gamma": "fp32"}, "fp16": {"default": "fp16", "gamma": "fp32"},
+                 "fp32": {"default": "fp32"}}
+        self.modes = dict(contract) if isinstance(contract, dict) else dict(named[contract])
+        self.scope = scope
+        for m in self.modes.values():
+            if m not in _CASTS:
+                raise ValueError(m)
+
+    def scoped(self, scope):
+        return Rounder(self.modes, scope)
+
+    def mode(self, tag=None):
+        for k in ((f"{self.scope}.{tag}" if self.scope and tag else None), tag, self.scope, "default"):
+            if k is not None and k in self.modes:
+                return self.modes[k]
+        return "fp32"
+
+    def __call__(self, t, tag=None):
+        return _CASTS[self.mode(tag)](t)
+
+
 def _rounder(contract):
-    if contract == "bf16":
-        return lambda t: t.to(torch.bfloat16).to(torch.float32)
-    if contract == "fp32":
-        return lambda t: t
-    raise ValueError(contract)
+    return contract if isinstance(contract, Rounder) else Rounder(contract)
 
 
 def as_torch(weights):
@@ -53,10 +88,12 @@ class DropTape:
 
     def __init__(self, seed, p, first_site=1):
         self.seed, self.p, self.site = int(seed), float(p), int(first_site) - 1
+        self.log = []  # (p, shape) of every site visited, in call order (compared with the reference's own sequence)
 
     def __call__(self, x, cols=None):
         from . import philox
         self.site += 1
+        self.log.append((self.p, tuple(x.shape)))
         if cols is None:
             keep = philox.keep_mask(x.numel(), self.p, self.seed, self.site).reshape(tuple(x.shape))
         else:
@@ -121,12 +158,12 @@ def encoder_layer(x, W, prefix, nhead, r, key_len=None, drop=_ident):
     return x
 
 
-def decoder_layer(x, mem, W, prefix, nhead, r):
+def decoder_layer(x, mem, W, prefix, nhead, r, drop=_ident):
     """nn.TransformerDecoderLayer defaults: post-LN, ReLU, no masks (train.py:405-406,413)."""
-    x = layer_norm(x + mha_module(x, x, W, prefix + ".self_attn", nhead, r), W, prefix + ".norm1")
-    x = layer_norm(x + mha_module(x, mem, W, prefix + ".multihead_attn", nhead, r), W, prefix + ".norm2")
-    f = r(torch.relu(linear(x, W, prefix + ".linear1", r)))
-    x = layer_norm(x + linear(f, W, prefix + ".linear2", r), W, prefix + ".norm3")
+    x = layer_norm(x + drop(mha_module(x, x, W, prefix + ".self_attn", nhead, r, drop=drop)), W, prefix + ".norm1")
+    x = layer_norm(x + drop(mha_module(x, mem, W, prefix + ".multihead_attn", nhead, r, drop=drop)), W, prefix + ".norm2")
+    f = r(drop(torch.relu(linear(x, W, prefix + ".linear1", r))))
+    x = layer_norm(x + drop(linear(f, W, prefix + ".linear2", r)), W, prefix + ".norm3")
     return x
 
 
@@ -156,14 +193,18 @@ def lane_polygon_encoder(W, cfg, polygon, lens, drop=_ident):
 # --------------------------------------------------------------------------------------
 # A3: BlipQFormer.forward (train.py:408-414) and q_proj (train.py:521)
 # --------------------------------------------------------------------------------------
-def qformer(W, cfg, vision, r):
+def qformer(W, cfg, vision, r, drop=_ident):
+    """drop: a DropTape in train mode -- sites in module call order: per encoder layer (attention weights, dropout1,
+    dropout, dropout2), per decoder layer (self-attention weights, dropout1, cross-attention weights, dropout2, dropout,
+    dropout3), nn.Transformer*Layer defaults p = 0.1 (train.py:401-406)."""
+    r = _rounder(r).scoped("qf")
     B = vision.shape[0]
     x = linear(vision, W, "mllm.qformer.vision_proj", r)
     for i in range(cfg.q_enc_layers):
-        x = encoder_layer(x, W, f"mllm.qformer.encoder.layers.{i}", cfg.q_nhead, r)
+        x = encoder_layer(x, W, f"mllm.qformer.encoder.layers.{i}", cfg.q_nhead, r, drop=drop)
     q = W["mllm.qformer.query_tokens"].unsqueeze(0).expand(B, -1, -1)
     for i in range(cfg.q_dec_layers):
-        q = decoder_layer(q, x, W, f"mllm.qformer.decoder.layers.{i}", cfg.q_nhead, r)
+        q = decoder_layer(q, x, W, f"mllm.qformer.decoder.layers.{i}", cfg.q_nhead, r, drop=drop)
     return q
 
 
@@ -204,8 +245,10 @@ def lora_scale(cfg):
 def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
     """embeds [B,L,H] fp32, attn_mask [B,L] (1 = valid, right padded) -> post-final-norm hidden
     states = outputs.hidden_states[-1] (train.py:553).  drop: LoRA dropout on the adapter branch's input (PEFT:
-    lora_B(lora_A(dropout(x))); one site per layer, shared by q_proj and v_proj as in the HIP path, DropTape)."""
+    lora_B(lora_A(dropout(x))) with one lora_dropout module PER adapted Linear: two sites per layer, q_proj then v_proj,
+    the order HF's attention forward calls them in, modeling_llama.py:254-256)."""
     ll = cfg.llama
+    r = _rounder(r)
     B, L, H = embeds.shape
     nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
     cos, sin = rope_tables(ll, L)
@@ -216,17 +259,18 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
     h = embeds
     for layer in range(ll.layers):
         P = f"{LLAMA}layers.{layer}."
-        xn = r(rms_norm(h, r(W[P + "input_layernorm.weight"]), ll.rms_eps))
-        q = xn @ r(W[P + "self_attn.q_proj.weight"]).T
-        k = xn @ r(W[P + "self_attn.k_proj.weight"]).T
-        v = xn @ r(W[P + "self_attn.v_proj.weight"]).T
+        xn = r(rms_norm(h, r(W[P + "input_layernorm.weight"], "gamma"), ll.rms_eps), "xn")
+        q = xn @ r(W[P + "self_attn.q_proj.weight"], "w").T
+        k = xn @ r(W[P + "self_attn.k_proj.weight"], "w").T
+        v = xn @ r(W[P + "self_attn.v_proj.weight"], "w").T
         if cfg.use_lora:
             s = lora_scale(cfg)
-            xl = xn if drop is _ident else r(drop(xn))
-            tq = r(s * (xl @ r(W[P + "self_attn.q_proj.lora_A.weight"]).T))
-            tv = r(s * (xl @ r(W[P + "self_attn.v_proj.lora_A.weight"]).T))
-            q = q + tq @ r(W[P + "self_attn.q_proj.lora_B.weight"]).T
-            v = v + tv @ r(W[P + "self_attn.v_proj.lora_B.weight"]).T
+            xq = xn if drop is _ident else r(drop(xn), "xn")
+            xv = xn if drop is _ident else r(drop(xn), "xn")
+            tq = r(s * (xq @ r(W[P + "self_attn.q_proj.lora_A.weight"], "w").T), "t")
+            tv = r(s * (xv @ r(W[P + "self_attn.v_proj.lora_A.weight"], "w").T), "t")
+            q = q + tq @ r(W[P + "self_attn.q_proj.lora_B.weight"], "w").T
+            v = v + tv @ r(W[P + "self_attn.v_proj.lora_B.weight"], "w").T
         q = q.view(B, L, nq, hd)
         k = k.view(B, L, nkv, hd)
         v = v.view(B, L, nkv, hd)
@@ -235,22 +279,22 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
             t1, t2 = t[..., : hd // 2], t[..., hd // 2:]
             return torch.cat([t1 * cos - t2 * sin, t2 * cos + t1 * sin], dim=-1)
 
-        q, k, v = r(rot(q)), r(rot(k)), r(v)
+        q, k, v = r(rot(q), "qkv"), r(rot(k), "qkv"), r(v, "qkv")
         qh = q.permute(0, 2, 1, 3)
         kh = k.permute(0, 2, 1, 3).repeat_interleave(nq // nkv, dim=1)
         vh = v.permute(0, 2, 1, 3).repeat_interleave(nq // nkv, dim=1)
         s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
         s = s.masked_fill(~allowed[:, None], float("-inf"))
-        a = r((torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, L, nq * hd))
-        h = h + a @ r(W[P + "self_attn.o_proj.weight"]).T
-        xn2 = r(rms_norm(h, r(W[P + "post_attention_layernorm.weight"]), ll.rms_eps))
-        g = xn2 @ r(W[P + "mlp.gate_proj.weight"]).T
-        u = xn2 @ r(W[P + "mlp.up_proj.weight"]).T
-        act = r(F.silu(g) * u)
-        h = h + act @ r(W[P + "mlp.down_proj.weight"]).T
+        a = r((r(torch.softmax(s, dim=-1), "p") @ vh).permute(0, 2, 1, 3).reshape(B, L, nq * hd), "att")
+        h = h + a @ r(W[P + "self_attn.o_proj.weight"], "w").T
+        xn2 = r(rms_norm(h, r(W[P + "post_attention_layernorm.weight"], "gamma"), ll.rms_eps), "xn")
+        g = xn2 @ r(W[P + "mlp.gate_proj.weight"], "w").T
+        u = xn2 @ r(W[P + "mlp.up_proj.weight"], "w").T
+        act = r(F.silu(g) * u, "act")
+        h = h + act @ r(W[P + "mlp.down_proj.weight"], "w").T
         if collect is not None:
             collect.append(h)
-    return rms_norm(h, r(W[LLAMA + "norm.weight"]), ll.rms_eps)
+    return rms_norm(h, r(W[LLAMA + "norm.weight"], "gamma"), ll.rms_eps)
 
 
 # --------------------------------------------------------------------------------------
@@ -266,21 +310,23 @@ def lm_head_and_loss(W, final_hidden, fused_labels):
     return F.cross_entropy(shift_logits, shift_labels, ignore_index=-100)
 
 
-def mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect=None, labels=None):
+def mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect=None, labels=None, drop_qf=_ident,
+                 drop_lora=_ident):
     """labels given => also run the reference's discarded lm_head + CE (timing fidelity only)."""
+    r = _rounder(r)
     if labels is not None:
-        final = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect)
+        final = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, collect, drop_qf=drop_qf, drop_lora=drop_lora)
         fused = torch.cat([torch.full((labels.shape[0], cfg.q_num_query_tokens), -100, dtype=labels.dtype), labels], 1)
         lm_head_and_loss(W, final, fused)
         return final
-    img = linear(qformer(W, cfg, vision, r), W, "mllm.q_proj", r)
+    img = linear(qformer(W, cfg, vision, r, drop=drop_qf), W, "mllm.q_proj", r.scoped("qf"))
     img = img + W["mllm.vision_modality_embedding"]
-    txt = r(W[LLAMA + "embed_tokens.weight"])[input_ids] + W["mllm.text_modality_embedding"]
+    txt = r(W[LLAMA + "embed_tokens.weight"][input_ids], "emb") + W["mllm.text_modality_embedding"]
     fused = torch.cat([img, txt], dim=1)
     mask = torch.cat([torch.ones(img.shape[0], img.shape[1], dtype=attention_mask.dtype), attention_mask], dim=1)
     if collect is not None:
         collect.append(fused)
-    return llama_decoder(W, cfg, fused, mask, r, collect)
+    return llama_decoder(W, cfg, fused, mask, r, collect, drop=drop_lora)
 
 
 # --------------------------------------------------------------------------------------
@@ -291,6 +337,7 @@ def _stack(W, fmt, n, suffix):
 
 
 def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r, drop=_ident, xattn_pad=64):
+    r = _rounder(r).scoped("xa")
     ident = _rounder("fp32")
     B = x.shape[0]
     C, T, To = cfg.d_model, cfg.seq_len, cfg.out_len
@@ -323,7 +370,7 @@ def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r, drop=_ident, xattn_pad=64
     # cross attention: K = V = final_hidden, NO key padding mask (train.py:795-798)
     H = proj.shape[-1]
     Win, bin_ = W["ltsf.decoder.cross_attn.in_proj_weight"], W["ltsf.decoder.cross_attn.in_proj_bias"]
-    fh = r(final_hidden)
+    fh = r(final_hidden, "fh")
     q = r(proj @ r(Win[:H]).T + bin_[:H])
     k = r(fh @ r(Win[H:2 * H]).T + bin_[H:2 * H])
     v = r(fh @ r(Win[2 * H:]).T + bin_[2 * H:])
@@ -350,20 +397,34 @@ def denorm(t, norm_stat):
     return out
 
 
+def dropout_tapes(cfg, seed, p_layers=0.1):
+    """The four DropTapes of one train-mode forward, numbered as tcavt_amd.model.DropoutCtx.sub(block) numbers the HIP
+    path's sites (block << 16 + 1, ...): 0 lane-polygon encoder, 1 Q-Former (nn.Transformer*Layer default p = 0.1),
+    2 LoRA dropout (cfg.lora_dropout), 3 LTSF (cfg.ltsf_dropout)."""
+    ps = (p_layers, p_layers, cfg.lora_dropout, cfg.ltsf_dropout)
+    return {name: (DropTape(seed, p, first_site=(blk << 16) + 1) if p > 0.0 else _ident)
+            for blk, (name, p) in enumerate(zip(("poly", "qf", "lora", "ltsf"), ps))}
+
+
 def model_forward(W, cfg, x, vision, polygon, polygon_len, input_ids, attention_mask, y=None, norm_stat=None,
-                  contract="fp32", extras=None, labels=None):
+                  contract="fp32", extras=None, labels=None, dropout_seed=None):
     """Returns decoded [B,2,To] or (loss, decoded) like the reference.  `extras` (dict) receives
     intermediate tensors (poly_emb, final_hidden) for stage-wise parity checks.  `labels` switches
-    on the reference's discarded lm_head + CE work (see lm_head_and_loss)."""
+    on the reference's discarded lm_head + CE work (see lm_head_and_loss).  dropout_seed: a train-mode forward
+    (ddp_model.train(), train.py:1152) with the HIP path's Philox masks of that seed; extras["tapes"] then holds the
+    DropTapes (their .log = the dropout sites visited, in order)."""
     r = _rounder(contract)
     W = as_torch(W)
-    poly_emb = lane_polygon_encoder(W, cfg, polygon, polygon_len)
-    final_hidden = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, labels=labels)
-    decoded = ltsf_forward(W, cfg, x, poly_emb, final_hidden, r)
+    tp = dropout_tapes(cfg, dropout_seed) if dropout_seed is not None else dict.fromkeys(("poly", "qf", "lora", "ltsf"), _ident)
+    poly_emb = lane_polygon_encoder(W, cfg, polygon, polygon_len, drop=tp["poly"])
+    final_hidden = mllm_forward(W, cfg, vision, input_ids, attention_mask, r, labels=labels, drop_qf=tp["qf"],
+                                drop_lora=tp["lora"])
+    decoded = ltsf_forward(W, cfg, x, poly_emb, final_hidden, r, drop=tp["ltsf"])
     decoded = decoded + x[:, :, -1:]
     if extras is not None:
         extras["poly_emb"] = poly_emb
         extras["final_hidden"] = final_hidden
+        extras["tapes"] = tp
     if y is not None and norm_stat is not None:
         dp, dg = denorm(decoded, norm_stat), denorm(y, norm_stat)
         loss = F.mse_loss(dp[:, 0], dg[:, 0]) + F.mse_loss(dp[:, 1], dg[:, 1])

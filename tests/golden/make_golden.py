@@ -76,14 +76,16 @@ class _Tok:
 
 
 class LoRALinear(nn.Module):
-    """y = W x + (alpha/r) * B(A(x)); PEFT's LoRA layer in eval mode, restated."""
+    """y = W x + (alpha/r) * B(A(dropout(x))); PEFT's LoRA layer restated (every adapted Linear owns its own
+    lora_dropout module, so q_proj and v_proj draw independent masks in train mode)."""
 
-    def __init__(self, base, A, B, scale):
+    def __init__(self, base, A, B, scale, p_drop=0.0):
         super().__init__()
         self.base, self.A, self.B, self.scale = base, nn.Parameter(A), nn.Parameter(B), scale
+        self.lora_dropout = nn.Dropout(p_drop)
 
     def forward(self, x):
-        return self.base(x) + self.scale * ((x @ self.A.T) @ self.B.T)
+        return self.base(x) + self.scale * ((self.lora_dropout(x) @ self.A.T) @ self.B.T)
 
 
 def build_reference_model(ref, cfg, weights):
@@ -108,7 +110,7 @@ def build_reference_model(ref, cfg, weights):
                 key = f"{LLAMA_PREFIX}layers.{i}.self_attn.{proj}."
                 A = torch.from_numpy(weights[key + "lora_A.weight"])
                 B = torch.from_numpy(weights[key + "lora_B.weight"])
-                setattr(layer.self_attn, proj, LoRALinear(getattr(layer.self_attn, proj), A, B, scale))
+                setattr(layer.self_attn, proj, LoRALinear(getattr(layer.self_attn, proj), A, B, scale, cfg.lora_dropout))
     model.eval()
     return model
 
@@ -151,6 +153,103 @@ def run_model_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_ev
     })
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(f"[golden] {name}: loss={loss.item():.6f} decoded[0,:,0]={decoded[0, :, 0].tolist()}")
+
+
+def _sample(t, cap=512):
+    """Full tensor when it has <= cap elements, otherwise an evenly strided sample of <= cap elements (the fixture stays
+    small; tests draw the same sample with tcavt_amd-independent code: flat[::stride], stride = ceil(n / cap))."""
+    flat = t.detach().reshape(-1)
+    stride = -(-flat.numel() // cap)
+    return flat[::stride].to(torch.float32).numpy().copy()
+
+
+def run_train_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_every, seed):
+    """Gradient / optimizer / dropout-site fixture of one model case (tests/golden/<name>_train.npz):
+      * loss.backward() on the reference model in eval arithmetic (dropout off, deterministic), gradients of the
+        train.py trainable set (everything outside mllm, scripts/train.py:1140-1145) and -- for the LoRA-trainable
+        loop of modify_scripts/modify_train.py:512-528 -- of the adapter matrices;
+      * one torch.optim.AdamW(lr=5e-4, weight_decay=1e-4) step on the train.py set (scripts/train.py:1145,1182-1183);
+      * the sequence of dropout calls of ONE train-mode forward (ddp_model.train(), scripts/train.py:1152):
+        (kind, p, shape) of every F.dropout (nn.Dropout, attention weights of nn.MultiheadAttention's explicit path)
+        and every scaled_dot_product_attention with dropout_p > 0 (the need_weights=False path of
+        nn.Transformer*Layer); masks themselves are torch's RNG stream and are not portable, the SITES are."""
+    import torch.nn.functional as F
+
+    cfg = tconfig.PRESETS[preset](seq_len=T, out_len=To, use_lora=lora)
+    weights = make_weights(cfg, seed)
+    model = build_reference_model(ref, cfg, weights)
+    batch = synth.make_batch(cfg, B, text_len=text_len, seed=seed, ragged=ragged, min_text=4,
+                             empty_polygon_every=empty_every)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    ns = [tuple(float(v) for v in row) for row in batch["norm_stat"]]
+    pl = [int(v) for v in batch["lane_polygon_len"]]
+
+    def fwd():
+        return model(t["traj_emb"], t["vision_emb"], None, t["lane_polygon"], pl, y=t["target_traj"], norm_stat=ns,
+                     input_ids=t["input_ids"], attention_mask=t["attention_mask"], labels=t["labels"])
+
+    # ---- (1) gradients, eval arithmetic
+    named = dict(model.named_parameters())
+    trainable = [k for k in named if not k.startswith("mllm.")]
+    for k, p in named.items():
+        p.requires_grad_(k in trainable or k.endswith((".A", ".B")))
+    model.eval()
+    loss, _ = fwd()
+    loss.backward()
+    out = {"preset": np.array(preset), "seed": np.array(seed), "use_lora": np.array(lora), "seq_len": np.array(T),
+           "out_len": np.array(To), "loss": np.array(loss.item(), np.float64),
+           "trainable": np.array(trainable)}
+    for k in trainable:
+        g = named[k].grad
+        out["grad." + k] = _sample(g)
+        out["gnorm." + k] = np.array(g.double().norm().item())
+    if lora:
+        layers = model.mllm.llama_wrapper.llama_model.model.layers
+        for i, layer in enumerate(layers):
+            for proj in ("q_proj", "v_proj"):
+                m = getattr(layer.self_attn, proj)
+                key = f"{LLAMA_PREFIX}layers.{i}.self_attn.{proj}."
+                out["grad." + key + "lora_A.weight"] = m.A.grad.numpy().copy()
+                out["grad." + key + "lora_B.weight"] = m.B.grad.numpy().copy()
+    # ---- (2) one AdamW step on the train.py set
+    opt = torch.optim.AdamW([named[k] for k in trainable], lr=5e-4, weight_decay=1e-4)
+    opt.step()
+    for k in trainable:
+        out["adamw." + k] = _sample(named[k])
+    # ---- (3) dropout sites of a train-mode forward
+    sites = []
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+
+    def rec_dropout(input, p=0.5, training=True, inplace=False):
+        if training and p > 0.0:
+            sites.append((0, float(p), tuple(input.shape)))
+        return real_dropout(input, p, training, inplace)
+
+    def rec_sdpa(query, key, value, attn_mask=None, dropout_p=0.0, *a, **kw):
+        if dropout_p > 0.0:
+            sites.append((1, float(dropout_p), tuple(query.shape[:-1]) + (key.shape[-2],)))  # shape of the weights
+        return real_sdpa(query, key, value, attn_mask, dropout_p, *a, **kw)
+
+    F.dropout, F.scaled_dot_product_attention = rec_dropout, rec_sdpa
+    try:
+        model.train()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            fwd()
+    finally:
+        F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+        model.eval()
+    out["drop_kind"] = np.array([s_[0] for s_ in sites], np.int32)
+    out["drop_p"] = np.array([s_[1] for s_ in sites], np.float64)
+    out["drop_numel"] = np.array([int(np.prod(s_[2])) for s_ in sites], np.int64)
+    shp = np.zeros((len(sites), 4), np.int64)
+    for i, s_ in enumerate(sites):
+        shp[i, : len(s_[2])] = s_[2]
+    out["drop_shape"] = shp
+    np.savez_compressed(os.path.join(HERE, name + "_train.npz"), **out)
+    print(f"[golden] {name}_train: loss={loss.item():.6f} {len(trainable)} gradient tensors, {len(sites)} dropout sites")
+    for s_ in sites:
+        print("   ", s_)
 
 
 def run_cv_case():
@@ -215,6 +314,8 @@ def main():
         ref = _import(os.path.join(REF, "ablation_study_without_lora.py"), "ref_nolora")
     for case in CASES:
         run_model_case(ref, *case)
+    for case in CASES[:2]:  # the ragged LoRA case and the ragged no-LoRA (train.py) case
+        run_train_case(ref, *case)
     run_cv_case()
 
 

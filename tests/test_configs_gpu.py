@@ -141,8 +141,7 @@ def test_config2_full_size_properties(gpu, full_model):
 @pytest.mark.timeout(1200)
 def test_config2_full_size_two_samples_against_oracle(gpu, full_model):
     """Two samples of the full-size batch against the CPU oracle with the same host-generated weights (fp32 graph and the
-    bf16-contract graph): the HIP path must be as close to the fp32 result as the bf16 contract itself is; ADE / FDE
-    against the contract's."""
+    fp16-contract graph): decoded, ADE and FDE within 1e-3 of the fp32 result."""
     from oracle import forward as O
 
     cfg, W, m, t = full_model
@@ -155,7 +154,7 @@ def test_config2_full_size_two_samples_against_oracle(gpu, full_model):
         args = (W, cfg, t2["traj_emb"], t2["vision_emb"], t2["lane_polygon"], t2["lane_polygon_len"], t2["input_ids"],
                 t2["attention_mask"])
         _, d32 = O.model_forward(*args, y=t2["target_traj"], norm_stat=t2["norm_stat"], contract="fp32")
-        _, d16 = O.model_forward(*args, y=t2["target_traj"], norm_stat=t2["norm_stat"], contract="bf16")
+        _, d16 = O.model_forward(*args, y=t2["target_traj"], norm_stat=t2["norm_stat"], contract="fp16")
     f_dec, o_dec, e_dec = rel_err(dec, d32), rel_err(d16, d32), rel_err(dec, d16)
     mg, m32, m16 = (O.traj_metrics(d, t2["target_traj"], t2["norm_stat"]) for d in (dec, d32, d16))
     ade16 = abs(mg["ade_sum"] - m16["ade_sum"]) / m16["ade_sum"]
@@ -164,5 +163,6 @@ def test_config2_full_size_two_samples_against_oracle(gpu, full_model):
     fde32 = abs(mg["fde_sum"] - m32["fde_sum"]) / m32["fde_sum"]
     print(f"[config 2 vs oracle] decoded: vs fp32 {f_dec:.2e} (contract's own {o_dec:.2e}), vs contract {e_dec:.2e}; "
           f"ADE/FDE vs contract {ade16:.2e}/{fde16:.2e}, vs fp32 {ade32:.2e}/{fde32:.2e}")
-    assert f_dec <= 1.5 * o_dec + 1e-3 and e_dec <= 1.5 * o_dec + 1e-3
-    assert ade16 < 1e-3 and fde16 < 1e-3
+    # BASELINE.json's bar at the full model size, against the reference's fp32 arithmetic (fp16 operand storage)
+    assert f_dec < 1e-3 and e_dec < 1e-3
+    assert ade32 < 1e-3 and fde32 < 1e-3 and ade16 < 1e-3 and fde16 < 1e-3

@@ -3,22 +3,18 @@
 References:
   (1) golden fixture  = the reference's own modules, fp32           (tests/golden/*.npz)
   (2) oracle fp32     = CPU restatement, pinned to (1) in tests/test_oracle_golden.py
-  (3) oracle bf16     = same graph with the GPU path's bf16 rounding points ("bf16 contract")
+  (3) oracle contract = same graph with the GPU path's 16-bit rounding points ("fp16" / "bf16" contract)
 
-What can and cannot be asserted (measured, see DESIGN.md "Precision contract"):
-  * bf16 storage of GEMM operands costs ~1.6e-3 relative per contraction against fp32, which
-    compounds to ~7e-3 on the decoder's final hidden states and ~1.4e-3 on the decoded
-    trajectories -- for ANY bf16 pipeline, (3) included.  Two bf16 pipelines that differ only in
-    fp32 summation order also drift apart at the ~2e-3 level over a whole stack (a 1e-6 input
-    perturbation moves (3) by 1.8e-3 on final_hidden), so a whole-model "<= 1e-3 vs (3)" bar is
-    not a property of correctness.  The 1e-3 bar of BASELINE.json is therefore enforced where it
-    is well-posed:
-      - per STAGE from identical inputs (one decoder layer, Q-Former, LTSF head): <= 1e-3 vs (3)
-      - fp32-only stages (lane polygon encoder, metrics): <= 1e-4 / 1e-5 vs (1)/(2)
-      - whole model: the HIP path must be as close to the fp32 reference (1) as the bf16 contract
-        itself is: err_hip <= 1.5 * err_(3) + 1e-3, plus decoded within 3e-3 of (1)
-      - ADE/FDE (pixels): within 1e-3 relative of (3)'s metrics and 3e-3 of (2)'s;
-        min-over-K indices bit-exact
+The HIP path stores GEMM operands in 16 bits and accumulates in fp32.  Its DEFAULT storage type is fp16
+(model.set_storage): 11 significant bits keep the whole model inside BASELINE.json's bar against the reference's own
+fp32 arithmetic, and that bar is asserted here directly:
+      - decoded trajectories within 1e-3 (relative) of fixture (1) / oracle (2), ADE / FDE within 1e-3
+      - per STAGE from identical inputs (one decoder layer, Q-Former, LTSF head): <= 1e-3 vs (2) and vs (3)
+      - fp32-only stages (lane polygon encoder, metrics): <= 1e-4 / 1e-5; min-over-K indices bit-exact
+bf16 storage (the round-1 contract, still used by the LoRA-trainable variant whose backward kernels read bf16 tapes)
+costs ~1.6e-3 per contraction and compounds to ~7e-3 on the final hidden states for ANY bf16 pipeline, (3) included
+(profiles/r02_error_budget_full_size.json tabulates every rounding point); for it the bars are per stage <= 1e-3 vs (3)
+and, whole model, "as close to fp32 as the contract itself": err_hip <= 1.5 * err_(3) + 1e-3.
 """
 import numpy as np
 import pytest
@@ -29,10 +25,14 @@ from tests.util import MODEL_CASES, batch_tensors, load_case, rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(cfg, weights, t, dev, with_loss=True):
+STORAGE = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _run_gpu(cfg, weights, t, dev, with_loss=True, storage="fp16"):
     from tcavt_amd import model
 
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    m.set_storage(STORAGE[storage])
     g = {k: v.to(dev) for k, v in t.items()}
     kw = dict(input_ids=g["input_ids"], attention_mask=g["attention_mask"], labels=g["labels"])
     if with_loss:
@@ -44,18 +44,19 @@ def _run_gpu(cfg, weights, t, dev, with_loss=True):
     return m, out
 
 
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
 @pytest.mark.parametrize("name", MODEL_CASES)
-def test_forward_matches_oracle_and_fixture(gpu, name):
+def test_forward_matches_oracle_and_fixture(gpu, name, storage):
     from oracle import forward as O
 
     cfg, weights, fx = load_case(name)
     t = batch_tensors(fx)
-    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"])
+    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"], storage=storage)
     ex16 = {}
     with torch.no_grad():
         loss16, dec16 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
                                         t["lane_polygon_len"], t["input_ids"], t["attention_mask"],
-                                        y=t["target_traj"], norm_stat=t["norm_stat"], contract="bf16", extras=ex16)
+                                        y=t["target_traj"], norm_stat=t["norm_stat"], contract=storage, extras=ex16)
     got_poly = m.last.poly_emb.cpu()
     got_fh = m.last.final_hidden.cpu()
     got_dec = decoded.cpu()
@@ -67,15 +68,19 @@ def test_forward_matches_oracle_and_fixture(gpu, name):
     # and vs the reference's fp32 result
     f_fh = rel_err(got_fh, fx["exp_final_hidden"])
     f_dec = rel_err(got_dec, fx["exp_decoded"])
-    print(f"[parity {name}] final_hidden: vs bf16-oracle {e_fh:.2e}, vs reference fp32 {f_fh:.2e}; "
-          f"decoded: vs bf16-oracle {e_dec:.2e}, vs reference fp32 {f_dec:.2e}")
+    print(f"[parity {name} {storage}] final_hidden: vs {storage}-oracle {e_fh:.2e}, vs reference fp32 {f_fh:.2e}; "
+          f"decoded: vs {storage}-oracle {e_dec:.2e}, vs reference fp32 {f_dec:.2e}")
     o_fh = rel_err(ex16["final_hidden"], fx["exp_final_hidden"])
     o_dec = rel_err(dec16, fx["exp_decoded"])
-    print(f"[parity {name}] bf16 contract's own error vs reference fp32: final_hidden {o_fh:.2e}, decoded {o_dec:.2e}")
+    print(f"[parity {name} {storage}] the contract's own error vs reference fp32: final_hidden {o_fh:.2e}, decoded {o_dec:.2e}")
     assert f_fh <= 1.5 * o_fh + 1e-3 and f_dec <= 1.5 * o_dec + 1e-3
     assert e_fh <= 1.5 * o_fh + 1e-3 and e_dec <= 1.5 * o_dec + 1e-3
-    assert f_dec < 3e-3
-    assert abs(loss.item() - float(fx["exp_loss"])) / float(fx["exp_loss"]) < 1e-2
+    if storage == "fp16":  # BASELINE.json's bar, against the reference's own fp32 result
+        assert f_dec < 1e-3 and f_fh < 2e-3
+        assert abs(loss.item() - float(fx["exp_loss"])) / float(fx["exp_loss"]) < 2e-3
+    else:
+        assert f_dec < 3e-3
+        assert abs(loss.item() - float(fx["exp_loss"])) / float(fx["exp_loss"]) < 1e-2
     assert abs(loss.item() - loss16.item()) / abs(loss16.item()) < 1e-2
 
 
@@ -91,7 +96,7 @@ def test_decoded_only_branch_and_padded_rows(gpu):
     ex = {}
     with torch.no_grad():
         O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
-                        t["input_ids"], t["attention_mask"], contract="bf16", extras=ex)
+                        t["input_ids"], t["attention_mask"], contract="fp16", extras=ex)
     mask = t["attention_mask"]
     pad = torch.cat([torch.zeros(mask.shape[0], cfg.q_num_query_tokens, dtype=torch.bool), mask == 0], dim=1)
     got = m.last.final_hidden.cpu()[pad]
@@ -126,7 +131,8 @@ def test_metrics_kernel_known_answers_and_argmin(gpu):
     assert abs(s[4].item() - ref["rmse_sum"]) / ref["rmse_sum"] < 1e-5
 
 
-def test_ade_fde_parity_on_fixed_seed_batch(gpu):
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
+def test_ade_fde_parity_on_fixed_seed_batch(gpu, storage):
     """ADE/FDE of the HIP path vs the oracle on a seeded synthetic batch at a mid-size shape."""
     from oracle import forward as O
     from tcavt_amd import config, ops, synth
@@ -136,10 +142,10 @@ def test_ade_fde_parity_on_fixed_seed_batch(gpu):
     weights = make_weights(cfg, 21)
     b = synth.make_batch(cfg, 8, text_len=112, seed=21, ragged=True, min_text=40)
     t = {k: torch.from_numpy(v) for k, v in b.items()}
-    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"])
+    m, (loss, decoded) = _run_gpu(cfg, weights, t, gpu["device"], storage=storage)
     with torch.no_grad():
         dec16 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
-                                t["input_ids"], t["attention_mask"], contract="bf16")
+                                t["input_ids"], t["attention_mask"], contract=storage)
         dec32 = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
                                 t["input_ids"], t["attention_mask"], contract="fp32")
     dev = gpu["device"]
@@ -148,19 +154,20 @@ def test_ade_fde_parity_on_fixed_seed_batch(gpu):
     r16 = O.traj_metrics(dec16, t["target_traj"], t["norm_stat"])
     r32 = O.traj_metrics(dec32, t["target_traj"], t["norm_stat"])
     ade, fde = sums[2].item() / 8, sums[3].item() / 8
-    print(f"[ADE/FDE] hip {ade:.4f}/{fde:.4f}  oracle-bf16 {r16['ade_sum']/8:.4f}/{r16['fde_sum']/8:.4f}  "
+    print(f"[ADE/FDE {storage}] hip {ade:.4f}/{fde:.4f}  oracle-{storage} {r16['ade_sum']/8:.4f}/{r16['fde_sum']/8:.4f}  "
           f"oracle-fp32 {r32['ade_sum']/8:.4f}/{r32['fde_sum']/8:.4f}")
     assert abs(ade - r16["ade_sum"] / 8) / (r16["ade_sum"] / 8) < 1e-3
     assert abs(fde - r16["fde_sum"] / 8) / (r16["fde_sum"] / 8) < 1e-3
-    assert abs(ade - r32["ade_sum"] / 8) / (r32["ade_sum"] / 8) < 3e-3
-    assert abs(fde - r32["fde_sum"] / 8) / (r32["fde_sum"] / 8) < 3e-3
+    bar = 1e-3 if storage == "fp16" else 3e-3  # fp16: BASELINE.json's "ADE/FDE within 1e-3 of reference", directly
+    assert abs(ade - r32["ade_sum"] / 8) / (r32["ade_sum"] / 8) < bar
+    assert abs(fde - r32["fde_sum"] / 8) / (r32["fde_sum"] / 8) < bar
 
 
 # ---------------------------------------------------------------------------------------------
 # stage-level parity from IDENTICAL inputs: this is where "<= 1e-3 vs the bf16 contract" is a
 # well-posed requirement (no cross-stage amplification of summation-order noise)
 # ---------------------------------------------------------------------------------------------
-def _tiny_model(dev, layers, lora=True, seed=5, q_layers=4):
+def _tiny_model(dev, layers, lora=True, seed=5, q_layers=4, storage="fp16"):
     import dataclasses
 
     from tcavt_amd import config, model
@@ -171,17 +178,28 @@ def _tiny_model(dev, layers, lora=True, seed=5, q_layers=4):
                               q_dec_layers=q_layers)
     weights = make_weights(cfg, seed)
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    m.set_storage(STORAGE[storage])
     return cfg, weights, m
 
 
+def _stage_bars(storage, e16, e32, o32, tight=True):
+    """e16: HIP vs the storage contract's oracle; e32: HIP vs fp32; o32: the contract's own distance from fp32."""
+    if tight:
+        assert e16 < 1e-3
+    assert e32 <= 1.5 * o32 + 1e-3
+    if storage == "fp16":
+        assert e32 < 1e-3  # one stage from identical inputs, against the reference's arithmetic itself
+
+
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
 @pytest.mark.parametrize("lora", [True, False])
-def test_stage_one_decoder_layer(gpu, lora):
+def test_stage_one_decoder_layer(gpu, lora, storage):
     """RMSNorm -> QKV(+LoRA)+RoPE -> causal GQA attention -> o_proj -> RMSNorm -> SiLU-MLP -> final norm,
     one layer, from the same embeddings, ragged right padding."""
     from oracle import forward as O
 
     dev = gpu["device"]
-    cfg, weights, m = _tiny_model(dev, layers=1, lora=lora)
+    cfg, weights, m = _tiny_model(dev, layers=1, lora=lora, storage=storage)
     g = torch.Generator().manual_seed(3)
     B, L, H = 3, 96, cfg.llama.hidden
     emb = torch.randn(B, L, H, generator=g)
@@ -191,42 +209,41 @@ def test_stage_one_decoder_layer(gpu, lora):
     with torch.no_grad():
         out = m.mllm.llama_wrapper(emb.to(dev), mask.to(dev), output_hidden_states=True).hidden_states[-1].cpu()
         W = O.as_torch(weights)
-        ref16 = O.llama_decoder(W, cfg, emb, mask, O._rounder("bf16"))
+        ref16 = O.llama_decoder(W, cfg, emb, mask, O._rounder(storage))
         ref32 = O.llama_decoder(W, cfg, emb, mask, O._rounder("fp32"))
     e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
-    print(f"[stage decoder-layer lora={lora}] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
-    assert e16 < 1e-3
-    assert e32 <= 1.5 * o32 + 1e-3
+    print(f"[stage decoder-layer lora={lora} {storage}] hip vs oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    _stage_bars(storage, e16, e32, o32)
 
 
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
 @pytest.mark.parametrize("depth", [1, 4])
-def test_stage_qformer(gpu, depth):
+def test_stage_qformer(gpu, depth, storage):
     """depth=1: one encoder + one decoder layer (the 1e-3 bar); depth=4: the reference's 4+4 stack,
     where summation-order noise compounds and only the contract-relative bar is well-posed."""
     from oracle import forward as O
 
     dev = gpu["device"]
-    cfg, weights, m = _tiny_model(dev, layers=1, q_layers=depth)
+    cfg, weights, m = _tiny_model(dev, layers=1, q_layers=depth, storage=storage)
     g = torch.Generator().manual_seed(4)
     vis = torch.randn(4, cfg.seq_len, cfg.vision_dim, generator=g)
     with torch.no_grad():
         out = m.mllm.qformer(vis.to(dev)).cpu()
         W = O.as_torch(weights)
-        ref16 = O.qformer(W, cfg, vis, O._rounder("bf16"))
+        ref16 = O.qformer(W, cfg, vis, O._rounder(storage))
         ref32 = O.qformer(W, cfg, vis, O._rounder("fp32"))
     e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
-    print(f"[stage qformer depth={depth}] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
-    if depth == 1:
-        assert e16 < 1e-3
-    assert e32 <= 1.5 * o32 + 1e-3
+    print(f"[stage qformer depth={depth} {storage}] hip vs oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    _stage_bars(storage, e16, e32, o32, tight=(depth == 1 or storage == "fp16"))
 
 
-def test_stage_ltsf_head(gpu):
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
+def test_stage_ltsf_head(gpu, storage):
     """TransformerLTSF incl. the head_dim-H/2 cross-attention over given final hidden states."""
     from oracle import forward as O
 
     dev = gpu["device"]
-    cfg, weights, m = _tiny_model(dev, layers=1)
+    cfg, weights, m = _tiny_model(dev, layers=1, storage=storage)
     g = torch.Generator().manual_seed(6)
     B, L, H = 5, 80, cfg.llama.hidden
     x = torch.rand(B, 2, cfg.seq_len, generator=g)
@@ -235,12 +252,11 @@ def test_stage_ltsf_head(gpu):
     with torch.no_grad():
         out = m.ltsf(x.to(dev), poly.to(dev), fh.to(dev)).cpu()
         W = O.as_torch(weights)
-        ref16 = O.ltsf_forward(W, cfg, x, poly, fh, O._rounder("bf16"))
+        ref16 = O.ltsf_forward(W, cfg, x, poly, fh, O._rounder(storage))
         ref32 = O.ltsf_forward(W, cfg, x, poly, fh, O._rounder("fp32"))
     e16, e32, o32 = rel_err(out, ref16), rel_err(out, ref32), rel_err(ref16, ref32)
-    print(f"[stage ltsf] hip vs bf16-oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
-    assert e16 < 1e-3
-    assert e32 <= 1.5 * o32 + 1e-3
+    print(f"[stage ltsf {storage}] hip vs oracle {e16:.2e}; hip vs fp32 {e32:.2e}; contract vs fp32 {o32:.2e}")
+    _stage_bars(storage, e16, e32, o32)
 
 
 def test_evaluate_model_k_candidates(gpu):
@@ -353,7 +369,7 @@ def test_edge_case_batches_match_oracle(gpu, case):
     with torch.no_grad():
         loss_o, dec_o = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
                                         t["lane_polygon_len"], t["input_ids"], t["attention_mask"], y=t["target_traj"],
-                                        norm_stat=t["norm_stat"], contract="bf16", extras=ex)
+                                        norm_stat=t["norm_stat"], contract="fp16", extras=ex)
         _, dec_f = O.model_forward(weights, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"],
                                    t["lane_polygon_len"], t["input_ids"], t["attention_mask"], y=t["target_traj"],
                                    norm_stat=t["norm_stat"], contract="fp32")
@@ -361,7 +377,6 @@ def test_edge_case_batches_match_oracle(gpu, case):
     assert rel_err(m.last.poly_emb.cpu(), ex["poly_emb"]) < 1e-4
     if case == "no_polygons":
         assert (m.last.poly_emb == 0).all()
-    o_dec = rel_err(dec_o, dec_f)  # the bf16 contract's own distance from fp32
-    assert rel_err(decoded.cpu(), dec_f) <= 1.5 * o_dec + 1e-3
-    assert rel_err(decoded.cpu(), dec_o) <= 1.5 * o_dec + 1e-3
+    assert rel_err(decoded.cpu(), dec_f) < 1e-3  # fp16 storage: BASELINE.json's bar against the fp32 graph itself
+    assert rel_err(decoded.cpu(), dec_o) < 1e-3
     assert abs(loss.item() - loss_o.item()) <= 1e-2 * abs(loss_o.item())

@@ -20,7 +20,7 @@ def test_oracle_matches_reference_fixture(name):
                                         y=t["target_traj"], norm_stat=t["norm_stat"], contract="fp32",
                                         extras=extras)
         W = O.as_torch(weights)
-        img = O.qformer(W, cfg, t["vision_emb"], lambda z: z)
+        img = O.qformer(W, cfg, t["vision_emb"], O._rounder("fp32"))
     assert rel_err(extras["poly_emb"], fx["exp_poly_emb"]) < 2e-5
     assert rel_err(img, fx["exp_img_tokens"]) < 2e-5
     assert rel_err(extras["final_hidden"], fx["exp_final_hidden"]) < 5e-5

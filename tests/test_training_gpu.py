@@ -39,7 +39,7 @@ def test_gradients_match_autograd(gpu, name):
     cfg, weights, fx = load_case(name)
     t = batch_tensors(fx)
     ref_loss, ref = _oracle_grads(cfg, weights, t)
-    _, ref16 = _oracle_grads(cfg, weights, t, contract="bf16")  # casts are straight-through for autograd
+    _, ref16 = _oracle_grads(cfg, weights, t, contract="fp16")  # casts are straight-through for autograd
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
     tr = training.Trainer(m)
     g = {k: v.to(dev) for k, v in t.items()}
@@ -129,7 +129,7 @@ def test_ltsf_backward_from_fixed_hidden_states(gpu):
     for k in names:
         W[k].requires_grad_(True)
     poly_r = poly.clone().requires_grad_(True)
-    out = O.ltsf_forward(W, cfg, t["traj_emb"], poly_r, fh, O._rounder("bf16")) + t["traj_emb"][:, :, -1:]
+    out = O.ltsf_forward(W, cfg, t["traj_emb"], poly_r, fh, O._rounder("fp16")) + t["traj_emb"][:, :, -1:]
     dp, dg = O.denorm(out, t["norm_stat"]), O.denorm(t["target_traj"], t["norm_stat"])
     loss = torch.nn.functional.mse_loss(dp[:, 0], dg[:, 0]) + torch.nn.functional.mse_loss(dp[:, 1], dg[:, 1])
     loss.backward()
@@ -138,8 +138,8 @@ def test_ltsf_backward_from_fixed_hidden_states(gpu):
     tr = training.Trainer(m)
     with torch.no_grad():
         x = t["traj_emb"].to(dev)
-        fh_b = torch.zeros(B * L + 64, H, dtype=torch.bfloat16, device=dev)
-        ops.cast_bf16(fh.to(dev).view(B * L, H), out=fh_b)
+        fh_b = torch.zeros(B * L + 64, H, dtype=m.storage, device=dev)
+        ops.cast16(fh.to(dev).view(B * L, H), out=fh_b)
         dec = m.ltsf(x, poly.to(dev), fh.to(dev), final_hidden_bf16=fh_b, _fuse_last_residual=True)
         tr.book.grads.zero_()
         tr.bw._poly_emb, tr.bw._fh_b, tr.bw._L = poly.to(dev), fh_b, L
@@ -273,7 +273,7 @@ def test_ltsf_backward_with_dropout(gpu):
     poly_r = poly.clone().requires_grad_(True)
     seed = 4321
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
-    out = O.ltsf_forward(W, cfg, t["traj_emb"], poly_r, fh, O._rounder("bf16"),
+    out = O.ltsf_forward(W, cfg, t["traj_emb"], poly_r, fh, O._rounder("fp16"),
                          drop=O.DropTape(seed, m.ltsf.dropout_p)) + t["traj_emb"][:, :, -1:]
     dp, dg = O.denorm(out, t["norm_stat"]), O.denorm(t["target_traj"], t["norm_stat"])
     loss = torch.nn.functional.mse_loss(dp[:, 0], dg[:, 0]) + torch.nn.functional.mse_loss(dp[:, 1], dg[:, 1])
@@ -281,8 +281,8 @@ def test_ltsf_backward_with_dropout(gpu):
     tr = training.Trainer(m)
     with torch.no_grad():
         x = t["traj_emb"].to(dev)
-        fh_b = torch.zeros(B * L + 64, H, dtype=torch.bfloat16, device=dev)
-        ops.cast_bf16(fh.to(dev).view(B * L, H), out=fh_b)
+        fh_b = torch.zeros(B * L + 64, H, dtype=m.storage, device=dev)
+        ops.cast16(fh.to(dev).view(B * L, H), out=fh_b)
         m.ltsf.dctx = m.ltsf.attn_block.dctx = model.DropoutCtx(seed)
         dec = m.ltsf(x, poly.to(dev), fh.to(dev), final_hidden_bf16=fh_b, _fuse_last_residual=True)
         m.ltsf.dctx = m.ltsf.attn_block.dctx = None

@@ -139,7 +139,8 @@ class Backward:
         return gx
 
     def lin_bwd_bf16(self, tag, x_b, W, gy, gW, gb, gx=None, xT=None, pin=None):
-        """y = bf16(x) bf16(W)^T + b on MFMA.  x_b bf16 [M,K]; W fp32 param [N,K]; gy bf16 or fp32 [M,N].
+        """y = x16 W16^T + b on MFMA.  x_b: the forward's 16-bit activation [M,K] (fp16 or bf16; its transposed copy is bf16
+        either way); W fp32 param [N,K]; gy bf16 or fp32 [M,N].
         gW fp32 [N,K] = gy^T x, gb = colsum(gy), optional gx [M,K] (dtype of the given buffer) = gy W."""
         M, K = x_b.shape
         N = W.shape[0]
@@ -178,11 +179,13 @@ class Backward:
         nh = dec.cross_nhead
         dh = H // nh
         fwd = lambda name, shape, dt=torch.float32: ws.get("lt." + name, shape, dt, dev)
+        st = m.storage  # 16-bit type of the forward's activations (fp16 by default); gradient-side tensors are bf16, and
+        # a forward activation that enters a gradient-side contraction is converted while it is transposed (ops.transpose16)
         # saved forward activations
         f2 = fwd("f2", (M, C)); f1 = fwd("f1", (M, C)); fn = fwd("fn", (M, C)); fused = fwd("fused", (M, C))
-        cross = fwd("cross", (M, H), torch.bfloat16); att = fwd("att", (M, H), torch.bfloat16)
-        q = fwd("q", (M, H), torch.bfloat16); proj = fwd("proj", (M, H), torch.bfloat16)
-        dec_tb = fwd("dectb", (M, C), torch.bfloat16)
+        cross = fwd("cross", (M, H), st); att = fwd("att", (M, H), st)
+        q = fwd("q", (M, H), st); proj = fwd("proj", (M, H), st)
+        dec_tb = fwd("dectb", (M, C), st)
         fl = dec.fusion_layer
 
         # head: out = f2 W_out^T + b (+ last position, no gradient needed)
@@ -336,8 +339,8 @@ class Backward:
         Tp = _rup(To, 64)
         M = B * To
         P = self.m.ltsf._prepared()
-        q = ws.get("lt.q", (M, H), torch.bfloat16, dev)
-        kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev)
+        q = ws.get("lt.q", (M, H), self.m.ltsf.storage, dev)
+        kx = ws.get("lt.k", (B * L + XATTN_PAD, H), self.m.ltsf.storage, dev)
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
         scale = 1.0 / math.sqrt(dh)
         # v (non-transposed, bf16) is recomputed: the forward only kept v^T in fp16.  It depends on no gradient, so

@@ -60,16 +60,16 @@ _SIGNATURES = {
     "tcavt_init": [c_int, ctypes.POINTER(c_int)],
     "tcavt_gemm_bf16": [ctypes.POINTER(GemmArgs), c_void_p],
     "tcavt_rmsnorm": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, ctypes.c_uint64,
-                      ctypes.c_uint32, c_void_p],
-    "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p],
-    "tcavt_cast_f32_bf16": [c_void_p, c_void_p, c_int64, c_void_p],
+                      ctypes.c_uint32, c_int, c_void_p],
+    "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_cast_f32_16": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                         c_int, c_void_p, c_void_p],
+                         c_int, c_void_p, c_int, c_void_p],
     "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,
                            ctypes.c_uint32, c_void_p],
     "tcavt_dropout": [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                   c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_gemm_f32": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
@@ -79,14 +79,14 @@ _SIGNATURES = {
     "tcavt_ltsf_front": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                          c_int, c_void_p],
     "tcavt_ltsf_decode": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "tcavt_transpose_ct": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_transpose_ct": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_out_head": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                        c_int, c_void_p],
     "tcavt_traj_metrics": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                            c_void_p],
     "tcavt_gemm_f32_strided": [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
                                c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
-    "tcavt_transpose16": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p],
+    "tcavt_transpose16": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p],
     "tcavt_transpose_f32_bf16": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_colsum": [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_relu_bwd": [c_void_p, c_void_p, c_int, c_int64, c_void_p],

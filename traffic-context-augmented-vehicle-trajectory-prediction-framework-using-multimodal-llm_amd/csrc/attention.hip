@@ -29,8 +29,6 @@
 
 namespace tcavt {
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
 __device__ __forceinline__ f16x8 cvt8_f16(const float* v) {
   f16x8 o;
 #pragma unroll
@@ -57,7 +55,9 @@ __device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits
 
 // MAXT = launch bound: 512 threads (GQA groups up to 4, the Llama-3.2-1B case) leaves the compiler 256 VGPRs per
 // lane -- with the 1024-thread bound (groups up to 8) the kernel is held to 128 and spills.
-template <int MAXT>
+// F16: q|k|v and the output are fp16 (the forward path's default storage): S^T = K . Q^T runs on the f16 MFMA and V needs
+// no conversion while it is transposed into LDS.
+template <int MAXT, bool F16>
 __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
                                                               bf16_t* __restrict__ out,
                                                               const int* __restrict__ kv_len_p,
@@ -91,8 +91,14 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
     if (r1 < L) bb = *reinterpret_cast<const u32x4*>(base + (long)r1 * ld + voff + c * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const unsigned int lo = bf16pair_to_f16pair(a[e] & 0xffffu, bb[e] & 0xffffu);
-      const unsigned int hi = bf16pair_to_f16pair(a[e] >> 16, bb[e] >> 16);
+      unsigned int lo, hi;
+      if constexpr (F16) {
+        lo = (a[e] & 0xffffu) | (bb[e] << 16);
+        hi = (a[e] >> 16) | (bb[e] & 0xffff0000u);
+      } else {
+        lo = bf16pair_to_f16pair(a[e] & 0xffffu, bb[e] & 0xffffu);
+        hi = bf16pair_to_f16pair(a[e] >> 16, bb[e] >> 16);
+      }
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e) * vstride + r0) = lo;
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e + 1) * vstride + r0) = hi;
     }
@@ -139,7 +145,10 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + hh) ^ kswz) << 4));
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+        if constexpr (F16)
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[s]), sacc, 0, 0, 0);
+        else
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
       }
       // scale + mask + tile max.  Only the diagonal tile and a tile that straddles kv_len need per-element masks
       // (wave-uniform test); every other tile is all-valid for all 32 queries of the block.
@@ -220,10 +229,10 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 8 * g + 4 * hh;
-        u32x2 a = {pack_bf16x2(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                   pack_bf16x2(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-        u32x2 c = {pack_bf16x2(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                   pack_bf16x2(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+        u32x2 a = {pack16x2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
+                   pack16x2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
+        u32x2 c = {pack16x2<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv),
+                   pack16x2<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(orow + d) = a;
         *reinterpret_cast<u32x2*>(orow + 32 + d) = c;
       }
@@ -239,12 +248,25 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
 // K and V rows are read from global/L2 (sequences here are <= 544 keys, the
 // per-(b,h) K/V footprint is <= 2 MB and is re-read from L2).
 // ---------------------------------------------------------------------------
+// element types of the small attention kernels: float, or 16-bit storage tagged with its format
+struct b16 { bf16_t v; };  // bf16
+struct h16 { bf16_t v; };  // fp16
 template <typename T>
 __device__ __forceinline__ float ldf(const T* p);
 template <>
 __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
 template <>
-__device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float ldf<b16>(const b16* p) { return bf16_to_f32(p->v); }
+template <>
+__device__ __forceinline__ float ldf<h16>(const h16* p) { return f16_to_f32(p->v); }
+template <typename T>
+__device__ __forceinline__ void stf(T* p, float x);
+template <>
+__device__ __forceinline__ void stf<float>(float* p, float x) { *p = x; }
+template <>
+__device__ __forceinline__ void stf<b16>(b16* p, float x) { p->v = f32_to_bf16(x); }
+template <>
+__device__ __forceinline__ void stf<h16>(h16* p, float x) { p->v = f32_to_f16(x); }
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q, long ldq,
@@ -306,8 +328,7 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const TI* __restrict__ q
     float acc = 0.f;
     for (int j = 0; j < klen; ++j) acc += row[j] * ldf<TI>(vb + (long)j * ldv + d);
     TO* o = out + ((long)b * Lq + i) * ldo + h * dh + d;
-    if constexpr (sizeof(TO) == 2) *o = f32_to_bf16(acc);
-    else *o = acc;
+    stf<TO>(o, acc);
   }
 }
 
@@ -384,8 +405,7 @@ __global__ __launch_bounds__(256) void mha_lds_kernel(const TI* __restrict__ q, 
     float acc = 0.f;
     for (int j = 0; j < klen; ++j) acc = fmaf(row[j], Vs[j * ds + d], acc);
     TO* o = out + ((long)b * Lq + i) * ldo + h * dh + d;
-    if constexpr (sizeof(TO) == 2) *o = f32_to_bf16(acc);
-    else *o = acc;
+    stf<TO>(o, acc);
   }
 }
 
@@ -394,8 +414,9 @@ __global__ __launch_bounds__(256) void mha_lds_kernel(const TI* __restrict__ q, 
 using namespace tcavt;
 
 extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B, int L,
-                                     int nq, int nkv, float scale, tcavt_stream_t stream) {
+                                     int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(qkv && out && kv_len, "attn_causal_gqa: null pointer");
+  TCAVT_CHECK_ARG(is16(dtype16), "attn_causal_gqa: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(B > 0 && L > 0 && L <= 544, "attn_causal_gqa: L=%d must be in [1, 544]", L);
   TCAVT_CHECK_ARG(nkv > 0 && nq % nkv == 0 && nq / nkv <= 8, "attn_causal_gqa: nq/nkv must be an integer <= 8");
   TCAVT_CHECK_ARG(aligned16(qkv) && aligned16(out), "attn_causal_gqa: unaligned pointer");
@@ -403,25 +424,30 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
   const int lds = Lp * 128 + 64 * (Lp + 4) * 2;
   const int group = nq / nkv;
   const bool small = 2 * group * 64 <= 512;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[small]) {
-    const void* fn = small ? reinterpret_cast<const void*>(attn_causal_gqa_kernel<512>)
-                           : reinterpret_cast<const void*>(attn_causal_gqa_kernel<1024>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  const bool f16 = dtype16 == TCAVT_F16;
+  const void* fns[4] = {reinterpret_cast<const void*>(attn_causal_gqa_kernel<1024, false>),
+                        reinterpret_cast<const void*>(attn_causal_gqa_kernel<512, false>),
+                        reinterpret_cast<const void*>(attn_causal_gqa_kernel<1024, true>),
+                        reinterpret_cast<const void*>(attn_causal_gqa_kernel<512, true>)};
+  const int which = (f16 ? 2 : 0) + (small ? 1 : 0);
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[which]) {
+    hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     if (e != hipSuccess) {
       set_error("attn_causal_gqa: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return TCAVT_ERR_HIP;
     }
-    attr_set[small] = true;
+    attr_set[which] = true;
   }
-  if (small)
-    hipLaunchKernelGGL(attn_causal_gqa_kernel<512>, dim3(B * nkv), dim3(2 * group * 64), lds,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
-                       static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
-  else
-    hipLaunchKernelGGL(attn_causal_gqa_kernel<1024>, dim3(B * nkv), dim3(2 * group * 64), lds,
-                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
-                       static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f);
+#define TCAVT_ATTN(MAXT, F)                                                                                       \
+  hipLaunchKernelGGL((attn_causal_gqa_kernel<MAXT, F>), dim3(B * nkv), dim3(2 * group * 64), lds,                  \
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), \
+                     kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f)
+  if (which == 0) TCAVT_ATTN(1024, false);
+  else if (which == 1) TCAVT_ATTN(512, false);
+  else if (which == 2) TCAVT_ATTN(1024, true);
+  else TCAVT_ATTN(512, true);
+#undef TCAVT_ATTN
   TCAVT_CHECK_LAUNCH("attn_causal_gqa");
   return TCAVT_OK;
 }
@@ -439,38 +465,30 @@ extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk,
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(B * nh), block(256);
   const long lds_all = ((long)(Lq + 2 * Lk) * (dh + 1) + (long)Lq * Lk) * 4;
-  if (lds_all <= 60 * 1024) {  // whole problem in LDS
-#define TCAVT_MHA_LDS(TI, TO)                                                                                   \
-  hipLaunchKernelGGL((mha_lds_kernel<TI, TO>), grid, block, lds_all, s, (const TI*)q, ldq, (const TI*)k, ldk, \
-                     (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop)
-    if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(float, float);
-    else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16) TCAVT_MHA_LDS(float, bf16_t);
-    else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32) TCAVT_MHA_LDS(bf16_t, float);
-    else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_BF16) TCAVT_MHA_LDS(bf16_t, bf16_t);
-    else {
-      set_error("mha: bad dtype %d/%d", in_dtype, out_dtype);
-      return TCAVT_ERR_ARG;
-    }
-#undef TCAVT_MHA_LDS
-    TCAVT_CHECK_LAUNCH("mha(lds)");
-    return TCAVT_OK;
-  }
-  if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_F32)
-    hipLaunchKernelGGL((mha_small_kernel<float, float>), grid, block, lds, s, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
-  else if (in_dtype == TCAVT_F32 && out_dtype == TCAVT_BF16)
-    hipLaunchKernelGGL((mha_small_kernel<float, bf16_t>), grid, block, lds, s, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
-  else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_F32)
-    hipLaunchKernelGGL((mha_small_kernel<bf16_t, float>), grid, block, lds, s, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (float*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
-  else if (in_dtype == TCAVT_BF16 && out_dtype == TCAVT_BF16)
-    hipLaunchKernelGGL((mha_small_kernel<bf16_t, bf16_t>), grid, block, lds, s, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);
-  else {
-    set_error("mha: bad dtype %d/%d", in_dtype, out_dtype);
-    return TCAVT_ERR_ARG;
-  }
+  const bool whole = lds_all <= 60 * 1024;  // whole problem in LDS
+  const long lds_use = whole ? lds_all : lds;
+#define TCAVT_MHA(TI, TO)                                                                                          \
+  do {                                                                                                             \
+    if (whole)                                                                                                     \
+      hipLaunchKernelGGL((mha_lds_kernel<TI, TO>), grid, block, lds_use, s, (const TI*)q, ldq, (const TI*)k, ldk, \
+                         (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);                  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((mha_small_kernel<TI, TO>), grid, block, lds_use, s, (const TI*)q, ldq, (const TI*)k, ldk, \
+                         (const TI*)v, ldv, (TO*)out, ldo, key_len, Lq, Lk, nh, dh, scale, drop);                  \
+  } while (0)
+#define TCAVT_MHA_IN(TI)                                  \
+  do {                                                    \
+    if (out_dtype == TCAVT_F32) TCAVT_MHA(TI, float);     \
+    else if (out_dtype == TCAVT_BF16) TCAVT_MHA(TI, b16); \
+    else TCAVT_MHA(TI, h16);                              \
+  } while (0)
+  TCAVT_CHECK_ARG((in_dtype == TCAVT_F32 || is16(in_dtype)) && (out_dtype == TCAVT_F32 || is16(out_dtype)),
+                  "mha: bad dtype %d/%d", in_dtype, out_dtype);
+  if (in_dtype == TCAVT_F32) TCAVT_MHA_IN(float);
+  else if (in_dtype == TCAVT_BF16) TCAVT_MHA_IN(b16);
+  else TCAVT_MHA_IN(h16);
+#undef TCAVT_MHA_IN
+#undef TCAVT_MHA
   TCAVT_CHECK_LAUNCH("mha");
   return TCAVT_OK;
 }

@@ -16,6 +16,9 @@ namespace tcavt {
 // out[c][r] = in[r][c] for 16-bit elements, batched, zero-filling r in [rows, rows_pad).
 // 64x64 tiles through LDS (+1 pad), 256 threads.
 // ---------------------------------------------------------------------------
+// F2B: the source is fp16 (a forward activation), the destination bf16 (operand of a gradient-side contraction, whose
+// other operand is a bf16 gradient): converted on the way (round-to-nearest-even of the fp16 value).
+template <bool F2B>
 __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restrict__ in, long ld_in,
                                                           bf16_t* __restrict__ out, long ld_out, int rows,
                                                           int cols, int rows_pad, long s_in, long s_out) {
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const bf16_t* __restri
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows_pad) out[(long)c * ld_out + r] = tile[tx][i];
+    if (c < cols && r < rows_pad) out[(long)c * ld_out + r] = F2B ? f32_to_bf16(f16_to_f32(tile[tx][i])) : tile[tx][i];
   }
 }
 
@@ -594,13 +597,18 @@ using namespace tcavt;
 #define S_(x) static_cast<hipStream_t>(x)
 
 extern "C" int tcavt_transpose16(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols,
-                                 int rows_pad, int batch, int64_t s_in, int64_t s_out, tcavt_stream_t stream) {
+                                 int rows_pad, int batch, int64_t s_in, int64_t s_out, int f16_to_bf16,
+                                 tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(in && out && rows > 0 && cols > 0 && rows_pad >= rows && batch >= 1 && ld_in >= cols &&
                       ld_out >= rows_pad && batch <= 65535,
                   "transpose16: bad args");
   dim3 grid((cols + 63) / 64, (rows_pad + 63) / 64, batch);
-  hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, S_(stream), static_cast<const bf16_t*>(in), (long)ld_in,
-                     static_cast<bf16_t*>(out), (long)ld_out, rows, cols, rows_pad, (long)s_in, (long)s_out);
+  if (f16_to_bf16)
+    hipLaunchKernelGGL(transpose16_kernel<true>, grid, dim3(256), 0, S_(stream), static_cast<const bf16_t*>(in), (long)ld_in,
+                       static_cast<bf16_t*>(out), (long)ld_out, rows, cols, rows_pad, (long)s_in, (long)s_out);
+  else
+    hipLaunchKernelGGL(transpose16_kernel<false>, grid, dim3(256), 0, S_(stream), static_cast<const bf16_t*>(in), (long)ld_in,
+                       static_cast<bf16_t*>(out), (long)ld_out, rows, cols, rows_pad, (long)s_in, (long)s_out);
   TCAVT_CHECK_LAUNCH("transpose16");
   return TCAVT_OK;
 }

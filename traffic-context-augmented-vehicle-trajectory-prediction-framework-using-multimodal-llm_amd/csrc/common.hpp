@@ -49,6 +49,43 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
          (static_cast<unsigned int>(f32_to_bf16(hi)) << 16);
 }
 
+// ---- fp16 storage (the default 16-bit storage type of the forward path; bf16 stays for gradient-side tensors) ----------
+// IEEE half, round-to-nearest-even; a value beyond +-65504 becomes inf and surfaces as a non-finite loss (it is outside
+// the storage contract, DESIGN.md "Precision contract") rather than being clamped silently.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ bf16_t f32_to_f16(float f) {
+  return __builtin_bit_cast(unsigned short, static_cast<_Float16>(f));
+}
+__device__ __forceinline__ float f16_to_f32(bf16_t v) {
+  return static_cast<float>(__builtin_bit_cast(_Float16, v));
+}
+__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
+  return static_cast<unsigned int>(f32_to_f16(lo)) | (static_cast<unsigned int>(f32_to_f16(hi)) << 16);
+}
+// 16-bit storage type chosen at compile time: F16 = IEEE half, otherwise bf16 (raw storage is `bf16_t` = uint16 either way)
+template <bool F16>
+__device__ __forceinline__ unsigned int pack16x2(float lo, float hi) {
+  if constexpr (F16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ bf16_t to16(float f) {
+  if constexpr (F16) return f32_to_f16(f);
+  else return f32_to_bf16(f);
+}
+template <bool F16>
+__device__ __forceinline__ float from16(bf16_t v) {
+  if constexpr (F16) return f16_to_f32(v);
+  else return bf16_to_f32(v);
+}
+// low / high half of a packed pair
+template <bool F16>
+__device__ __forceinline__ float from16_lo(unsigned int w) { return from16<F16>(static_cast<bf16_t>(w & 0xffffu)); }
+template <bool F16>
+__device__ __forceinline__ float from16_hi(unsigned int w) { return from16<F16>(static_cast<bf16_t>(w >> 16)); }
+
+static inline bool is16(int dtype) { return dtype == TCAVT_BF16 || dtype == TCAVT_F16; }
+
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

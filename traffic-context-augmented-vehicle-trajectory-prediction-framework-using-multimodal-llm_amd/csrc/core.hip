@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // NV > 0: H == NV * 256 exactly, the row lives in NV float4 per lane (no bounds logic, one HBM pass).
 // NV == 0: any H % 4 == 0; two passes over the row (the second one hits L2).
-template <int NV>
+template <int NV, bool F16>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ gamma, float eps,
                                                       bf16_t* __restrict__ out_bf16,
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     dropout_quad(drop, ((unsigned long long)row * (unsigned long long)H + 4ull * idx) >> 2, sc);
     float z[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) z[e] = bf16_to_f32(f32_to_bf16(y[e])) * sc[e];
-    u32x2 o = {pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3])};
+    for (int e = 0; e < 4; ++e) z[e] = from16<F16>(to16<F16>(y[e])) * sc[e];
+    u32x2 o = {pack16x2<F16>(z[0], z[1]), pack16x2<F16>(z[2], z[3])};
     *reinterpret_cast<u32x2*>(out_drop + (long)row * H + idx * 4) = o;
   };
   const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * H);
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = v[i][e] * rs * g[e];
       if (out_bf16) {
-        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        u32x2 o = {pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
       }
       if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = t[e] * rs * g[e];
       if (out_bf16) {
-        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        u32x2 o = {pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * H + idx * 4) = o;
       }
       if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * H + idx * 4) = y;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 // LayerNorm with optional residual add (torch.nn.LayerNorm semantics: biased
 // variance, eps inside the sqrt).  One wave per row.
 // ---------------------------------------------------------------------------
-template <int NV>
+template <int NV, bool F16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ res,
                                                         const float* __restrict__ gamma,
@@ -150,13 +150,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rs * g[e] + b[e];
       if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + (long)row * D + idx * 4) = y;
       if (out_bf16) {
-        u32x2 o = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+        u32x2 o = {pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
         *reinterpret_cast<u32x2*>(out_bf16 + (long)row * D + idx * 4) = o;
       }
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x,
                                                    bf16_t* __restrict__ out, long n) {
   const long nvec = n >> 3;
@@ -164,20 +165,21 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x,
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
     const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i];
     const f32x4 b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
-    u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]),
-               pack_bf16x2(b[2], b[3])};
+    u32x4 o = {pack16x2<F16>(a[0], a[1]), pack16x2<F16>(a[2], a[3]), pack16x2<F16>(b[0], b[1]),
+               pack16x2<F16>(b[2], b[3])};
     reinterpret_cast<u32x4*>(out)[i] = o;
   }
   // tail (n % 8 elements)
   const long tail0 = nvec << 3;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < n - tail0) out[tail0 + gid] = f32_to_bf16(x[tail0 + gid]);
+  if (gid < n - tail0) out[tail0 + gid] = to16<F16>(x[tail0 + gid]);
 }
 
 // ---------------------------------------------------------------------------
 // Fused embedding build (scripts/train.py:521-528): one wave per output row,
 // 8 elements per lane per step (16-byte bf16 table reads, 2 x float4 writes).
 // ---------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restrict__ table,
                                                          const int64_t* __restrict__ ids,
                                                          const float* __restrict__ img,
@@ -210,14 +212,14 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
       const f32x4 m0 = *reinterpret_cast<const f32x4*>(txt_mod + c);
       const f32x4 m1 = *reinterpret_cast<const f32x4*>(txt_mod + c + 4);
       f32x4 o0, o1;
-      o0[0] = __uint_as_float(t[0] << 16) + m0[0];
-      o0[1] = __uint_as_float(t[0] & 0xffff0000u) + m0[1];
-      o0[2] = __uint_as_float(t[1] << 16) + m0[2];
-      o0[3] = __uint_as_float(t[1] & 0xffff0000u) + m0[3];
-      o1[0] = __uint_as_float(t[2] << 16) + m1[0];
-      o1[1] = __uint_as_float(t[2] & 0xffff0000u) + m1[1];
-      o1[2] = __uint_as_float(t[3] << 16) + m1[2];
-      o1[3] = __uint_as_float(t[3] & 0xffff0000u) + m1[3];
+      o0[0] = from16_lo<F16>(t[0]) + m0[0];
+      o0[1] = from16_hi<F16>(t[0]) + m0[1];
+      o0[2] = from16_lo<F16>(t[1]) + m0[2];
+      o0[3] = from16_hi<F16>(t[1]) + m0[3];
+      o1[0] = from16_lo<F16>(t[2]) + m1[0];
+      o1[1] = from16_hi<F16>(t[2]) + m1[1];
+      o1[2] = from16_lo<F16>(t[3]) + m1[2];
+      o1[3] = from16_hi<F16>(t[3]) + m1[3];
       *reinterpret_cast<f32x4*>(out + c) = o0;
       *reinterpret_cast<f32x4*>(out + c + 4) = o1;
     }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 
 // Elementwise dropout, one Philox call per quad of elements.
-template <typename T>
+template <typename T, bool F16 = false>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long n, DropoutP drop) {
   const long nq = (n + 3) >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     for (int e = 0; e < 4; ++e) {
       const long i = 4 * q + e;
       if (i < n) {
-        if constexpr (sizeof(T) == 2) out[i] = f32_to_bf16(bf16_to_f32(x[i]) * sc[e]);
+        if constexpr (sizeof(T) == 2) out[i] = to16<F16>(from16<F16>(x[i]) * sc[e]);
         else out[i] = x[i] * sc[e];
       }
     }
@@ -305,15 +307,18 @@ extern "C" int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t 
 extern "C" int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
                              tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
-  TCAVT_CHECK_ARG(dtype == TCAVT_F32 || dtype == TCAVT_BF16, "dropout: dtype must be f32 or bf16");
+  TCAVT_CHECK_ARG(dtype == TCAVT_F32 || is16(dtype), "dropout: dtype must be f32, bf16 or fp16");
   long blocks = ((n + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   const DropoutP d = make_dropout(p, seed, site);
   if (dtype == TCAVT_F32)
     hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float*>(x), static_cast<float*>(out), (long)n, d);
+  else if (dtype == TCAVT_F16)
+    hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d);
   else
-    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d);
   TCAVT_CHECK_LAUNCH("dropout");
   return TCAVT_OK;
@@ -355,8 +360,9 @@ extern "C" int tcavt_init(int device, int* num_cus) {
 
 extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void* out_bf16,
                              float* out_f32, int M, int H, void* out_drop_bf16, float dropout_p,
-                             uint64_t dropout_seed, uint32_t dropout_site, tcavt_stream_t stream) {
+                             uint64_t dropout_seed, uint32_t dropout_site, int dtype16, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && gamma && (out_bf16 || out_f32), "rmsnorm: null pointer");
+  TCAVT_CHECK_ARG(is16(dtype16), "rmsnorm: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f && (!out_drop_bf16 || dropout_p > 0.f),
                   "rmsnorm: out_drop needs 0 < dropout_p < 1");
   bf16_t* od = static_cast<bf16_t*>(out_drop_bf16);
@@ -366,7 +372,11 @@ extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((M + 3) / 4), block(256);
   bf16_t* ob = static_cast<bf16_t*>(out_bf16);
-#define TCAVT_RMS(NV) hipLaunchKernelGGL(rmsnorm_kernel<NV>, grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H, od, drop)
+#define TCAVT_RMS(NV)                                                                                                  \
+  do {                                                                                                                 \
+    if (dtype16 == TCAVT_F16) hipLaunchKernelGGL((rmsnorm_kernel<NV, true>), grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H, od, drop); \
+    else hipLaunchKernelGGL((rmsnorm_kernel<NV, false>), grid, block, 0, s, x, gamma, eps, ob, out_f32, M, H, od, drop); \
+  } while (0)
   switch (H % 256 == 0 ? H / 256 : 0) {
     case 1: TCAVT_RMS(1); break;
     case 2: TCAVT_RMS(2); break;
@@ -383,41 +393,58 @@ extern "C" int tcavt_rmsnorm(const float* x, const float* gamma, float eps, void
 
 extern "C" int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
                                const float* beta, float eps, float* out_f32, void* out_bf16, int M,
-                               int D, tcavt_stream_t stream) {
+                               int D, int dtype16, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && gamma && beta && (out_f32 || out_bf16), "layernorm: null pointer");
+  TCAVT_CHECK_ARG(is16(dtype16), "layernorm: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, "layernorm: D=%d must be a multiple of 4 and <= 4096", D);
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((M + 3) / 4), block(256);
   bf16_t* ob = static_cast<bf16_t*>(out_bf16);
   const int nvec = D / 4;
-  if (nvec <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
-  else if (nvec <= 256) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
-  else hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D);
+#define TCAVT_LN(NV)                                                                                                    \
+  do {                                                                                                                  \
+    if (dtype16 == TCAVT_F16) hipLaunchKernelGGL((layernorm_kernel<NV, true>), grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D); \
+    else hipLaunchKernelGGL((layernorm_kernel<NV, false>), grid, block, 0, s, x, residual, gamma, beta, eps, out_f32, ob, M, D); \
+  } while (0)
+  if (nvec <= 64) TCAVT_LN(1);
+  else if (nvec <= 256) TCAVT_LN(4);
+  else TCAVT_LN(16);
+#undef TCAVT_LN
   TCAVT_CHECK_LAUNCH("layernorm");
   return TCAVT_OK;
 }
 
-extern "C" int tcavt_cast_f32_bf16(const float* x, void* out_bf16, int64_t n, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(x && out_bf16 && n > 0, "cast: null pointer or n <= 0");
+extern "C" int tcavt_cast_f32_16(const float* x, void* out_bf16, int64_t n, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && out_bf16 && n > 0 && is16(dtype16), "cast: null pointer, n <= 0 or bad dtype16");
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(out_bf16), "cast: unaligned pointer");
   long blocks = (n / 8 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     static_cast<bf16_t*>(out_bf16), (long)n);
-  TCAVT_CHECK_LAUNCH("cast_f32_bf16");
+  if (dtype16 == TCAVT_F16)
+    hipLaunchKernelGGL(cast_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<bf16_t*>(out_bf16), (long)n);
+  else
+    hipLaunchKernelGGL(cast_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<bf16_t*>(out_bf16), (long)n);
+  TCAVT_CHECK_LAUNCH("cast_f32_16");
   return TCAVT_OK;
 }
 
 extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                                 const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
-                                int Lt, int H, int V, int* bad_id_flag, tcavt_stream_t stream) {
+                                int Lt, int H, int V, int* bad_id_flag, int table_dtype, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && h && bad_id_flag, "embed_fuse: null pointer");
+  TCAVT_CHECK_ARG(is16(table_dtype), "embed_fuse: table_dtype must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(B > 0 && Nq >= 0 && Lt >= 0 && Nq + Lt > 0 && H % 8 == 0 && V > 0, "embed_fuse: bad shape");
   const long rows = (long)B * (Nq + Lt);
-  hipLaunchKernelGGL(embed_fuse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                     vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
+  if (table_dtype == TCAVT_F16)
+    hipLaunchKernelGGL(embed_fuse_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
+  else
+    hipLaunchKernelGGL(embed_fuse_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
   TCAVT_CHECK_LAUNCH("embed_fuse");
   return TCAVT_OK;
 }

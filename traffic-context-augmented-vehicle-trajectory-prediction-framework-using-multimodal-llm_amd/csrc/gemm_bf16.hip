@@ -65,14 +65,6 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-
-__device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
-  const unsigned short a = __builtin_bit_cast(unsigned short, static_cast<_Float16>(lo));
-  const unsigned short b = __builtin_bit_cast(unsigned short, static_cast<_Float16>(hi));
-  return static_cast<unsigned int>(a) | (static_cast<unsigned int>(b) << 16);
-}
-
 __device__ __forceinline__ void store_quad(const GemmP& p, int m, int n, f32x4 v) {
   if (p.out_kind == TCAVT_BF16) {
     u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -97,8 +89,10 @@ __device__ __forceinline__ float silu_mul(float g, float u) {
 
 // WHOLE_ONLY: the caller guarantees whole tiles (the 4-wave kernel); the bounds-checked paths are compiled out where
 // a fast path covers the form.
-template <int TM, int TN, int EPI, bool WHOLE_ONLY = false>
+// F16: the operands' 16-bit type; the fast paths below write 16-bit outputs of that same type (OUT16).
+template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+  constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
   // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
   const int nq = 4 * (lane >> 4);
   const int ml = lane & 15;
@@ -118,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       }
       return;
     }
-    if (whole && p.acc_scale == 1.f && p.out_kind == TCAVT_BF16 && p.flags == 0) {
+    if (whole && p.acc_scale == 1.f && p.out_kind == OUT16 && p.flags == 0) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const long m = m_base + j * 16 + ml;
@@ -126,14 +120,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const f32x4 v = acc[i][j];
-          *reinterpret_cast<u32x2*>(crow + i * 16) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(crow + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
         }
       }
       return;
     }
   }
   if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE) {
-    if (whole && p.out_kind == TCAVT_BF16) {
+    if (whole && p.out_kind == OUT16) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const long m = m_base + j * 16 + ml;
@@ -143,19 +137,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           const f32x4 g = acc[i][j], u = acc[i + 1][j];
           if constexpr (EPI == EPI_SILU_SAVE) {
             bf16_t* arow = p.aux + m * p.ldaux + n_base + i * 16 + nq;
-            *reinterpret_cast<u32x2*>(arow) = u32x2{pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
-            *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+            *reinterpret_cast<u32x2*>(arow) = u32x2{pack16x2<F16>(g[0], g[1]), pack16x2<F16>(g[2], g[3])};
+            *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack16x2<F16>(u[0], u[1]), pack16x2<F16>(u[2], u[3])};
           }
           *reinterpret_cast<u32x2*>(crow + (i >> 1) * 16) =
-              u32x2{pack_bf16x2(silu_mul(g[0], u[0]), silu_mul(g[1], u[1])),
-                    pack_bf16x2(silu_mul(g[2], u[2]), silu_mul(g[3], u[3]))};
+              u32x2{pack16x2<F16>(silu_mul(g[0], u[0]), silu_mul(g[1], u[1])),
+                    pack16x2<F16>(silu_mul(g[2], u[2]), silu_mul(g[3], u[3]))};
         }
       }
       return;
     }
   }
   if constexpr (EPI == EPI_ROPE) {
-    if (whole && p.out_kind == TCAVT_BF16) {
+    if (whole && p.out_kind == OUT16) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int m = m_base + j * 16 + ml;
@@ -176,14 +170,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
               const f32x4 s = *reinterpret_cast<const f32x4*>(srp + i * 16);
               const f32x4 l2 = lo * c - hi * s;
               const f32x4 h2 = hi * c + lo * s;
-              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(l2[0], l2[1]), pack_bf16x2(l2[2], l2[3])};
-              *reinterpret_cast<u32x2*>(crow + hh * 64 + 32 + i * 16) = u32x2{pack_bf16x2(h2[0], h2[1]), pack_bf16x2(h2[2], h2[3])};
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack16x2<F16>(l2[0], l2[1]), pack16x2<F16>(l2[2], l2[3])};
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + 32 + i * 16) = u32x2{pack16x2<F16>(h2[0], h2[1]), pack16x2<F16>(h2[2], h2[3])};
             }
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const f32x4 v = acc[hh * 4 + i][j];
-              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
             }
           }
         }
@@ -235,8 +229,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         const f32x4 g = acc[i][j], u = acc[i + 1][j];
         if constexpr (EPI == EPI_SILU_SAVE) {
           bf16_t* arow = p.aux + (long)m * p.ldaux + n_base + i * 16 + nq;
-          *reinterpret_cast<u32x2*>(arow) = u32x2{pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3])};
-          *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3])};
+          *reinterpret_cast<u32x2*>(arow) = u32x2{pack16x2<F16>(g[0], g[1]), pack16x2<F16>(g[2], g[3])};
+          *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack16x2<F16>(u[0], u[1]), pack16x2<F16>(u[2], u[3])};
         }
         f32x4 v;
 #pragma unroll
@@ -477,7 +471,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
       if (t + NS - 1 < nt) stage((t + NS - 1) % NS, t + NS - 1);
       compute(t % NS);
     }
-    gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+    gemm_epilogue<TM, TN, EPI, false, F16>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
     return;
   }
   if (p.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
@@ -508,7 +502,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   }
   compute(cur);
 
-  gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+  gemm_epilogue<TM, TN, EPI, false, F16>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 // (gx, gy) minimising gy * |A| + 3 * gx * |W| among the partitions the tile grid divides evenly into
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
         else
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
   }
-  gemm_epilogue<TM, TN, EPI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
+  gemm_epilogue<TM, TN, EPI, false, F16>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 #endif  // TCAVT_EXPERIMENTS
@@ -707,8 +701,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmP p) {
 // ===========================================================================
 // MFMA with the accumulator pinned to AGPRs and tied in place.  Written as inline asm because the compiler's
 // VGPR/AGPR rewriting turned the 256-register accumulator of the 4-wave kernel into ~350 v_accvgpr copies per K-tile.
+template <bool F16>
 __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
 // DBG (timing experiments only, results are wrong): 1 = no DMA in the loop, 2 = no barrier, 4 = no fragment loads
@@ -716,7 +712,7 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x
 // instead of global_load ... lds (64-bit per-lane address, two VALU ops per piece).
 // BN = 256: 2 x 2 waves of 128 x 128.  BN = 192: 4 x 1 waves of 64 x 192 (4 x 12 MFMA tiles, 192 accumulator
 // registers) for N = 3072 (fused q|k|v): 512 tiles = two full waves of 256 CUs instead of 384 = one and a half.
-template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256>
+template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   constexpr int BM = 256, NW = 4;
   constexpr int WN_ = BN == 256 ? 2 : 1, WM_ = NW / WN_;
@@ -893,7 +889,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = 0; i < TN; ++i) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        mfma_agpr(acc[i][j], w0[i], x0[j]);
+        mfma_agpr<F16>(acc[i][j], w0[i], x0[j]);
         const int idx = i * TM + j;
         if (frd && !S1 && idx < 32 && (idx & 1) == 0) {  // 16 fragment loads, one per 2 MFMAs
           const int f = idx >> 1;
@@ -930,7 +926,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = 0; i < TN - B2R; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        mfma_agpr(acc[i][j], w1[i], x1[j]);
+        mfma_agpr<F16>(acc[i][j], w1[i], x1[j]);
         const int idx = i * TM + j;
         if constexpr (DEEP) {
           if (dma && (idx & 3) == 3 && 6 + idx / 4 < NP) piece(cur, sn2, 6 + idx / 4);  // pieces 6..15 of tile t+2
@@ -961,7 +957,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = TN - B2R; i < TN; ++i) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        mfma_agpr(acc[i][j], w1[i], x1[j]);
+        mfma_agpr<F16>(acc[i][j], w1[i], x1[j]);
         const int idx = (i - (TN - B2R)) * TM + j;  // 0..NB2-1
         if (frd && more && !S2 && TM == TN && idx < TM) {  // the 16 fragment loads go first, two per MFMA
           x0[idx] = ldx(nbase, off0, idx);
@@ -997,7 +993,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-    gemm_epilogue<TM, TN, EPI, true>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
+    gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
     if (!PERS_OK || !has_next) break;  // (uniform) non-persistent launches leave here
     // ---- next output tile: F0 already holds its first fragments, its second K-tile is in flight
     vb += gridDim.x;
@@ -1020,7 +1016,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
 #endif
 }
 
-template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256>
+template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256, bool F16 = false>
 static int launch_w4(const GemmP& p0, hipStream_t stream) {
   if (BUF && ((long)256 * p0.lda * 2 + (long)p0.K * 2 >= (1L << 31) || (long)256 * p0.ldw * 2 + (long)p0.K * 2 >= (1L << 31))) {
     set_error("gemm_bf16(w4, buffer loads): a 256-row operand panel must span < 2 GiB");
@@ -1031,7 +1027,7 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   p.tiles_n = p.N / BN;
   p.xcd_gx = choose_xcd_partition(p);
   constexpr int lds = 2 * (256 + BN) * 128;
-  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF, BN>;
+  auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF, BN, F16>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1128,24 +1124,22 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
     case 250: return launch_ring<EPI, F16>(q, batch, stream);
 #endif
     case 271:  // 256 x 192 tiles (N % 192 == 0)
-      if constexpr (!F16) {
-        if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 192 == 0 &&
-            (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16))
-          return launch_w4<EPI, 4, 0, false, 192>(q, stream);
-      }
-      set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs bf16 operands, M %% 256 == 0, N %% 192 == 0, no batch");
+      if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 192 == 0 &&
+          (EPI != EPI_ROPE || q.out_kind == (F16 ? TCAVT_F16 : TCAVT_BF16)))
+        return launch_w4<EPI, 4, 0, false, 192, F16>(q, stream);
+      set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs M %% 256 == 0, N %% 192 == 0, no batch");
       return TCAVT_ERR_ARG;
     case 257: case 272:
 #ifdef TCAVT_EXPERIMENTS
     case 258: case 259: case 268: case 269: case 270:
 #endif
-      if constexpr (!F16) {
-        if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
-            (EPI != EPI_ROPE || q.out_kind == TCAVT_BF16)) {
-          if (tile == 272) {
-            if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 64>(q, stream);
-          }
+      if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
+          (EPI != EPI_ROPE || q.out_kind == (F16 ? TCAVT_F16 : TCAVT_BF16))) {
+        if (tile == 272) {
+          if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 64, false, 256, F16>(q, stream);
+        }
 #ifdef TCAVT_EXPERIMENTS
+        if constexpr (!F16) {
           if (tile == 270) {
             if constexpr (EPI != EPI_ROPE) return launch_w4<EPI, 2, 0, true>(q, stream);
           }
@@ -1153,11 +1147,11 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
           if (tile == 269) return launch_w4<EPI, 2, 32>(q, stream);
           if (tile == 258) return launch_w4<EPI, 3>(q, stream);
           if (tile == 259) return launch_w4<EPI, 4>(q, stream);
-#endif
-          return launch_w4<EPI, 2>(q, stream);
         }
+#endif
+        return launch_w4<EPI, 2, 0, false, 256, F16>(q, stream);
       }
-      set_error("gemm_bf16: tile %d (4-wave kernel) needs bf16 operands, whole 256x256 tiles, one K source, no batch", tile);
+      set_error("gemm_bf16: tile %d (4-wave kernel) needs whole 256x256 tiles, one K source, no batch", tile);
       return TCAVT_ERR_ARG;
 #ifdef TCAVT_EXPERIMENTS
     case 261: case 262: case 263: case 264: case 265: case 267: {  // timing experiments (wrong results)
@@ -1210,9 +1204,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   TCAVT_CHECK_ARG(a->in_dtype == 0 || a->in_dtype == TCAVT_BF16 || a->in_dtype == TCAVT_F16, "gemm_bf16: bad in_dtype");
   const bool f16 = a->in_dtype == TCAVT_F16;
   const int batch = a->batch > 1 ? a->batch : 1;
-  if (f16 || batch > 1)
+  if (batch > 1)
     TCAVT_CHECK_ARG(!(a->epilogue & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)),
-                    "gemm_bf16: fp16 operands / batching are supported by the generic epilogue only");
+                    "gemm_bf16: batching is supported by the generic epilogue only");
   if (batch > 1) {
     TCAVT_CHECK_ARG(a->batch_inner >= 1 && batch % a->batch_inner == 0, "gemm_bf16: batch must be a multiple of batch_inner");
     TCAVT_CHECK_ARG(a->sAo % 8 == 0 && a->sAi % 8 == 0 && a->sWo % 8 == 0 && a->sWi % 8 == 0 && a->sCo % 4 == 0 &&
@@ -1293,8 +1287,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 0;  // 0: dispatch_tile picks 128 / 64
     // whole 256x256 tiles, one K source, bf16, no RoPE: the 4-wave kernel (gate|up 406 vs 434 us, down 204 vs 218,
     // o 57.5 vs 60 on the 8-wave kernel)
-    if (tile == 256 && !f16 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 &&
-        ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == TCAVT_BF16 : K2 == 0)) {
+    if (tile == 256 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 &&
+        ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) : K2 == 0)) {
       tile = 257;
       // 256 x 192 tiles where they fill whole waves of 256 CUs and 256 x 256 tiles do not (q|k|v: N = 3072)
       if (a->N % 192 == 0) {
@@ -1314,14 +1308,14 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                       "gemm_bf16: silu_preact needs 16-byte alignment and ld_preact >= N, %% 4 == 0");
       p.aux = static_cast<bf16_t*>(a->silu_preact);
       p.ldaux = a->ld_preact;
-      return dispatch_tile<EPI_SILU_SAVE, false>(p, tile, 1, s);
+      return f16 ? dispatch_tile<EPI_SILU_SAVE, true>(p, tile, 1, s) : dispatch_tile<EPI_SILU_SAVE, false>(p, tile, 1, s);
     }
-    return dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
+    return f16 ? dispatch_tile<EPI_SILU, true>(p, tile, 1, s) : dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
   }
-  if (epi & TCAVT_EPI_ROPE) return dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
+  if (epi & TCAVT_EPI_ROPE) return f16 ? dispatch_tile<EPI_ROPE, true>(p, tile, 1, s) : dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
   if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
-    TCAVT_CHECK_ARG(!f16, "gemm_bf16: dropout needs bf16 operands");
-    return launch_small<EPI_DROP, false>(p, a->tile == 64 || a->tile == 128 ? a->tile : 0, 1, s);
+    const int t = a->tile == 64 || a->tile == 128 ? a->tile : 0;
+    return f16 ? launch_small<EPI_DROP, true>(p, t, 1, s) : launch_small<EPI_DROP, false>(p, t, 1, s);
   }
   if (f16) return dispatch_tile<EPI_GENERIC, true>(p, tile, batch, s);
   return dispatch_tile<EPI_GENERIC, false>(p, tile, batch, s);

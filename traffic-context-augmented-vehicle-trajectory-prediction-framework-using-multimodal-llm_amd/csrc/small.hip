@@ -183,7 +183,7 @@ __global__ void ltsf_decode_kernel(const float* __restrict__ e, const float* __r
 }
 
 __global__ void transpose_ct_kernel(const float* __restrict__ in, float* __restrict__ of,
-                                    bf16_t* __restrict__ ob, int B, int C, int To) {
+                                    bf16_t* __restrict__ ob, int B, int C, int To, int f16) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over [B][To][C]
   if (idx >= (long)B * C * To) return;
   const int c = (int)(idx % C);
@@ -192,7 +192,7 @@ __global__ void transpose_ct_kernel(const float* __restrict__ in, float* __restr
   const long b = bs / To;
   const float v = in[(b * C + c) * To + s];
   if (of) of[idx] = v;
-  if (ob) ob[idx] = f32_to_bf16(v);
+  if (ob) ob[idx] = f16 ? f32_to_f16(v) : f32_to_bf16(v);
 }
 
 // out[b][f][s] = w[f] . fused[b][s] + bias[f] + x[b][f][T-1]   (train.py:804-805,941-943)
@@ -381,11 +381,13 @@ extern "C" int tcavt_ltsf_decode(const float* e_tok, const float* dec_w, const f
 }
 
 extern "C" int tcavt_transpose_ct(const float* in, float* out_f32, void* out_bf16, int B, int C, int To,
-                                  tcavt_stream_t stream) {
+                                  int dtype16, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(in && (out_f32 || out_bf16) && B > 0 && C > 0 && To > 0, "transpose_ct: bad args");
+  TCAVT_CHECK_ARG(is16(dtype16), "transpose_ct: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   const long n = (long)B * C * To;
   hipLaunchKernelGGL(transpose_ct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, out_f32, static_cast<bf16_t*>(out_bf16), B, C, To);
+                     static_cast<hipStream_t>(stream), in, out_f32, static_cast<bf16_t*>(out_bf16), B, C, To,
+                     dtype16 == TCAVT_F16 ? 1 : 0);
   TCAVT_CHECK_LAUNCH("transpose_ct");
   return TCAVT_OK;
 }

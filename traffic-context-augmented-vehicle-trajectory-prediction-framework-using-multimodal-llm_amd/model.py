@@ -98,8 +98,9 @@ class _Workspace:
         return t
 
 
-def _bf16(t):
-    return ops.cast_bf16(t.detach().contiguous())
+def _to16(t, dtype):
+    """fp32 master -> packed 16-bit device copy in the module's storage type (fp16 by default, model.set_storage)."""
+    return ops.cast16(t.detach().contiguous(), dtype=dtype)
 
 
 XATTN_PAD = 64  # key counts of the head cross-attention are padded to a multiple of this
@@ -131,7 +132,14 @@ def _spec(dctx, p):
 
 
 class _Prepared:
-    """Mixin: lazily (re)build packed / bf16 device buffers derived from the parameters."""
+    """Mixin: lazily (re)build packed 16-bit device buffers derived from the parameters.
+
+    `storage` is the 16-bit type of every GEMM operand the module keeps or produces: torch.float16 by default -- 11
+    significant bits keep the whole model within 1e-3 of the fp32 reference (decoded 2.0e-4, ADE 7.7e-5, FDE 4.5e-4 at
+    the full size against 2.6e-3 / 1.3e-3 / 7.4e-3 with bf16: profiles/r02_error_budget_full_size.json) at the same MFMA
+    rate -- or torch.bfloat16 (the LoRA-trainable variant, whose backward kernels read bf16 tapes).  Accumulation,
+    residual streams, norms, softmax and RoPE are fp32 either way."""
+    storage = torch.float16
 
     def _invalidate(self):
         self._prep = None
@@ -148,9 +156,9 @@ class _Prepared:
 # defaults: post-LN, ReLU, eval).  bf16=True: GEMMs in bf16 MFMA (Q-Former);
 # bf16=False: everything fp32 (lane polygon encoder).
 # --------------------------------------------------------------------------------------
-def _prep_mha(m, bf16, split_kv=False):
+def _prep_mha(m, bf16, split_kv=False, dt16=torch.float16):
     e = m.in_proj_weight.shape[1]
-    cv = _bf16 if bf16 else (lambda t: t.detach().contiguous())
+    cv = (lambda t: _to16(t, dt16)) if bf16 else (lambda t: t.detach().contiguous())
     d = SimpleNamespace(e=e, b_in=m.in_proj_bias.detach(), w_out=cv(m.out_proj.weight), b_out=m.out_proj.bias.detach())
     if split_kv:
         d.w_q, d.w_kv = cv(m.in_proj_weight[:e]), cv(m.in_proj_weight[e:])
@@ -160,13 +168,13 @@ def _prep_mha(m, bf16, split_kv=False):
     return d
 
 
-def _prep_layer(layer, bf16, decoder=False):
-    cv = _bf16 if bf16 else (lambda t: t.detach().contiguous())
-    d = SimpleNamespace(sa=_prep_mha(layer.self_attn, bf16), w1=cv(layer.linear1.weight), b1=layer.linear1.bias.detach(),
+def _prep_layer(layer, bf16, decoder=False, dt16=torch.float16):
+    cv = (lambda t: _to16(t, dt16)) if bf16 else (lambda t: t.detach().contiguous())
+    d = SimpleNamespace(sa=_prep_mha(layer.self_attn, bf16, dt16=dt16), w1=cv(layer.linear1.weight), b1=layer.linear1.bias.detach(),
                         w2=cv(layer.linear2.weight), b2=layer.linear2.bias.detach(),
                         n1=layer.norm1, n2=layer.norm2)
     if decoder:
-        d.ca = _prep_mha(layer.multihead_attn, bf16, split_kv=True)
+        d.ca = _prep_mha(layer.multihead_attn, bf16, split_kv=True, dt16=dt16)
         d.n3 = layer.norm3
     return d
 
@@ -174,8 +182,8 @@ def _prep_layer(layer, bf16, decoder=False):
 class _TLayerRunner:
     """Runs post-LN layers on token matrices [M, D] (fp32 master copy x, bf16 shadow xb)."""
 
-    def __init__(self, ws, bf16, nhead, tag, record=None, dctx=None, p_drop=0.0):
-        self.ws, self.bf16, self.nhead, self.tag = ws, bf16, nhead, tag
+    def __init__(self, ws, bf16, nhead, tag, record=None, dctx=None, p_drop=0.0, dt16=torch.float16):
+        self.ws, self.bf16, self.nhead, self.tag, self.dt16 = ws, bf16, nhead, tag, dt16
         self.dctx, self.p_drop = dctx, p_drop  # train-mode dropout of nn.Transformer*Layer (default 0.1)
         # training: `record` (a list) receives one dict of retained activations per encoder layer, and
         # `layer_tag` gives every layer its own buffers instead of recycling them
@@ -199,7 +207,7 @@ class _TLayerRunner:
     def self_attn(self, p, x, xb, B, L, key_len):
         """returns y = x + out_proj(MHA(x)) (fp32 [M, E])"""
         dev, E, M = x.device, p.e, x.shape[0]
-        act_dt = torch.bfloat16 if self.bf16 else torch.float32
+        act_dt = self.dt16 if self.bf16 else torch.float32
         qkv = self._buf("qkv", (M, 3 * E), torch.float32, dev)
         self._gemm(xb if self.bf16 else x, p.w_in, out=qkv, bias=p.b_in, out_dtype=torch.float32)
         att = self._buf("att", (M, E), act_dt, dev)
@@ -213,7 +221,7 @@ class _TLayerRunner:
 
     def cross_attn(self, p, x, xb, mem, memb, B, Lq, Lk):
         dev, E, M = x.device, p.e, x.shape[0]
-        act_dt = torch.bfloat16 if self.bf16 else torch.float32
+        act_dt = self.dt16 if self.bf16 else torch.float32
         q = self._buf("cq", (M, E), torch.float32, dev)
         self._gemm(xb if self.bf16 else x, p.w_q, out=q, bias=p.b_q, out_dtype=torch.float32)
         kv = self._buf("ckv", (mem.shape[0], 2 * E), torch.float32, dev)
@@ -230,14 +238,14 @@ class _TLayerRunner:
     def norm(self, y, n, name):
         dev, (M, E) = y.device, y.shape
         x = self._buf(name, (M, E), torch.float32, dev)
-        xb = self._buf(name + "b", (M, E), torch.bfloat16, dev) if self.bf16 else None
+        xb = self._buf(name + "b", (M, E), self.dt16, dev) if self.bf16 else None
         ops.layernorm(y, n.weight, n.bias, 1e-5, out_f32=x, out_bf16=xb)
         return x, xb
 
     def ffn(self, p, x, xb):
         dev, M = x.device, x.shape[0]
         ff = p.w1.shape[0]
-        act_dt = torch.bfloat16 if self.bf16 else torch.float32
+        act_dt = self.dt16 if self.bf16 else torch.float32
         f = self._buf("ffh", (M, ff), act_dt, dev)
         self._gemm(xb if self.bf16 else x, p.w1, out=f, bias=p.b1, relu=True, out_dtype=act_dt,
                    dropout=self._draw())
@@ -257,8 +265,8 @@ class _TLayerRunner:
             self.record.append(dict(
                 drop=specs,  # [attention weights, after out_proj, after ReLU, after linear2] or Nones
                 x=x, y=y, x1=x1, y2=y2, qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev),
-                att=self._buf("att", (M, E), torch.bfloat16 if self.bf16 else torch.float32, dev),
-                f=self._buf("ffh", (M, p.w1.shape[0]), torch.bfloat16 if self.bf16 else torch.float32, dev)))
+                att=self._buf("att", (M, E), self.dt16 if self.bf16 else torch.float32, dev),
+                f=self._buf("ffh", (M, p.w1.shape[0]), self.dt16 if self.bf16 else torch.float32, dev)))
         return out
 
     def decoder_layer(self, p, x, xb, mem, memb, B, Lq, Lk, slot=0):
@@ -332,26 +340,28 @@ class BlipQFormer(nn.Module, _Prepared):
 
     def _prepare(self):
         return SimpleNamespace(
-            w_vp=_bf16(self.vision_proj.weight), enc=[_prep_layer(l, True) for l in self.encoder.layers],
-            dec=[_prep_layer(l, True, decoder=True) for l in self.decoder.layers], q0={})
+            w_vp=_to16(self.vision_proj.weight, self.storage),
+            enc=[_prep_layer(l, True, dt16=self.storage) for l in self.encoder.layers],
+            dec=[_prep_layer(l, True, decoder=True, dt16=self.storage) for l in self.decoder.layers], q0={})
 
     def forward(self, vision_embs, return_bf16=False):
         B, Tv, Dv = vision_embs.shape
         dev, E, Nq = vision_embs.device, self.hidden_size, self.num_query_tokens
         P = self._prepared()
-        run = _TLayerRunner(self._ws, bf16=True, nhead=self.nhead, tag="qf", dctx=self.dctx, p_drop=self.dropout_p)
-        vb = self._ws.get("qf.vb", (B * Tv, Dv), torch.bfloat16, dev)
-        ops.cast_bf16(vision_embs.contiguous().view(B * Tv, Dv), out=vb)
+        run = _TLayerRunner(self._ws, bf16=True, nhead=self.nhead, tag="qf", dctx=self.dctx, p_drop=self.dropout_p,
+                            dt16=self.storage)
+        vb = self._ws.get("qf.vb", (B * Tv, Dv), self.storage, dev)
+        ops.cast16(vision_embs.contiguous().view(B * Tv, Dv), out=vb)
         x = self._ws.get("qf.x0", (B * Tv, E), torch.float32, dev)
         ops.gemm_bf16(vb, P.w_vp, out=x, bias=self.vision_proj.bias)
-        xb = self._ws.get("qf.x0b", (B * Tv, E), torch.bfloat16, dev)
-        ops.cast_bf16(x, out=xb)
+        xb = self._ws.get("qf.x0b", (B * Tv, E), self.storage, dev)
+        ops.cast16(x, out=xb)
         for i, p in enumerate(P.enc):
             x, xb = run.encoder_layer(p, x, xb, B, Tv, slot=i & 1)
         mem, memb = x, xb
         if B not in P.q0:  # learned queries broadcast over the batch (train.py:412); constant per B
             q = self.query_tokens.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, E).contiguous()
-            P.q0[B] = (q, ops.cast_bf16(q))
+            P.q0[B] = (q, ops.cast16(q, dtype=self.storage))
         q, qb = P.q0[B]
         for i, p in enumerate(P.dec):
             q, qb = run.decoder_layer(p, q, qb, mem, memb, B, Nq, Tv, slot=i & 1)
@@ -453,7 +463,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         ll = self.shape
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         layers = []
-        rnd = lambda t: t.detach().to(torch.bfloat16).to(torch.float32).contiguous()  # bf16-valued fp32 (gamma)
+        rnd = lambda t: t.detach().contiguous()  # RMSNorm gains stay fp32 (rounding them cost 1.1e-3 on decoded, error budget)
+        _bf16 = lambda t: _to16(t, self.storage)
         nL = len(self.llama_model.model.layers)
         a_all = b_all = None
         for li, lyr in enumerate(self.llama_model.model.layers):
@@ -466,8 +477,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 if a_all is None:
                     # all layers' packed adapters in two tensors, LAST layer first (the order of the trainer's flat
                     # parameter vector): refresh_lora() then re-packs every layer with a handful of strided copies
-                    a_all = torch.zeros(nL, 64, H, dtype=torch.bfloat16, device=d.w_qkv.device)
-                    b_all = torch.zeros(nL, (nq + 2 * nkv) * hd, 64, dtype=torch.bfloat16, device=d.w_qkv.device)
+                    a_all = torch.zeros(nL, 64, H, dtype=self.storage, device=d.w_qkv.device)
+                    b_all = torch.zeros(nL, (nq + 2 * nkv) * hd, 64, dtype=self.storage, device=d.w_qkv.device)
                 d.a_cat, d.b_ext = a_all[nL - 1 - li], b_all[nL - 1 - li]
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
                 d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
@@ -545,11 +556,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         nqkv = (nq + 2 * nkv) * hd
         cos, sin = self._rope_tables(L, dev)
-        xn = ws.get("ll.xn", (M, H), torch.bfloat16, dev)
-        qkv = ws.get("ll.qkv", (M, nqkv), torch.bfloat16, dev)
-        att = ws.get("ll.att", (M, nq * hd), torch.bfloat16, dev)
-        act = ws.get("ll.act", (M, ll.inter), torch.bfloat16, dev)
-        t = ws.get("ll.lora_t", (M, 64), torch.bfloat16, dev) if self.use_lora else None
+        xn = ws.get("ll.xn", (M, H), self.storage, dev)
+        qkv = ws.get("ll.qkv", (M, nqkv), self.storage, dev)
+        att = ws.get("ll.att", (M, nq * hd), self.storage, dev)
+        act = ws.get("ll.act", (M, ll.inter), self.storage, dev)
+        t = ws.get("ll.lora_t", (M, 64), self.storage, dev) if self.use_lora else None
         scale = 1.0 / math.sqrt(hd)
         tile = self.gemm_tile
         tm = self.timer
@@ -567,16 +578,16 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 sv = SimpleNamespace(h_in=h, dspec=dspec,
                                      h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
                                      h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
-                                     qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), torch.bfloat16, dev, zero=True),
-                                     gu=ws.get(f"ll.sv.gu{li}", (M, 2 * ll.inter), torch.bfloat16, dev),
-                                     t=ws.get(f"ll.sv.t{li}", (M, 64), torch.bfloat16, dev) if self.use_lora else None)
+                                     qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), self.storage, dev, zero=True),
+                                     gu=ws.get(f"ll.sv.gu{li}", (M, 2 * ll.inter), self.storage, dev),
+                                     t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev) if self.use_lora else None)
                 sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
                 qkv, t, h_mid, h_out = sv.qkv, sv.t, sv.h_mid, sv.h_out
             else:
                 h_mid = h_out = h
             if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
-                xl = ws.get("ll.xn_drop", (M, H), torch.bfloat16, dev)
+                xl = ws.get("ll.xn_drop", (M, H), self.storage, dev)
                 ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xl, dropout=dspec)  # both from one pass over h
             else:
                 ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
@@ -690,7 +701,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         self._pf = (self._pf_key(vision_embs), done, vision_embs, tag)
 
     def _prepare(self):
-        return SimpleNamespace(w_qp=_bf16(self.q_proj.weight),
+        return SimpleNamespace(w_qp=_to16(self.q_proj.weight, self.storage),
                                vis=self.vision_modality_embedding.detach().reshape(-1).contiguous(),
                                txt=self.text_modality_embedding.detach().reshape(-1).contiguous())
 
@@ -728,7 +739,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
         # bf16 copy for the cross-attention K/V projections; XATTN_PAD zeroed tail rows let those
         # GEMMs run on key counts padded to a multiple of 64 (TransformerLTSF.forward)
-        final_b = ws.get("mm.finalb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
+        final_b = ws.get("mm.finalb", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
         LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
         self._last_flags = flags
         if return_bf16:
@@ -857,6 +868,7 @@ class TransformerLTSF(nn.Module, _Prepared):
         st = lambda mods, attr: torch.stack([getattr(m, attr).detach() for m in mods], dim=0).contiguous()
         H = dec.cross_dim
         ca = dec.cross_attn
+        _bf16 = lambda t: _to16(t, self.storage)
         return SimpleNamespace(
             conv_w=self.token_proj.weight.detach()[:, :, 0].contiguous(),
             enc_w=st(self.nlinear_encoder.encoder_linears, "weight"), enc_b=st(self.nlinear_encoder.encoder_linears, "bias"),
@@ -893,8 +905,8 @@ class TransformerLTSF(nn.Module, _Prepared):
         dh = H // nh
         Lp = (L + XATTN_PAD - 1) // XATTN_PAD * XATTN_PAD
         if final_hidden_bf16 is None:
-            final_hidden_bf16 = ws.get("lt.fhb", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
-            ops.cast_bf16(final_hidden.contiguous().view(B * L, H), out=final_hidden_bf16)
+            final_hidden_bf16 = ws.get("lt.fhb", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
+            ops.cast16(final_hidden.contiguous().view(B * L, H), out=final_hidden_bf16)
         elif final_hidden_bf16.shape[0] < (B - 1) * L + Lp:
             raise ValueError("final_hidden_bf16 needs XATTN_PAD zeroed tail rows")
         # The cross-attention K / V projections (two chip-filling GEMMs over the LLM's final hidden states) do not depend
@@ -910,7 +922,7 @@ class TransformerLTSF(nn.Module, _Prepared):
             kv_ctx = contextlib.nullcontext()
         with kv_ctx:
             # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
-            kx = ws.get("lt.k", (B * L + XATTN_PAD, H), torch.bfloat16, dev, zero=True)
+            kx = ws.get("lt.k", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
             ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
             # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
             # (roles of weights and activations swapped, batched over samples), so that P.V is again
@@ -933,12 +945,12 @@ class TransformerLTSF(nn.Module, _Prepared):
         else:
             d1 = d0
         dec_t = ws.get("lt.dect", (B * To, C), torch.float32, dev)
-        dec_tb = ws.get("lt.dectb", (B * To, C), torch.bfloat16, dev)
+        dec_tb = ws.get("lt.dectb", (B * To, C), self.storage, dev)
         ops.transpose_ct(d1, dec_t, dec_tb, B, C, To)
         # cross attention over the LLM's final hidden states: K = V = final_hidden, no padding mask
-        proj = ws.get("lt.proj", (B * To, H), torch.bfloat16, dev)
+        proj = ws.get("lt.proj", (B * To, H), self.storage, dev)
         ops.gemm_bf16(dec_tb, P.w_dp, out=proj, bias=dec.dec_proj.bias)
-        q = ws.get("lt.q", (B * To, H), torch.bfloat16, dev)
+        q = ws.get("lt.q", (B * To, H), self.storage, dev)
         ops.gemm_bf16(proj, P.w_q, out=q, bias=P.b_q)
         if main is not None:
             main.wait_stream(self._kv_stream)
@@ -949,10 +961,10 @@ class TransformerLTSF(nn.Module, _Prepared):
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
         self.drop_xattn = _spec(self.dctx, self.dropout_p)
         ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
-        att = ws.get("lt.att", (B * To, H), torch.bfloat16, dev)
+        att = ws.get("lt.att", (B * To, H), self.storage, dev)
         ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
                          sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
-        cross = ws.get("lt.cross", (B * To, H), torch.bfloat16, dev)
+        cross = ws.get("lt.cross", (B * To, H), self.storage, dev)
         ops.gemm_bf16(att, P.w_co, out=cross, bias=dec.cross_attn.out_proj.bias)
         fused = ws.get("lt.fused", (B * To, C), torch.float32, dev)
         ops.gemm_bf16(cross, P.w_un, out=fused, bias=dec.dec_unproj.bias, residual=dec_t)
@@ -1028,6 +1040,21 @@ class MultiModalTrajectoryModel(nn.Module):
         for m in self.modules():
             if isinstance(m, _Prepared):
                 m._invalidate()
+
+    def set_storage(self, dtype):
+        """16-bit storage type of every GEMM operand of the model (weights copies and activations): torch.float16 (the
+        default, see _Prepared.storage) or torch.bfloat16.  Packed copies are rebuilt on the next forward."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("storage must be torch.float16 or torch.bfloat16")
+        for m in self.modules():
+            if isinstance(m, _Prepared):
+                m.storage = dtype
+                m._invalidate()
+        return self
+
+    @property
+    def storage(self):
+        return self.mllm.llama_wrapper.storage
 
     def mllm_is_deterministic(self):
         """True when a forward of the MLLM cannot depend on the dropout seed: eval mode, or no dropout site inside it

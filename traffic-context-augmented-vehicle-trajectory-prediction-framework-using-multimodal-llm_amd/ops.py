@@ -31,6 +31,21 @@ def _req(t, dtype, name):
         raise capi.TcavtError(f"{name}: tensor must be contiguous")
 
 
+_H16 = (torch.float16, torch.bfloat16)
+
+
+def _req16(t, name, like=None):
+    """16-bit storage tensor (fp16 = the forward path's default, or bf16); `like`: must share that tensor's dtype."""
+    if t is None:
+        return
+    if not t.is_cuda and not _ALLOW_CPU:
+        raise capi.TcavtError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype not in _H16 or (like is not None and t.dtype != like.dtype):
+        raise capi.TcavtError(f"{name}: expected {'fp16 or bf16' if like is None else like.dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise capi.TcavtError(f"{name}: tensor must be contiguous")
+
+
 def _need(t, numel, name):
     """Host-side guard: the buffer must hold at least what the kernel's grid will touch."""
     if t is not None and t.numel() < numel:
@@ -45,29 +60,30 @@ def _drop(d):
     return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(site) & 0xFFFFFFFF
 
 
-def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False, residual=None, a2=None,
+def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual=None, a2=None,
               w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None, silu_preact=None):
-    """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K] bf16, w [N,K] bf16.
+    """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K], w [N,K]: both fp16 or both bf16 (the name is
+    historical); out: fp32 or either 16-bit type (default: the operands' type).
 
     silu_preact (with silu_mul): bf16 [M, N] buffer that receives the gate|up pre-activations (for silu_mul_bwd).
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
     """
-    _req(a, torch.bfloat16, "gemm_bf16.a")
-    _req(w, torch.bfloat16, "gemm_bf16.w")
+    _req16(a, "gemm_bf16.a")
+    _req16(w, "gemm_bf16.w", like=a)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K
     n_out = N // 2 if silu_mul else N
     if out is None:
-        out = torch.empty((M, n_out), dtype=out_dtype, device=a.device)
+        out = torch.empty((M, n_out), dtype=out_dtype or a.dtype, device=a.device)
     _req(out, out.dtype, "gemm_bf16.out")
     args = capi.GemmArgs()
     args.A, args.lda = a.data_ptr(), a.stride(0)
     args.W, args.ldw = w.data_ptr(), w.stride(0)
     if a2 is not None:
-        _req(a2, torch.bfloat16, "gemm_bf16.a2")
-        _req(w2, torch.bfloat16, "gemm_bf16.w2")
+        _req16(a2, "gemm_bf16.a2", like=a)
+        _req16(w2, "gemm_bf16.w2", like=a)
         args.A2, args.lda2 = a2.data_ptr(), a2.stride(0)
         args.W2, args.ldw2 = w2.data_ptr(), w2.stride(0)
         args.K2 = a2.shape[1]
@@ -86,7 +102,7 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
     if silu_mul:
         epi |= EPI_SILU_MUL
         if silu_preact is not None:
-            _req(silu_preact, torch.bfloat16, "gemm_bf16.silu_preact")
+            _req16(silu_preact, "gemm_bf16.silu_preact", like=a)
             if silu_preact.shape[0] < M or silu_preact.shape[1] < N:
                 raise capi.TcavtError("gemm_bf16.silu_preact: smaller than (M, N)")
             args.silu_preact, args.ld_preact = silu_preact.data_ptr(), silu_preact.stride(0)
@@ -106,7 +122,8 @@ def gemm_bf16(a, w, out=None, *, out_dtype=torch.bfloat16, bias=None, relu=False
     if residual is not None and (residual.shape[0] < M or residual.shape[1] < N):
         raise capi.TcavtError("gemm_bf16.residual: smaller than (M, N)")
     args.M, args.N, args.K = M, N, K
-    args.out_dtype = BF16 if out.dtype == torch.bfloat16 else F32
+    args.out_dtype = _DT[out.dtype]
+    args.in_dtype = _DT[a.dtype]
     args.epilogue = epi
     args.tile = tile
     args.acc_scale = acc_scale
@@ -184,8 +201,8 @@ def dropout_(x, spec):
 
 def dropout(x, out, p, seed, site):
     """out = x * keep / (1 - p) with the Philox mask of (seed, site); x/out fp32 or bf16, in place allowed."""
-    if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16):
-        raise capi.TcavtError("dropout: x and out must both be fp32 or both bf16")
+    if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise capi.TcavtError("dropout: x and out must share one of fp32 / bf16 / fp16")
     _need(out, x.numel(), "dropout.out")
     check(lib().tcavt_dropout(ptr(x), ptr(out), x.numel(), _DT[x.dtype], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
                               int(site) & 0xFFFFFFFF, stream_ptr()), "tcavt_dropout")
@@ -202,11 +219,13 @@ def rmsnorm(x, gamma, eps, out_bf16=None, out_f32=None, out_drop=None, dropout=N
     _need(out_f32, M * H, "rmsnorm.out_f32")
     if (out_drop is None) != (dropout is None):
         raise capi.TcavtError("rmsnorm: out_drop and dropout go together")
+    _req16(out_bf16, "rmsnorm.out_bf16")
     if out_drop is not None:
-        _req(out_drop, torch.bfloat16, "rmsnorm.out_drop")
+        _req16(out_drop, "rmsnorm.out_drop", like=out_bf16)
         _need(out_drop, M * H, "rmsnorm.out_drop")
+    dt16 = _DT[out_bf16.dtype] if out_bf16 is not None else (_DT[out_drop.dtype] if out_drop is not None else BF16)
     check(lib().tcavt_rmsnorm(ptr(x), ptr(gamma), eps, ptr(out_bf16), ptr(out_f32), M, H, ptr(out_drop),
-                              *_drop(dropout), stream_ptr()), "tcavt_rmsnorm")
+                              *_drop(dropout), dt16, stream_ptr()), "tcavt_rmsnorm")
 
 
 def layernorm(x, gamma, beta, eps=1e-5, residual=None, out_f32=None, out_bf16=None):
@@ -216,20 +235,29 @@ def layernorm(x, gamma, beta, eps=1e-5, residual=None, out_f32=None, out_bf16=No
     for t, n, nm in ((gamma, D, "gamma"), (beta, D, "beta"), (residual, M * D, "residual"), (out_f32, M * D, "out_f32"),
                      (out_bf16, M * D, "out_bf16")):
         _need(t, n, "layernorm." + nm)
+    _req16(out_bf16, "layernorm.out_bf16")
     check(lib().tcavt_layernorm(ptr(x), ptr(residual), ptr(gamma), ptr(beta), eps, ptr(out_f32), ptr(out_bf16), M,
-                                D, stream_ptr()), "tcavt_layernorm")
+                                D, _DT[out_bf16.dtype] if out_bf16 is not None else BF16, stream_ptr()), "tcavt_layernorm")
 
 
-def cast_bf16(x, out=None):
+def cast16(x, out=None, dtype=torch.float16):
+    """fp32 -> fp16 / bf16 copy (round to nearest even); the type is `out`'s when given."""
     _req(x, torch.float32, "cast.x")
     if out is None:
-        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    check(lib().tcavt_cast_f32_bf16(ptr(x), ptr(out), x.numel(), stream_ptr()), "tcavt_cast_f32_bf16")
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _req16(out, "cast.out")
+    _need(out, x.numel(), "cast.out")
+    check(lib().tcavt_cast_f32_16(ptr(x), ptr(out), x.numel(), _DT[out.dtype], stream_ptr()), "tcavt_cast_f32_16")
     return out
 
 
+def cast_bf16(x, out=None):
+    """fp32 -> bf16 (gradient-side tensors); out may also be an fp16 buffer, whose type then wins."""
+    return cast16(x, out, torch.bfloat16)
+
+
 def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag):
-    _req(table, torch.bfloat16, "embed.table")
+    _req16(table, "embed.table")
     _req(ids, torch.int64, "embed.ids")
     _req(img, torch.float32, "embed.img")
     B, Lt = ids.shape
@@ -241,7 +269,7 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag):
     _need(txt_mod, H, "embed.txt_mod")
     _need(bad_flag, 1, "embed.bad_flag")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
-                                 V, ptr(bad_flag), stream_ptr()), "tcavt_embed_fuse")
+                                 V, ptr(bad_flag), _DT[table.dtype], stream_ptr()), "tcavt_embed_fuse")
 
 
 def mask_to_kvlen(mask, Nq, kv_len, flag):
@@ -254,20 +282,19 @@ def mask_to_kvlen(mask, Nq, kv_len, flag):
 
 
 def attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, scale):
-    _req(qkv, torch.bfloat16, "attn.qkv")
-    _req(out, torch.bfloat16, "attn.out")
+    _req16(qkv, "attn.qkv")
+    _req16(out, "attn.out", like=qkv)
     _req(kv_len, torch.int32, "attn.kv_len")
     _need(qkv, B * L * (nq + 2 * nkv) * 64, "attn.qkv")
     _need(out, B * L * nq * 64, "attn.out")
     _need(kv_len, B, "attn.kv_len")
-    check(lib().tcavt_attn_causal_gqa(ptr(qkv), ptr(out), ptr(kv_len), B, L, nq, nkv, scale, stream_ptr()),
-          "tcavt_attn_causal_gqa")
+    check(lib().tcavt_attn_causal_gqa(ptr(qkv), ptr(out), ptr(kv_len), B, L, nq, nkv, scale, _DT[qkv.dtype],
+                                      stream_ptr()), "tcavt_attn_causal_gqa")
 
 
 def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None, dropout=None):
     """q/k/v may be column slices of wider row-major buffers: pass the slice's data_ptr tensor and ld."""
-    in_dt = BF16 if q.dtype == torch.bfloat16 else F32
-    out_dt = BF16 if out.dtype == torch.bfloat16 else F32
+    in_dt, out_dt = _DT[q.dtype], _DT[out.dtype]
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise capi.TcavtError("mha: q, k, v must share a dtype")
     lq, lk, lv, lo = (ldq or q.stride(-2)), (ldk or k.stride(-2)), (ldv or v.stride(-2)), (ldo or out.stride(-2))
@@ -341,8 +368,9 @@ def ltsf_decode(e_tok, dec_w, dec_b, lane_adj, out, B, C, T, To):
 def transpose_ct(x, out_f32, out_bf16, B, C, To):
     for t, nm in ((x, "x"), (out_f32, "out_f32"), (out_bf16, "out_bf16")):
         _need(t, B * C * To, "transpose_ct." + nm)
-    check(lib().tcavt_transpose_ct(ptr(x), ptr(out_f32), ptr(out_bf16), B, C, To, stream_ptr()),
-          "tcavt_transpose_ct")
+    _req16(out_bf16, "transpose_ct.out_bf16")
+    check(lib().tcavt_transpose_ct(ptr(x), ptr(out_f32), ptr(out_bf16), B, C, To,
+                                   _DT[out_bf16.dtype] if out_bf16 is not None else BF16, stream_ptr()), "tcavt_transpose_ct")
 
 
 def out_head(fused, w, bias, x, out, B, To, C, F, T, add_last=True):
@@ -380,7 +408,8 @@ def gemm_f32_strided(a, rsA, csA, w, rsW, csW, out, M, N, K, bias=None, relu=Fal
 
 
 def transpose16(x, out, rows, cols, rows_pad, ld_in=None, ld_out=None, batch=1, s_in=0, s_out=0):
-    """out[c][r] = x[r][c] (16-bit), zero-filled for r in [rows, rows_pad); batched with strides."""
+    """out[c][r] = x[r][c] (16-bit), zero-filled for r in [rows, rows_pad); batched with strides.  An fp16 source with a
+    bf16 destination is converted on the way (forward activations entering a gradient-side contraction)."""
     ld_in = ld_in or x.stride(-2)
     ld_out = ld_out or out.stride(-2)
     if _avail(x) < (batch - 1) * s_in + (rows - 1) * ld_in + cols or \
@@ -388,8 +417,10 @@ def transpose16(x, out, rows, cols, rows_pad, ld_in=None, ld_out=None, batch=1, 
         raise capi.TcavtError("transpose16: buffer too small")
     if x.element_size() != 2 or out.element_size() != 2:
         raise capi.TcavtError("transpose16: 16-bit tensors only")
+    if x.dtype != out.dtype and not (x.dtype == torch.float16 and out.dtype == torch.bfloat16):
+        raise capi.TcavtError("transpose16: same 16-bit type on both sides, or fp16 -> bf16")
     check(lib().tcavt_transpose16(ptr(x), ld_in, ptr(out), ld_out, rows, cols, rows_pad, batch, s_in, s_out,
-                                  stream_ptr()), "tcavt_transpose16")
+                                  int(x.dtype != out.dtype), stream_ptr()), "tcavt_transpose16")
     return out
 
 

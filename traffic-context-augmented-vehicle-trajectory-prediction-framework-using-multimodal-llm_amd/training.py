@@ -49,6 +49,10 @@ class Trainer:
         for p in model.mllm.parameters():  # train.py:1141-1142
             p.requires_grad_(False)
         self.lora_trainable = bool(lora_trainable)
+        if self.lora_trainable and model.storage != torch.bfloat16:
+            # the decoder backward's kernels (csrc/llm_backward.hip) read the forward's tapes as bf16 and exchange bf16
+            # gradients with them: this variant runs the whole model with bf16 storage (the round-1 contract)
+            model.set_storage(torch.bfloat16)
         self.max_grad_norm = max_grad_norm
         # modify_train.py:1190-1196 skips clip + step on a non-finite loss; train.py has no such test
         self.skip_nonfinite = self.lora_trainable if skip_nonfinite is None else bool(skip_nonfinite)
@@ -134,7 +138,7 @@ class Trainer:
             if next_vision_embs is not None:
                 m.prefetch(next_vision_embs)  # before the backward: its leaf work shares the prefetch stream's queue
             B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
-            fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), torch.bfloat16, x.device)
+            fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), m.mllm.storage, x.device)
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
                         after_ltsf=lambda: self._allreduce_bucket(0, self.n_ltsf))
             self._allreduce_bucket(self.n_ltsf, self.n_base)
