@@ -163,6 +163,7 @@ int tcavt_layernorm(const float* x, const float* residual, const float* gamma,
 /* Elementwise train-mode dropout: out[i] = x[i] * keep(i) / (1-p), dtype TCAVT_F32, TCAVT_BF16 or TCAVT_F16 (in place
  * allowed).  Used for the LoRA branch input (lora_dropout, scripts/train.py:433-439). */
 int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
+                  const void* add /* optional, same dtype: out[i] = dropout(x)[i] + add[i] (two masked gradient addends) */,
                   tcavt_stream_t stream);
 
 /* fp32 -> fp16 / bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */

@@ -222,14 +222,18 @@ def test_lora_trainable_step(gpu):
     assert (a1 - a0).abs().max().item() > 0
     # the packed bf16 operands (and their transposes for the dgrad GEMMs) follow the updated parameters, every layer
     lw, r = m.mllm.llama_wrapper, cfg.lora_r
+    from tcavt_amd.model import LORA_V as LV
     nqh, nkvh = cfg.llama.n_q_heads * 64, cfg.llama.n_kv_heads * 64
     for li, lyr in enumerate(lw.llama_model.model.layers):
         d, dT, sa = lw._prepared().layers[li], lw.prepared_T()[li], lyr.self_attn
         assert torch.equal(d.a_cat[:r], sa.q_proj.lora_A.weight.detach().to(torch.bfloat16))
-        assert torch.equal(d.a_cat[r:2 * r], sa.v_proj.lora_A.weight.detach().to(torch.bfloat16))
+        assert torch.equal(d.a_cat[LV:LV + r], sa.v_proj.lora_A.weight.detach().to(torch.bfloat16))
         assert torch.equal(d.b_ext[:nqh, :r], sa.q_proj.lora_B.weight.detach().to(torch.bfloat16))
-        assert torch.equal(d.b_ext[nqh + nkvh:, r:2 * r], sa.v_proj.lora_B.weight.detach().to(torch.bfloat16))
-        assert d.a_cat[2 * r:].abs().max().item() == 0 and d.b_ext[nqh:nqh + nkvh].abs().max().item() == 0
+        assert torch.equal(d.b_ext[nqh + nkvh:, LV:LV + r], sa.v_proj.lora_B.weight.detach().to(torch.bfloat16))
+        assert d.a_cat[r:LV].abs().max().item() == 0 and d.a_cat[LV + r:].abs().max().item() == 0
+        assert d.b_ext[nqh:nqh + nkvh].abs().max().item() == 0
+        assert torch.equal(dT.a_q[:, :LV], d.a_cat[:LV].t()) and dT.a_q[:, LV:].abs().max().item() == 0
+        assert torch.equal(dT.a_v[:, LV:], d.a_cat[LV:].t()) and dT.a_v[:, :LV].abs().max().item() == 0
         assert torch.equal(dT.a_cat, d.a_cat.t()) and torch.equal(dT.b_ext, d.b_ext.t())
     l1, _ = tr.forward_backward(*args)
     torch.cuda.synchronize()

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // Elementwise dropout, one Philox call per quad of elements.
 template <typename T, bool F16 = false>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long n, DropoutP drop) {
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long n, DropoutP drop,
+                                                      const T* __restrict__ add) {
   const long nq = (n + 3) >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     for (int e = 0; e < 4; ++e) {
       const long i = 4 * q + e;
       if (i < n) {
-        if constexpr (sizeof(T) == 2) out[i] = to16<F16>(from16<F16>(x[i]) * sc[e]);
-        else out[i] = x[i] * sc[e];
+        if constexpr (sizeof(T) == 2) out[i] = to16<F16>(from16<F16>(x[i]) * sc[e] + (add ? from16<F16>(add[i]) : 0.f));
+        else out[i] = x[i] * sc[e] + (add ? add[i] : 0.f);
       }
     }
   }
@@ -305,7 +306,7 @@ extern "C" int tcavt_softmax_rows(const float* S, int64_t lds, void* P, int64_t 
 }
 
 extern "C" int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint64_t seed, uint32_t site,
-                             tcavt_stream_t stream) {
+                             const void* add, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
   TCAVT_CHECK_ARG(dtype == TCAVT_F32 || is16(dtype), "dropout: dtype must be f32, bf16 or fp16");
   long blocks = ((n + 3) / 4 + 255) / 256;
@@ -313,13 +314,13 @@ extern "C" int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, flo
   const DropoutP d = make_dropout(p, seed, site);
   if (dtype == TCAVT_F32)
     hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(x), static_cast<float*>(out), (long)n, d);
+                       static_cast<const float*>(x), static_cast<float*>(out), (long)n, d, static_cast<const float*>(add));
   else if (dtype == TCAVT_F16)
     hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d);
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add));
   else
     hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d);
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add));
   TCAVT_CHECK_LAUNCH("dropout");
   return TCAVT_OK;
 }

@@ -10,7 +10,8 @@ adapter gradients:
     per layer, last to first:
         down^T (dgrad GEMM)  ->  d(silu*up)  ->  gate|up^T (dgrad GEMM)  ->  RMSNorm backward        (MLP half)
         o^T (dgrad GEMM)  ->  causal GQA attention backward  ->  RoPE^T  ->  g(q|k|v)
-        LoRA:  g_t = s * g(q|k|v) B_ext ;  dB = g(q|k|v)^T t ;  dA = g_t^T dropout(xn) ;  g_xl = mask * (g_t A_cat)
+        LoRA:  g_t = s * g(q|k|v) B_ext ;  dB = g(q|k|v)^T t ;  dA_q = g_tq^T drop_q(xn), dA_v = g_tv^T drop_v(xn) ;
+               g_xl = mask_q * (g_tq A_q) + mask_v * (g_tv A_v)      (one dropout site per adapter, as PEFT has them)
         q|k|v^T (dgrad GEMM)  ->  RMSNorm backward                                                    (attention half)
 
 The dgrad GEMMs are the forward's MFMA kernel on transposed copies of the frozen weights (prepared_T); the gate|up
@@ -24,6 +25,7 @@ import os
 import torch
 
 from . import ops, streams
+from .model import LORA_V
 
 
 def _rup(x, m):
@@ -146,6 +148,8 @@ class LoraBackward:
         g_hb = self._buf("g_hb", (M, H))
         xn = self._buf("xn", (M, H))
         xl = self._buf("xl", (M, H))
+        xl2 = self._buf("xl2", (M, H))
+        g_xl2 = self._buf("g_xl2", (M, H))
         g_xn = self._buf("g_xn", (M, H))
         g_xl = self._buf("g_xl", (M, H))
         g_act = self._buf("g_act", (M, I))
@@ -182,19 +186,20 @@ class LoraBackward:
             ops.gemm_bf16(g_qkv, dT.b_ext, out=g_t, acc_scale=s)
 
             def adapter_grads(li=li, d=d, sv=sv, g_qkv=g_qkv, g_t=g_t):
-                if sv.dspec is not None:  # the adapter branch's input, recomputed with the forward's mask
-                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec)
-                    x_lora = xl
+                self._wgrad("dB", g_qkv, sv.t, dB)
+                if sv.dspec is not None:  # the adapter branches' inputs, recomputed with the forward's two masks
+                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
+                    ops.dropout(xn, xl2, *sv.dspec[1])
+                    self._wgrad("dAq", g_t[:, :LORA_V], xl, dA[:LORA_V])
+                    self._wgrad("dAv", g_t[:, LORA_V:2 * LORA_V], xl2, dA[LORA_V:2 * LORA_V])
                 else:
                     ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
-                    x_lora = xn
-                self._wgrad("dB", g_qkv, sv.t, dB)
-                self._wgrad("dA", g_t, x_lora, dA)
+                    self._wgrad("dA", g_t, xn, dA)
                 p = f"{pre}{li}.self_attn."
                 G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
-                G[p + "v_proj.lora_A.weight"].copy_(dA[r:2 * r])
+                G[p + "v_proj.lora_A.weight"].copy_(dA[LORA_V:LORA_V + r])
                 G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
-                G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, r:2 * r])
+                G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, LORA_V:LORA_V + r])
 
             if leaf is None:
                 adapter_grads()
@@ -208,8 +213,13 @@ class LoraBackward:
                     leaf_done[par].record(leaf)
             if li == 0:
                 break
-            ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
-            ops.dropout_(g_xl, sv.dspec)
+            if sv.dspec is None:
+                ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
+            else:  # each adapter's input gradient under its own mask, summed
+                ops.gemm_bf16(g_t, dT.a_q, out=g_xl2)
+                ops.dropout_(g_xl2, sv.dspec[0])
+                ops.gemm_bf16(g_t, dT.a_v, out=g_xl)
+                ops.dropout(g_xl, g_xl, *sv.dspec[1], add=g_xl2)
             ops.gemm_bf16(g_qkv, dT.w_qkv, out=g_xn)
             ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True, gx_bf16=g_hb)
         if leaf is not None:

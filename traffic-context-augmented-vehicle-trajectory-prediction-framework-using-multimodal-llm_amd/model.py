@@ -104,6 +104,11 @@ def _to16(t, dtype):
 
 
 XATTN_PAD = 64  # key counts of the head cross-attention are padded to a multiple of this
+# Packed LoRA layout: a_cat [64, H] holds A_q in rows [0, r) and A_v in rows [LORA_V, LORA_V + r); b_ext [nqkv, 64] holds B_q in
+# columns [0, r) of the q rows and B_v in columns [LORA_V, LORA_V + r) of the v rows; everything else is zero.  The two adapters
+# sit in separate 16-column groups so that, with LoRA dropout on, each down-projection can be a GEMM of its own (N = 16) on its
+# own dropped input -- PEFT gives every adapted Linear its own lora_dropout module (independent masks for q_proj and v_proj).
+LORA_V = 16
 
 
 class DropoutCtx:
@@ -473,6 +478,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             d.w_qkv = _bf16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
             if self.use_lora:
                 r = self.lora_r
+                if r > LORA_V:
+                    raise ValueError(f"lora_r = {r}: the packed adapter layout holds ranks up to {LORA_V}")
                 H = ll.hidden
                 if a_all is None:
                     # all layers' packed adapters in two tensors, LAST layer first (the order of the trainer's flat
@@ -481,9 +488,9 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                     b_all = torch.zeros(nL, (nq + 2 * nkv) * hd, 64, dtype=self.storage, device=d.w_qkv.device)
                 d.a_cat, d.b_ext = a_all[nL - 1 - li], b_all[nL - 1 - li]
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
-                d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
+                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
                 d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
-                d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
             d.w_o = _bf16(a.o_proj.weight)
             d.w_gu = _bf16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()))
             d.w_d = _bf16(lyr.mlp.down_proj.weight)
@@ -502,11 +509,20 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             nL = len(P.layers)
             at_all = P.a_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), H, 64]
             bt_all = P.b_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), 64, nqkv]
+            # with LoRA dropout on, the two adapters' input gradients carry different masks: A_q^T and A_v^T alone
+            # (the other adapter's columns zeroed), each the W operand of its own K = 64 product
+            atq_all = atv_all = None
+            if self.use_lora:
+                atq_all, atv_all = at_all.clone(), at_all.clone()
+                atq_all[:, :, LORA_V:] = 0
+                atv_all[:, :, :LORA_V] = 0
             self._prep_T = [SimpleNamespace(w_qkv=tr(d.w_qkv), w_o=tr(d.w_o), w_gu=tr(d.w_gu), w_d=tr(d.w_d),
                                             a_cat=at_all[nL - 1 - li] if self.use_lora else None,
+                                            a_q=atq_all[nL - 1 - li] if self.use_lora else None,
+                                            a_v=atv_all[nL - 1 - li] if self.use_lora else None,
                                             b_ext=bt_all[nL - 1 - li] if self.use_lora else None)
                             for li, d in enumerate(P.layers)]
-            self._prep_T_all = (at_all, bt_all)
+            self._prep_T_all = (at_all, bt_all, atq_all, atv_all)
         return self._prep_T
 
     def _invalidate(self):
@@ -526,20 +542,22 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         if stacked is not None:
             aq, bq, av, bv = stacked
             P.a_all[:, :r].copy_(aq)
-            P.a_all[:, r:2 * r].copy_(av)
+            P.a_all[:, LORA_V:LORA_V + r].copy_(av)
             P.b_all[:, : nq * hd, :r].copy_(bq)
-            P.b_all[:, (nq + nkv) * hd:, r:2 * r].copy_(bv)
+            P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv)
         else:
             for li, lyr in enumerate(self.llama_model.model.layers):
                 a, d = lyr.self_attn, P.layers[li]
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
-                d.a_cat[r:2 * r].copy_(a.v_proj.lora_A.weight.detach())
+                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
                 d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
-                d.b_ext[(nq + nkv) * hd:, r:2 * r].copy_(a.v_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
         if self._prep_T is not None:
-            at_all, bt_all = self._prep_T_all
+            at_all, bt_all, atq_all, atv_all = self._prep_T_all
             at_all.copy_(P.a_all.transpose(1, 2))
             bt_all.copy_(P.b_all.transpose(1, 2))
+            atq_all[:, :, :LORA_V].copy_(at_all[:, :, :LORA_V])
+            atv_all[:, :, LORA_V:].copy_(at_all[:, :, LORA_V:])
 
     def _rope_tables(self, L, dev):
         key = (L, str(dev))
@@ -560,7 +578,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         qkv = ws.get("ll.qkv", (M, nqkv), self.storage, dev)
         att = ws.get("ll.att", (M, nq * hd), self.storage, dev)
         act = ws.get("ll.act", (M, ll.inter), self.storage, dev)
-        t = ws.get("ll.lora_t", (M, 64), self.storage, dev) if self.use_lora else None
+        t = ws.get("ll.lora_t", (M, 64), self.storage, dev, zero=True) if self.use_lora else None
         scale = 1.0 / math.sqrt(hd)
         tile = self.gemm_tile
         tm = self.timer
@@ -570,8 +588,12 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         if self.save_for_backward:
             tape = self.tape = SimpleNamespace(layers=[], kv_len=kv_len, B=B, L=L, h_last=None)
         for li, d in enumerate(P.layers):
-            xl = xn
-            dspec = _spec(self.dctx, self.lora_dropout) if self.use_lora else None
+            # PEFT: lora_B(lora_A(dropout(x))) with one dropout module per adapted Linear -> two sites per layer, q_proj
+            # then v_proj (the order modeling_llama.py:254-256 calls them in); the base projection sees x itself
+            dspec = None
+            if self.use_lora:
+                dq, dv = _spec(self.dctx, self.lora_dropout), _spec(self.dctx, self.lora_dropout)
+                dspec = (dq, dv) if dq is not None else None
             if tape is not None:
                 # per-layer buffers instead of the shared ones: the residual stream is written to a new buffer by each
                 # residual epilogue (no copies), q|k|v and the LoRA down-projection stay where the backward finds them
@@ -580,19 +602,25 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                                      h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
                                      qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), self.storage, dev, zero=True),
                                      gu=ws.get(f"ll.sv.gu{li}", (M, 2 * ll.inter), self.storage, dev),
-                                     t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev) if self.use_lora else None)
+                                     t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev, zero=True) if self.use_lora else None)
                 sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
                 qkv, t, h_mid, h_out = sv.qkv, sv.t, sv.h_mid, sv.h_out
             else:
                 h_mid = h_out = h
-            if dspec is not None:  # PEFT: lora_B(lora_A(dropout(x))); the base projection sees x itself
-                xl = ws.get("ll.xn_drop", (M, H), self.storage, dev)
-                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xl, dropout=dspec)  # both from one pass over h
+            sc = self.lora_alpha / self.lora_r
+            if dspec is not None:
+                xq = ws.get("ll.xn_drop", (M, H), self.storage, dev)
+                xv = ws.get("ll.xn_drop2", (M, H), self.storage, dev)
+                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xq, dropout=dspec[0])  # both from one pass over h
+                ops.dropout(xn, xv, *dspec[1])
+                ops.gemm_bf16(xq, d.a_cat[:LORA_V], out=t[:, :LORA_V], acc_scale=sc, tile=128)
+                ops.gemm_bf16(xv, d.a_cat[LORA_V:2 * LORA_V], out=t[:, LORA_V:2 * LORA_V], acc_scale=sc, tile=128)
             else:
                 ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
+                if self.use_lora:
+                    ops.gemm_bf16(xn, d.a_cat, out=t, acc_scale=sc, tile=128)
             if self.use_lora:
-                ops.gemm_bf16(xl, d.a_cat, out=t, acc_scale=self.lora_alpha / self.lora_r, tile=128)
                 mark("qkv")
                 ops.gemm_bf16(xn, d.w_qkv, out=qkv, a2=t, w2=d.b_ext, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
                 done("qkv")

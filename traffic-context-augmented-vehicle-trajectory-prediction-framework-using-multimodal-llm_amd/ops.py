@@ -77,7 +77,8 @@ def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual
     n_out = N // 2 if silu_mul else N
     if out is None:
         out = torch.empty((M, n_out), dtype=out_dtype or a.dtype, device=a.device)
-    _req(out, out.dtype, "gemm_bf16.out")
+    if (not out.is_cuda and not _ALLOW_CPU) or out.dim() != 2 or out.stride(1) != 1:  # a column slice of a wider buffer is fine
+        raise capi.TcavtError("gemm_bf16.out: 2-D GPU tensor with unit column stride required")
     args = capi.GemmArgs()
     args.A, args.lda = a.data_ptr(), a.stride(0)
     args.W, args.ldw = w.data_ptr(), w.stride(0)
@@ -199,13 +200,16 @@ def dropout_(x, spec):
     return x
 
 
-def dropout(x, out, p, seed, site):
-    """out = x * keep / (1 - p) with the Philox mask of (seed, site); x/out fp32 or bf16, in place allowed."""
+def dropout(x, out, p, seed, site, add=None):
+    """out = x * keep / (1 - p) (+ add) with the Philox mask of (seed, site); x/out/add share fp32, bf16 or fp16; in
+    place allowed."""
     if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         raise capi.TcavtError("dropout: x and out must share one of fp32 / bf16 / fp16")
     _need(out, x.numel(), "dropout.out")
+    if add is not None and (add.dtype != x.dtype or add.numel() < x.numel()):
+        raise capi.TcavtError("dropout.add: same dtype and at least as many elements as x")
     check(lib().tcavt_dropout(ptr(x), ptr(out), x.numel(), _DT[x.dtype], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                              int(site) & 0xFFFFFFFF, stream_ptr()), "tcavt_dropout")
+                              int(site) & 0xFFFFFFFF, ptr(add), stream_ptr()), "tcavt_dropout")
     return out
 
 
