@@ -30,11 +30,20 @@ import torch.nn.functional as F
 LLAMA = "mllm.llama_wrapper.llama_model.model."
 
 
+def _ste(dtype):
+    """Round the VALUE to `dtype` and let the gradient pass unchanged (straight-through): autograd through a plain
+    .to(fp16).to(fp32) pair would push the gradient through fp16 as well, where the pixel-space loss overflows it."""
+    def cast(t):
+        q = t.detach().to(dtype).to(torch.float32)
+        return t + (q - t.detach()) if t.requires_grad else q
+    return cast
+
+
 _CASTS = {
     "fp32": lambda t: t,
-    "bf16": lambda t: t.to(torch.bfloat16).to(torch.float32),
+    "bf16": _ste(torch.bfloat16),
     # fp16 storage as the HIP path does it: IEEE half, round to nearest even; beyond +-65504 -> inf (outside the contract)
-    "fp16": lambda t: t.to(torch.float16).to(torch.float32),
+    "fp16": _ste(torch.float16),
 }
 
 
