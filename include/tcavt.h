@@ -85,6 +85,16 @@ int tcavt_init(int device, int* num_cus);
                                  activations and weights are swapped to emit a transposed result) */
 #define TCAVT_EPI_ACCUM 64    /* tcavt_gemm_f32[_strided] only: C already holds a valid partial result (zeros or an
                                  earlier gradient contribution); the product is ADDED to it and no memset is issued */
+/* Llama RMSNorm (modeling_llama.py:62-67) fused into the GEMMs on either side of it -- "fused RMSNorm+RoPE+QKV-proj":
+ *   y = (x * rsqrt(mean(x^2) + eps) * gamma) . W^T  ==  rsqrt(mean(x^2) + eps) * ( x . (W * gamma)^T )
+ * NORM_OUT  (producer: o_proj / down_proj; fp32 output, optionally + RESIDUAL): besides C the epilogue writes the
+ *           16-bit copy of C's rows to `norm_h16` (leading dimension ldc; it is the next projection's A operand) and,
+ *           for every row and 64-column group, the sum of squares of the fp32 values to norm_part[M][N / 64].
+ * ROWSCALE  (consumer: ROPE or SILU_MUL epilogue; gamma is folded into W by the caller): the accumulator row m is
+ *           multiplied by rsqrt(sum_i rowscale_part[m][i] / rowscale_h + rowscale_eps) first; the partials are added in
+ *           index order (no atomics: bit-reproducible).  rowscale_npart % 4 == 0. */
+#define TCAVT_EPI_NORM_OUT 128
+#define TCAVT_EPI_ROWSCALE 256
 
 typedef struct tcavt_gemm_args {
   const void* A;   int64_t lda;  /* bf16 [M][K]  */
@@ -131,6 +141,14 @@ typedef struct tcavt_gemm_args {
    * dimension ld_preact) next to the activated output -- what the backward of silu(gate)*up needs (tcavt_silu_mul_bwd) */
   void* silu_preact;
   int64_t ld_preact;
+  /* TCAVT_EPI_NORM_OUT / TCAVT_EPI_ROWSCALE (see the flag definitions) */
+  void* norm_h16;
+  float* norm_part;
+  const float* rowscale_part;
+  int32_t rowscale_npart;
+  int32_t rowscale_h;
+  float rowscale_eps;
+  int32_t reserved1;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -175,11 +193,14 @@ int tcavt_cast_f32_16(const float* x, void* out16, int64_t n, int dtype16, tcavt
  *   h[b][Nq + j] = table[ids[b][j]] + txt_mod        j <  Lt
  * table fp16 / bf16 (table_dtype) [V][H]; ids int64 [B][Lt]; img fp32 [B][Nq][H]; h fp32 [B][Nq+Lt][H].
  * Ids outside [0,V) are reported through *bad_id_flag (device int, set to 1).
+ * h16 / part (optional, both or neither): what the first decoder layer's fused RMSNorm needs (TCAVT_EPI_ROWSCALE) --
+ * the 16-bit copy of h (same type as the table) and part[row][npart] with the row's sum of squares in slot 0 and zeros
+ * in the others (npart = H / 64, the layout TCAVT_EPI_NORM_OUT writes).
  * ---------------------------------------------------------------------- */
 int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                      const float* vis_mod, const float* txt_mod, float* h, int B,
                      int Nq, int Lt, int H, int V, int* bad_id_flag, int table_dtype,
-                     tcavt_stream_t stream);
+                     void* h16, float* part, int npart, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * attention_mask -> per-sample valid key count of the fused sequence
@@ -420,6 +441,79 @@ int tcavt_masked_mean_bwd(const float* gemb, const int32_t* len, float* genc, in
 /* torch.optim.AdamW step over a flat fp32 vector; grad_scale multiplies g first (1/world for DP mean) */
 int tcavt_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, float grad_scale, tcavt_stream_t stream);
+
+/* ========================================================================
+ * Stage-level entry points: the decoder stack issued from C++ -- one call enqueues the whole
+ * HF LlamaModel.forward (modeling_llama.py:376-424 as called from scripts/train.py:446-452) for a batch: per layer
+ *   [LoRA down-projection(s)]  q|k|v projection with the input RMSNorm fused in (gamma folded into the weights, 1 / rms
+ *   as a row scale in the RoPE epilogue) + LoRA update  ->  causal GQA attention  ->  o_proj + residual (emitting the next
+ *   norm's 16-bit input and partial sums of squares)  ->  gate|up with the post-attention RMSNorm fused in the same way,
+ *   SiLU * up epilogue  ->  down_proj + residual (again emitting the next norm's inputs);  then the final RMSNorm.
+ * No allocation, no synchronisation, graph-capturable; every buffer is the caller's.  Host cost: a few microseconds
+ * per launch instead of a Python call each.
+ * ====================================================================== */
+typedef struct tcavt_llama_layer {
+  const void* w_qkv;  /* 16-bit [(nq + 2 nkv) * 64][H], rows q | k | v, input_layernorm.weight folded in (W * gamma) */
+  const void* a_cat;  /* 16-bit [64][H] or NULL (no LoRA): A_q in rows [0, r), A_v in rows [16, 16 + r), gamma folded in */
+  const void* b_ext;  /* 16-bit [(nq + 2 nkv) * 64][64]: B_q in columns [0, r) of the q rows, B_v in [16, 16 + r) of the v rows */
+  const void* w_o;    /* 16-bit [H][nq * 64] */
+  const void* w_gu;   /* 16-bit [2 I][H], gate / up rows interleaved in blocks of 16 (TCAVT_EPI_SILU_MUL), post_attention_layernorm.weight folded in */
+  const void* w_d;    /* 16-bit [H][I] */
+  /* LoRA-trainable variant (optional, all NULL otherwise): per-layer buffers the backward reads (csrc/llm_backward.hip) */
+  float* tape_h_mid;  /* fp32 [M][H]: residual stream after the attention half (then h_in stays untouched) */
+  float* tape_h_out;  /* fp32 [M][H]: residual stream after the MLP half */
+  void* tape_qkv;     /* 16-bit [M (+ pad)][(nq + 2 nkv) * 64]: rotated q|k|v of this layer */
+  void* tape_gu;      /* 16-bit [M][2 I]: gate|up pre-activations (interleaved layout) */
+  void* tape_t;       /* 16-bit [M][64]: LoRA down-projection */
+} tcavt_llama_layer;
+
+typedef struct tcavt_llama_stack_args {
+  const tcavt_llama_layer* layers; /* HOST array of n_layers entries */
+  const float* gamma_final;        /* fp32 [H]: model.norm.weight */
+  const float* rope_cos;           /* fp32 [L][32] */
+  const float* rope_sin;
+  float* h;                        /* fp32 [M][H]: the fused input embeddings; updated in place unless a tape is kept */
+  void* h16;                       /* 16-bit [M][H]: copy of h (tcavt_embed_fuse writes it); rewritten by every residual epilogue */
+  float* part;                     /* fp32 [M][H / 64]: partial sums of squares of h's rows (same producers) */
+  const int32_t* kv_len;           /* int32 [B] */
+  /* workspaces, 16-bit */
+  void* qkv;                       /* [M][(nq + 2 nkv) * 64] (unused when the layers carry tape_qkv) */
+  void* att;                       /* [M][nq * 64] */
+  void* act;                       /* [M][I] */
+  void* t;                         /* [M][64], zero-initialised once by the caller (columns >= 32 are never written) */
+  void* xq;                        /* [M][H] x 2 (lora_dropout_p > 0 only): dropped copies of h16 for the two adapters */
+  void* xv;
+  /* outputs */
+  float* out_f32;                  /* fp32 [M][H] or NULL: hidden_states[-1] (scripts/train.py:553) */
+  void* out16;                     /* 16-bit [M][H] or NULL */
+  /* optional: rotated keys / values of every layer, for the decode steps that follow a prefill (text generation,
+     scripts/train.py:577-654): 16-bit [n_layers][B][kv_lmax][nkv * 64] each */
+  void* k_cache;
+  void* v_cache;
+  /* optional: HOST array of hipEvent_t, 10 per layer (start / stop around q|k|v, attention, o, gate|up, down) --
+     in-situ kernel timing on the launching stream (bench.py's roofline leg) */
+  void* const* events;
+  int32_t n_layers, B, L, H, I, nq, nkv, dtype16;
+  int32_t kv_lmax;
+  int32_t gemm_tile;               /* tcavt_gemm_args.tile for the four big projections (0 = auto) */
+  float rms_eps, lora_scale;       /* lora_scale = alpha / r */
+  float lora_dropout_p;            /* > 0: train mode; sites first_site + 2 l (q_proj), first_site + 2 l + 1 (v_proj) */
+  uint32_t lora_first_site;
+  uint64_t dropout_seed;
+} tcavt_llama_stack_args;
+
+int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
+
+/* x16 = 16-bit copy of x fp32 [M][H], part[M][npart] = (sum of squares of the row, 0, 0, ...): the h16 / part inputs of
+ * tcavt_llama_stack_forward for embeddings that do not come from tcavt_embed_fuse (HF-style inputs_embeds call) */
+int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16,
+                       tcavt_stream_t stream);
+
+/* hipEvent helpers for tcavt_llama_stack_args.events (timing enabled); elapsed time in milliseconds between two
+ * recorded events after the stream has been synchronised by the caller */
+int tcavt_events_create(void** events, int n);
+int tcavt_events_destroy(void** events, int n);
+int tcavt_event_elapsed_ms(void* start, void* stop, float* ms);
 
 /* tcavt_adamw gated on a finite loss, as the LoRA-trainable loop does (modify_scripts/modify_train.py:1190-1196:
  * `if torch.isfinite(loss): clip; optimizer.step()  else: skip`), decided on the device: the update is skipped when

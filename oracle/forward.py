@@ -266,23 +266,31 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
     causal = i[None, :] <= i[:, None]
     allowed = causal[None] & (attn_mask[:, None, :] > 0)  # [B, Lq, Lk]
     h = embeds
+    # RMSNorm (modeling_llama.py:62-67) in the algebraic form the HIP path computes it in (csrc/stack.hip): the gain is
+    # folded into the following projection's weights (product in fp32, rounded once), the 16-bit operand is the rounded
+    # residual stream itself, and rs = rsqrt(mean(h^2) + eps) scales the fp32 accumulator rows:
+    #     (h rs gamma) W^T  ==  rs * (h (W gamma)^T)          -- identical in exact arithmetic, and in the fp32 contract
+    def norm_parts(x):
+        return r(x, "xn"), torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + ll.rms_eps)
+
     for layer in range(ll.layers):
         P = f"{LLAMA}layers.{layer}."
-        xn = r(rms_norm(h, r(W[P + "input_layernorm.weight"], "gamma"), ll.rms_eps), "xn")
-        q = xn @ r(W[P + "self_attn.q_proj.weight"], "w").T
-        k = xn @ r(W[P + "self_attn.k_proj.weight"], "w").T
-        v = xn @ r(W[P + "self_attn.v_proj.weight"], "w").T
+        g1, g2 = W[P + "input_layernorm.weight"], W[P + "post_attention_layernorm.weight"]
+        hb, rs = norm_parts(h)
+        q = hb @ r(W[P + "self_attn.q_proj.weight"] * g1, "w").T
+        k = hb @ r(W[P + "self_attn.k_proj.weight"] * g1, "w").T
+        v = hb @ r(W[P + "self_attn.v_proj.weight"] * g1, "w").T
         if cfg.use_lora:
             s = lora_scale(cfg)
-            xq = xn if drop is _ident else r(drop(xn), "xn")
-            xv = xn if drop is _ident else r(drop(xn), "xn")
-            tq = r(s * (xq @ r(W[P + "self_attn.q_proj.lora_A.weight"], "w").T), "t")
-            tv = r(s * (xv @ r(W[P + "self_attn.v_proj.lora_A.weight"], "w").T), "t")
+            xq = hb if drop is _ident else r(drop(hb), "xn")
+            xv = hb if drop is _ident else r(drop(hb), "xn")
+            tq = r(s * (xq @ r(W[P + "self_attn.q_proj.lora_A.weight"] * g1, "w").T), "t")
+            tv = r(s * (xv @ r(W[P + "self_attn.v_proj.lora_A.weight"] * g1, "w").T), "t")
             q = q + tq @ r(W[P + "self_attn.q_proj.lora_B.weight"], "w").T
             v = v + tv @ r(W[P + "self_attn.v_proj.lora_B.weight"], "w").T
-        q = q.view(B, L, nq, hd)
-        k = k.view(B, L, nkv, hd)
-        v = v.view(B, L, nkv, hd)
+        q = (rs * q).view(B, L, nq, hd)
+        k = (rs * k).view(B, L, nkv, hd)
+        v = (rs * v).view(B, L, nkv, hd)
 
         def rot(t):
             t1, t2 = t[..., : hd // 2], t[..., hd // 2:]
@@ -296,14 +304,14 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
         s = s.masked_fill(~allowed[:, None], float("-inf"))
         a = r((r(torch.softmax(s, dim=-1), "p") @ vh).permute(0, 2, 1, 3).reshape(B, L, nq * hd), "att")
         h = h + a @ r(W[P + "self_attn.o_proj.weight"], "w").T
-        xn2 = r(rms_norm(h, r(W[P + "post_attention_layernorm.weight"], "gamma"), ll.rms_eps), "xn")
-        g = xn2 @ r(W[P + "mlp.gate_proj.weight"], "w").T
-        u = xn2 @ r(W[P + "mlp.up_proj.weight"], "w").T
+        hb2, rs2 = norm_parts(h)
+        g = rs2 * (hb2 @ r(W[P + "mlp.gate_proj.weight"] * g2, "w").T)
+        u = rs2 * (hb2 @ r(W[P + "mlp.up_proj.weight"] * g2, "w").T)
         act = r(F.silu(g) * u, "act")
         h = h + act @ r(W[P + "mlp.down_proj.weight"], "w").T
         if collect is not None:
             collect.append(h)
-    return rms_norm(h, r(W[LLAMA + "norm.weight"], "gamma"), ll.rms_eps)
+    return rms_norm(h, W[LLAMA + "norm.weight"], ll.rms_eps)  # the final norm is a kernel of its own: fp32 in, fp32 out
 
 
 # --------------------------------------------------------------------------------------

@@ -29,21 +29,41 @@ def test_header_symbols_are_exported_and_bound():
     assert capi.lib().tcavt_abi_version() == capi.ABI_VERSION == 2
 
 
-def test_gemm_args_struct_matches_header_layout():
-    """Field order of the ctypes mirror must follow the C struct."""
-    from tcavt_amd import capi
-
+def _struct_fields(name):
     text = open(os.path.join(ROOT, "include", "tcavt.h")).read()
-    body = text[text.index("typedef struct tcavt_gemm_args {"):text.index("} tcavt_gemm_args;")]
+    body = text[text.index("typedef struct %s {" % name):text.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
         decl = decl.split("{")[-1].strip()
         if not decl:
             continue
-        parts = re.sub(r"^(const\s+)?[A-Za-z0-9_]+\s*\*?", "", decl).split(",")
-        names += [p.strip().lstrip("*").strip() for p in parts if p.strip()]
-    assert names == [f[0] for f in capi.GemmArgs._fields_]
+        decl = re.sub(r"^(const\s+)?[A-Za-z0-9_]+(\s+const)?\s*\**(\s*const)?", "", decl)
+        names += [p.strip().lstrip("*").strip() for p in decl.split(",") if p.strip()]
+    return names
+
+
+@pytest.mark.parametrize("cname,mirror", [("tcavt_gemm_args", "GemmArgs"), ("tcavt_llama_layer", "LlamaLayer"),
+                                          ("tcavt_llama_stack_args", "LlamaStackArgs")])
+def test_struct_mirrors_match_header_layout(cname, mirror, tmp_path):
+    """Field order of each ctypes mirror follows the C struct, and -- compiled with the host C compiler against the real
+    header -- so do sizeof and every field offset."""
+    import subprocess
+
+    from tcavt_amd import capi
+
+    cls = getattr(capi, mirror)
+    names = _struct_fields(cname)
+    assert names == [f[0] for f in cls._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tcavt.h"\nint main(void) {\n'
+                   + f'  printf("%zu\\n", sizeof({cname}));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof({cname}, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(cls)
+    assert out[1:] == [getattr(cls, n).offset for n in names]
 
 
 def test_argument_errors_are_reported_not_crashed():

@@ -364,6 +364,7 @@ def test_step_with_qformer_prefetch_is_equivalent(gpu):
     la, pa = run(False)
     lb, pb = run(True)
     assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0])  # same forward (the loss is a float-atomic sum over the samples)
-    # later steps: equal up to the float-atomic summation order of the weight gradients, which the bf16 forward
-    # amplifies step by step (two runs WITHOUT prefetch differ by the same amount)
-    assert np.allclose(la[:2], lb[:2], rtol=1e-5) and np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
+    # later steps: equal up to the float-atomic summation order of the weight gradients, which the first AdamW step
+    # (lr * g / (|g| + eps): a sign decision where g ~ 0) and the 16-bit forward amplify step by step -- two runs WITHOUT
+    # prefetch differ by the same amount.  (With bf16 storage the forward's coarser rounding hid it on step 2.)
+    assert np.allclose(la[:2], lb[:2], rtol=2e-4) and np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3

@@ -21,6 +21,7 @@ if os.environ.get("TCAVT_LIB") == "exp":  # tools/ only: the -DTCAVT_EXPERIMENTS
 ABI_VERSION = 2  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+EPI_NORM_OUT, EPI_ROWSCALE = 128, 256
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -50,6 +51,35 @@ class GemmArgs(ctypes.Structure):
         ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
         ("batch_w_group", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("silu_preact", c_void_p), ("ld_preact", c_int64),
+        ("norm_h16", c_void_p), ("norm_part", c_void_p), ("rowscale_part", c_void_p),
+        ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
+        ("reserved1", ctypes.c_int32),
+    ]
+
+
+class LlamaLayer(ctypes.Structure):
+    """Mirror of ``tcavt_llama_layer`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("w_qkv", "a_cat", "b_ext", "w_o", "w_gu", "w_d", "tape_h_mid", "tape_h_out",
+                                        "tape_qkv", "tape_gu", "tape_t")]
+
+
+class LlamaStackArgs(ctypes.Structure):
+    """Mirror of ``tcavt_llama_stack_args`` (include/tcavt.h)."""
+
+    _fields_ = [
+        ("layers", ctypes.POINTER(LlamaLayer)),
+        ("gamma_final", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
+        ("h", c_void_p), ("h16", c_void_p), ("part", c_void_p), ("kv_len", c_void_p),
+        ("qkv", c_void_p), ("att", c_void_p), ("act", c_void_p), ("t", c_void_p), ("xq", c_void_p), ("xv", c_void_p),
+        ("out_f32", c_void_p), ("out16", c_void_p),
+        ("k_cache", c_void_p), ("v_cache", c_void_p),
+        ("events", ctypes.POINTER(c_void_p)),
+        ("n_layers", ctypes.c_int32), ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("I", ctypes.c_int32), ("nq", ctypes.c_int32), ("nkv", ctypes.c_int32), ("dtype16", ctypes.c_int32),
+        ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32),
+        ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
+        ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
     ]
 
 
@@ -64,7 +94,7 @@ _SIGNATURES = {
     "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_cast_f32_16": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                         c_int, c_void_p, c_int, c_void_p],
+                         c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,
                            ctypes.c_uint32, c_void_p],
     "tcavt_dropout": [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p, c_void_p],
@@ -122,6 +152,11 @@ _SIGNATURES = {
     "tcavt_masked_mean_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                     c_int, c_float, c_void_p],
+    "tcavt_llama_stack_forward": [ctypes.POINTER(LlamaStackArgs), c_void_p],
+    "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
+    "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],
+    "tcavt_event_elapsed_ms": [c_void_p, c_void_p, ctypes.POINTER(c_float)],
     "tcavt_adamw_gated": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                           c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -186,19 +186,30 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
                                                          const float* __restrict__ vis_mod,
                                                          const float* __restrict__ txt_mod,
                                                          float* __restrict__ h, int B, int Nq, int Lt,
-                                                         int H, int V, int* bad_flag) {
+                                                         int H, int V, int* bad_flag, bf16_t* __restrict__ h16,
+                                                         float* __restrict__ part, int npart) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int L = Nq + Lt;
   if (row >= (long)B * L) return;
   const int b = (int)(row / L), i = (int)(row % L);
   float* out = h + row * H;
+  bf16_t* out16 = h16 ? h16 + row * H : nullptr;
+  float ss = 0.f;  // sum of squares of the row (first decoder layer's fused RMSNorm)
+  auto emit = [&](int c, const f32x4& o) {
+    *reinterpret_cast<f32x4*>(out + c) = o;
+    if (out16) *reinterpret_cast<u32x2*>(out16 + c) = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+    ss += o[0] * o[0];
+    ss += o[1] * o[1];
+    ss += o[2] * o[2];
+    ss += o[3] * o[3];
+  };
   if (i < Nq) {
     const float* src = img + ((long)b * Nq + i) * H;
     for (int c = lane * 4; c < H; c += 256) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(src + c);
       const f32x4 m = *reinterpret_cast<const f32x4*>(vis_mod + c);
-      *reinterpret_cast<f32x4*>(out + c) = a + m;
+      emit(c, a + m);
     }
   } else {
     int64_t id = ids[(long)b * Lt + (i - Nq)];
@@ -220,10 +231,35 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
       o1[1] = from16_hi<F16>(t[2]) + m1[1];
       o1[2] = from16_lo<F16>(t[3]) + m1[2];
       o1[3] = from16_hi<F16>(t[3]) + m1[3];
-      *reinterpret_cast<f32x4*>(out + c) = o0;
-      *reinterpret_cast<f32x4*>(out + c + 4) = o1;
+      emit(c, o0);
+      emit(c + 4, o1);
     }
   }
+  if (part) {
+    ss = wave_sum(ss);
+    for (int k = lane; k < npart; k += 64) part[row * npart + k] = k == 0 ? ss : 0.f;
+  }
+}
+
+// 16-bit copy + partial sums of squares of arbitrary fp32 rows: the inputs of a fused RMSNorm (TCAVT_EPI_ROWSCALE) when
+// the rows do not come from tcavt_embed_fuse or a TCAVT_EPI_NORM_OUT epilogue (inputs_embeds given by the caller).
+template <bool F16>
+__global__ __launch_bounds__(256) void rownorm_prep_kernel(const float* __restrict__ x, bf16_t* __restrict__ x16,
+                                                           float* __restrict__ part, long M, int H, int npart) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float ss = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * H + c);
+    *reinterpret_cast<u32x2*>(x16 + row * H + c) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+    ss += v[0] * v[0];
+    ss += v[1] * v[1];
+    ss += v[2] * v[2];
+    ss += v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  for (int k = lane; k < npart; k += 64) part[row * npart + k] = k == 0 ? ss : 0.f;
 }
 
 // Row softmax (one wave per row): P = softmax(S[:, :n_valid]), zero-padded to n_out columns.
@@ -433,19 +469,36 @@ extern "C" int tcavt_cast_f32_16(const float* x, void* out_bf16, int64_t n, int 
 
 extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                                 const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
-                                int Lt, int H, int V, int* bad_id_flag, int table_dtype, tcavt_stream_t stream) {
+                                int Lt, int H, int V, int* bad_id_flag, int table_dtype, void* h16, float* part,
+                                int npart, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && h && bad_id_flag, "embed_fuse: null pointer");
   TCAVT_CHECK_ARG(is16(table_dtype), "embed_fuse: table_dtype must be TCAVT_BF16 or TCAVT_F16");
+  TCAVT_CHECK_ARG((h16 == nullptr) == (part == nullptr) && (!part || npart > 0), "embed_fuse: h16 and part go together (npart > 0)");
   TCAVT_CHECK_ARG(B > 0 && Nq >= 0 && Lt >= 0 && Nq + Lt > 0 && H % 8 == 0 && V > 0, "embed_fuse: bad shape");
   const long rows = (long)B * (Nq + Lt);
   if (table_dtype == TCAVT_F16)
     hipLaunchKernelGGL(embed_fuse_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart);
   else
     hipLaunchKernelGGL(embed_fuse_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart);
   TCAVT_CHECK_LAUNCH("embed_fuse");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16,
+                                  tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x && x16 && part && M > 0 && H > 0 && H % 4 == 0 && npart > 0 && is16(dtype16), "rownorm_prep: bad args");
+  TCAVT_CHECK_ARG(aligned16(x) && aligned16(x16), "rownorm_prep: unaligned pointer");
+  const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  if (dtype16 == TCAVT_F16)
+    hipLaunchKernelGGL(rownorm_prep_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<bf16_t*>(x16), part, (long)M, H, npart);
+  else
+    hipLaunchKernelGGL(rownorm_prep_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<bf16_t*>(x16), part, (long)M, H, npart);
+  TCAVT_CHECK_LAUNCH("rownorm_prep");
   return TCAVT_OK;
 }

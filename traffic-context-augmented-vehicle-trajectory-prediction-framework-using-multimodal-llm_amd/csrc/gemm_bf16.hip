@@ -51,13 +51,35 @@ struct GemmP {
   DropoutP drop;  // epilogue dropout (generic epilogue only)
   int pers_tiles;  // > 0: persistent launch of the 4-wave kernel, workgroup w runs tiles w, w + gridDim.x, ... < pers_tiles
   int prio;  // wave-priority experiment: 0 none, 1 static s_setprio(1) for the upper half of the waves, 2 around MFMA clusters
+  // ---- RMSNorm fused into the GEMMs around it (TCAVT_EPI_NORM_OUT / TCAVT_EPI_ROWSCALE, include/tcavt.h)
+  bf16_t* norm_h16;       // NORM_OUT: 16-bit copy of the fp32 output rows (leading dimension ldc)
+  float* norm_part;       // NORM_OUT: [M][N / 64] sums of squares of the fp32 output, one per 64-column group
+  const float* rs_part;   // ROWSCALE: [M][rs_npart] sums of squares of the row the A operand was rounded from
+  int rs_npart;
+  float rs_eps, rs_inv_h;
 };
+
+// 1 / rms of row m from its partial sums of squares, added in index order (bit-reproducible; rs_npart % 4 == 0)
+__device__ __forceinline__ float row_rscale(const GemmP& p, long m) {
+  const f32x4* q = reinterpret_cast<const f32x4*>(p.rs_part + m * p.rs_npart);
+  float ss = 0.f;
+  for (int i = 0; i < (p.rs_npart >> 2); ++i) {
+    const f32x4 v = q[i];
+    ss += v[0];
+    ss += v[1];
+    ss += v[2];
+    ss += v[3];
+  }
+  return rsqrtf(ss * p.rs_inv_h + p.rs_eps);
+}
 
 // EPI_DROP = EPI_GENERIC + Philox dropout.  A separate instantiation: with the mask code inside the generic
 // epilogue the 256x256 kernel spilled its accumulators (528 B/lane of scratch, 3x slower).
 // EPI_SILU_SAVE = EPI_SILU + a bf16 copy of the gate|up pre-activations (LoRA-trainable variant: the backward of
 // silu(gate)*up needs them); its own instantiation so that the production SiLU kernel keeps its register allocation.
-enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4 };
+// EPI_NORM = TCAVT_EPI_NORM_OUT (fp32 residual output + 16-bit copy + per-row partial sums of squares): its own
+// instantiation as well -- inside EPI_GENERIC it pushed the 4-wave kernel's generic form into 460 bytes of scratch.
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4, EPI_NORM = 5 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -99,6 +121,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   // Fast paths for the forms the decoder launches (whole wave tile inside the matrix): row pointers hoisted,
   // no per-quad flag tests -- the general path below costs ~55 instructions per quad, these ~8.
   const bool whole = WHOLE_ONLY || (m_base + TM * 16 <= p.M && n_base + TN * 16 <= p.N);  // wave-uniform
+  if constexpr (EPI == EPI_NORM && TN % 4 == 0) {
+    // o_proj / down_proj of the decoder with the NEXT RMSNorm's input side fused in: besides the fp32 residual stream
+    // the epilogue leaves its 16-bit copy (the next projection's A operand; gamma is folded into that projection's
+    // weights) and, per 64-column group, the row's partial sum of squares -- the consumer adds the N / 64 partials in
+    // index order and applies rsqrt(mean + eps) as a row scale (TCAVT_EPI_ROWSCALE).  No float atomics anywhere.
+    {
+      const bool res = p.flags & TCAVT_EPI_RESIDUAL;
+      const int npart = p.N >> 6;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const long m = m_base + j * 16 + ml;
+        const bool rowok = WHOLE_ONLY || m < p.M;
+        const long mm = rowok ? m : 0;  // (rows beyond M read row 0 and store nothing: the shuffles below need every lane)
+        float* crow = reinterpret_cast<float*>(p.C) + mm * p.ldc + n_base + nq;
+        bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
+        const float* rrow = res ? p.residual + mm * p.ldr + n_base + nq : nullptr;
+#pragma unroll
+        for (int g = 0; g < TN / 4; ++g) {
+          const bool colok = WHOLE_ONLY || n_base + g * 64 < p.N;  // (N % 64 == 0: a group is inside or outside)
+          float ss = 0.f;
+#pragma unroll
+          for (int i = g * 4; i < g * 4 + 4; ++i) {
+            f32x4 v = acc[i][j];
+            if (res && colok) v += *reinterpret_cast<const f32x4*>(rrow + i * 16);
+            if (rowok && colok) {
+              *reinterpret_cast<f32x4*>(crow + i * 16) = v;
+              *reinterpret_cast<u32x2*>(hrow + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+            }
+            ss += v[0] * v[0];
+            ss += v[1] * v[1];
+            ss += v[2] * v[2];
+            ss += v[3] * v[3];
+          }
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          if (lane < 16 && rowok && colok) p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+        }
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_GENERIC) {
     if (whole && p.acc_scale == 1.f && p.out_kind == TCAVT_F32 && p.flags == TCAVT_EPI_RESIDUAL) {
 #pragma unroll
@@ -132,9 +195,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       for (int j = 0; j < TM; ++j) {
         const long m = m_base + j * 16 + ml;
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + (n_base >> 1) + nq;
+        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
         for (int i = 0; i < TN; i += 2) {
-          const f32x4 g = acc[i][j], u = acc[i + 1][j];
+          const f32x4 g = acc[i][j] * rs, u = acc[i + 1][j] * rs;
           if constexpr (EPI == EPI_SILU_SAVE) {
             bf16_t* arow = p.aux + m * p.ldaux + n_base + i * 16 + nq;
             *reinterpret_cast<u32x2*>(arow) = u32x2{pack16x2<F16>(g[0], g[1]), pack16x2<F16>(g[2], g[3])};
@@ -157,6 +221,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         const float* crp = p.cosT + pos * 32 + nq;
         const float* srp = p.sinT + pos * 32 + nq;
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base + nq;
+        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
         for (int hh = 0; hh < TN / 4; ++hh) {
           const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
@@ -165,7 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           if (rot) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
+              const f32x4 lo = acc[hh * 4 + i][j] * rs, hi = acc[hh * 4 + i + 2][j] * rs;
               const f32x4 c = *reinterpret_cast<const f32x4*>(crp + i * 16);
               const f32x4 s = *reinterpret_cast<const f32x4*>(srp + i * 16);
               const f32x4 l2 = lo * c - hi * s;
@@ -176,7 +241,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const f32x4 v = acc[hh * 4 + i][j];
+              const f32x4 v = acc[hh * 4 + i][j] * rs;
               *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
             }
           }
@@ -187,6 +252,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   }
   if constexpr (WHOLE_ONLY && EPI == EPI_ROPE) {
     return;  // the 4-wave kernel is dispatched for bf16 output only on this epilogue (launch_w4 checks)
+  }
+  if constexpr (EPI == EPI_NORM) {
+    return;  // (TN % 4 != 0: the 64x64 form, never dispatched for this epilogue)
   }
   if constexpr (EPI == EPI_GENERIC || EPI == EPI_DROP) {
 #pragma unroll
@@ -226,7 +294,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       for (int i = 0; i < TN; i += 2) {
         if (n_base + i * 16 >= p.N) continue;  // partial last tile column
         const int n = ((n_base) >> 1) + (i >> 1) * 16 + nq;
-        const f32x4 g = acc[i][j], u = acc[i + 1][j];
+        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;
+        const f32x4 g = acc[i][j] * rs, u = acc[i + 1][j] * rs;
         if constexpr (EPI == EPI_SILU_SAVE) {
           bf16_t* arow = p.aux + (long)m * p.ldaux + n_base + i * 16 + nq;
           *reinterpret_cast<u32x2*>(arow) = u32x2{pack16x2<F16>(g[0], g[1]), pack16x2<F16>(g[2], g[3])};
@@ -252,7 +321,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int d = i * 16 + nq;
-          f32x4 lo = acc[hh * 4 + i][j], hi = acc[hh * 4 + i + 2][j];
+          const float rs = p.rs_part ? row_rscale(p, m) : 1.f;
+          f32x4 lo = acc[hh * 4 + i][j] * rs, hi = acc[hh * 4 + i + 2][j] * rs;
           if (rot) {
             const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
             const f32x4 s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
@@ -1096,9 +1166,10 @@ static int launch_small(const GemmP& p, int tile, int batch, hipStream_t stream)
   const long wgs = (long)((q.M + 127) / 128) * ((q.N + 127) / 128) * batch;
   static const bool no_deep = getenv("TCAVT_GEMM_NO_DEEP") != nullptr;  // A/B switches
   static const bool no_64 = getenv("TCAVT_GEMM_NO_64") != nullptr;
-  if constexpr (EPI != EPI_ROPE) {
+  if constexpr (EPI != EPI_ROPE && EPI != EPI_NORM) {
     // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
     // each K-tile costing a quarter of the DMA issue and MFMA time
+    // (not for EPI_NORM: the 64x64 form's waves cover 32 columns, no whole 64-column group)
     if ((tile == 64 || (tile == 0 && wgs <= 128 && !no_64)) && !no_deep) return launch<64, 64, 2, 2, EPI, F16, 2>(q, batch, stream);
   }
   if (wgs <= 256 && !no_deep) return launch<128, 128, 2, 2, EPI, F16, 2>(q, batch, stream);
@@ -1224,16 +1295,18 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                     "gemm_bf16: bad lda2/ldw2/alignment");
     K2 = a->K2;
   }
-  const int epi = a->epilogue;
+  int epi = a->epilogue;
   if (epi & TCAVT_EPI_BIAS) TCAVT_CHECK_ARG(a->bias && aligned16(a->bias), "gemm_bf16: BIAS needs an aligned bias pointer");
   if (epi & TCAVT_EPI_BIAS_ROW) TCAVT_CHECK_ARG(a->bias && !(epi & TCAVT_EPI_BIAS), "gemm_bf16: BIAS_ROW needs bias and excludes BIAS");
   if (epi & TCAVT_EPI_RESIDUAL)
     TCAVT_CHECK_ARG(a->residual && aligned16(a->residual) && a->ldr >= a->N && a->ldr % 4 == 0,
                     "gemm_bf16: RESIDUAL needs residual pointer and ldr >= N");
   if (epi & TCAVT_EPI_SILU_MUL)
-    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~TCAVT_EPI_SILU_MUL), "gemm_bf16: SILU_MUL needs N %% 128 == 0 and no other flag");
+    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~(TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE)),
+                    "gemm_bf16: SILU_MUL needs N %% 128 == 0 and no other flag but ROWSCALE");
   if (epi & TCAVT_EPI_ROPE) {
-    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~TCAVT_EPI_ROPE), "gemm_bf16: ROPE needs N %% 128 == 0 and no other flag");
+    TCAVT_CHECK_ARG(a->N % 128 == 0 && !(epi & ~(TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE)),
+                    "gemm_bf16: ROPE needs N %% 128 == 0 and no other flag but ROWSCALE");
     TCAVT_CHECK_ARG(a->rope_cos && a->rope_sin && a->rope_L > 0 && a->rope_cols % 64 == 0 &&
                         aligned16(a->rope_cos) && aligned16(a->rope_sin),
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
@@ -1269,6 +1342,29 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.prio = 0;
   p.pers_tiles = 0;
   p.xcd_gx = 8;
+  p.norm_h16 = nullptr;
+  p.norm_part = nullptr;
+  p.rs_part = nullptr;
+  p.rs_npart = 0;
+  p.rs_eps = p.rs_inv_h = 0.f;
+  if (epi & TCAVT_EPI_NORM_OUT) {
+    TCAVT_CHECK_ARG(!(epi & ~(TCAVT_EPI_NORM_OUT | TCAVT_EPI_RESIDUAL)) && a->out_dtype == TCAVT_F32 && batch == 1 && K2 == 0 &&
+                        a->N % 64 == 0 && a->norm_h16 && a->norm_part && aligned16(a->norm_h16) && a->dropout_p == 0.f &&
+                        (a->acc_scale == 0.f || a->acc_scale == 1.f) && a->tile != 64,
+                    "gemm_bf16: NORM_OUT goes with an fp32 output (+ RESIDUAL) only, N %% 64 == 0, and needs norm_h16 / norm_part");
+    p.norm_h16 = static_cast<bf16_t*>(a->norm_h16);
+    p.norm_part = a->norm_part;
+  }
+  if (epi & TCAVT_EPI_ROWSCALE) {
+    TCAVT_CHECK_ARG((epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)) && a->rowscale_part && aligned16(a->rowscale_part) &&
+                        a->rowscale_npart > 0 && a->rowscale_npart % 4 == 0 && a->rowscale_h > 0,
+                    "gemm_bf16: ROWSCALE goes with the ROPE / SILU_MUL epilogues and needs rowscale_part, npart %% 4 == 0, h > 0");
+    p.rs_part = a->rowscale_part;
+    p.rs_npart = a->rowscale_npart;
+    p.rs_eps = a->rowscale_eps;
+    p.rs_inv_h = 1.f / (float)a->rowscale_h;
+  }
+  epi &= ~TCAVT_EPI_ROWSCALE;  // (carried by p.rs_part from here on)
   TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "gemm_bf16: dropout_p must be in [0, 1)");
   if (a->dropout_p > 0.f)
     TCAVT_CHECK_ARG(!(epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)) && batch == 1 && a->N % 4 == 0,
@@ -1313,6 +1409,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     return f16 ? dispatch_tile<EPI_SILU, true>(p, tile, 1, s) : dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
   }
   if (epi & TCAVT_EPI_ROPE) return f16 ? dispatch_tile<EPI_ROPE, true>(p, tile, 1, s) : dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
+  if (epi & TCAVT_EPI_NORM_OUT) return f16 ? dispatch_tile<EPI_NORM, true>(p, tile, 1, s) : dispatch_tile<EPI_NORM, false>(p, tile, 1, s);
   if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
     const int t = a->tile == 64 || a->tile == 128 ? a->tile : 0;
     return f16 ? launch_small<EPI_DROP, true>(p, t, 1, s) : launch_small<EPI_DROP, false>(p, t, 1, s);

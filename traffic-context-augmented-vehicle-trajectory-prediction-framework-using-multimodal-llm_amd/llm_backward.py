@@ -149,6 +149,7 @@ class LoraBackward:
         xn = self._buf("xn", (M, H))
         xl = self._buf("xl", (M, H))
         xl2 = self._buf("xl2", (M, H))
+        t_re = self._buf("t_re", (M, 64), zero=True)
         g_xl2 = self._buf("g_xl2", (M, H))
         g_xn = self._buf("g_xn", (M, H))
         g_xl = self._buf("g_xl", (M, H))
@@ -186,15 +187,20 @@ class LoraBackward:
             ops.gemm_bf16(g_qkv, dT.b_ext, out=g_t, acc_scale=s)
 
             def adapter_grads(li=li, d=d, sv=sv, g_qkv=g_qkv, g_t=g_t):
-                self._wgrad("dB", g_qkv, sv.t, dB)
-                if sv.dspec is not None:  # the adapter branches' inputs, recomputed with the forward's two masks
+                # the adapter branches' inputs and down-projections in the un-fused form the backward walks (the forward
+                # kept only the un-normalised t of its fused RMSNorm): xn = rmsnorm(h_in), t = s * dropout(xn) A^T
+                if sv.dspec is not None:  # ... with the forward's two masks
                     ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
                     ops.dropout(xn, xl2, *sv.dspec[1])
+                    ops.gemm_bf16(xl, dT.a_plain[:LORA_V], out=t_re[:, :LORA_V], acc_scale=s, tile=128)
+                    ops.gemm_bf16(xl2, dT.a_plain[LORA_V:2 * LORA_V], out=t_re[:, LORA_V:2 * LORA_V], acc_scale=s, tile=128)
                     self._wgrad("dAq", g_t[:, :LORA_V], xl, dA[:LORA_V])
                     self._wgrad("dAv", g_t[:, LORA_V:2 * LORA_V], xl2, dA[LORA_V:2 * LORA_V])
                 else:
                     ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
+                    ops.gemm_bf16(xn, dT.a_plain, out=t_re, acc_scale=s, tile=128)
                     self._wgrad("dA", g_t, xn, dA)
+                self._wgrad("dB", g_qkv, t_re, dB)
                 p = f"{pre}{li}.self_attn."
                 G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
                 G[p + "v_proj.lora_A.weight"].copy_(dA[LORA_V:LORA_V + r])

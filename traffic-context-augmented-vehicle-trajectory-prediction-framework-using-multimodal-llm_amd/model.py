@@ -452,7 +452,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self.config = self.llama_model.config
         self.hidden_size = self.shape.hidden
         self.gemm_tile = 0
-        self.timer = None  # optional profiling.KernelTimer (bench.py roofline leg)
+        self.timer = None  # optional ops.StackEvents: in-situ timing of the five big kernels of every layer (bench.py roofline leg)
         self.dctx = None   # DropoutCtx of the current forward (LoRA dropout on the adapter branch input)
         self._ws = _Workspace()
         self._prep = None
@@ -465,17 +465,27 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
 
     # ---- packed device-side weights -------------------------------------------------
     def _prepare(self):
+        """16-bit packed copies for tcavt_llama_stack_forward.  The RMSNorm gains are FOLDED into the projections that
+        follow them (fused RMSNorm: (x rs gamma) W^T == rs (x (W gamma)^T), csrc/stack.hip): W_qkv and the LoRA A
+        matrices carry input_layernorm.weight, W_gateup carries post_attention_layernorm.weight; the product W * gamma
+        is formed in fp32 and rounded once."""
+        import ctypes
+
+        from . import capi
+
         ll = self.shape
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         layers = []
-        rnd = lambda t: t.detach().contiguous()  # RMSNorm gains stay fp32 (rounding them cost 1.1e-3 on decoded, error budget)
-        _bf16 = lambda t: _to16(t, self.storage)
+        to16 = lambda t: _to16(t, self.storage)
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
         nL = len(self.llama_model.model.layers)
-        a_all = b_all = None
+        a_all = b_all = g1_all = None
+        carr = (capi.LlamaLayer * nL)()
         for li, lyr in enumerate(self.llama_model.model.layers):
             a = lyr.self_attn
             d = SimpleNamespace()
-            d.w_qkv = _bf16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0))
+            d.g1, d.g2 = f32(lyr.input_layernorm.weight), f32(lyr.post_attention_layernorm.weight)
+            d.w_qkv = to16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).detach() * d.g1[None, :])
             if self.use_lora:
                 r = self.lora_r
                 if r > LORA_V:
@@ -486,54 +496,86 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                     # parameter vector): refresh_lora() then re-packs every layer with a handful of strided copies
                     a_all = torch.zeros(nL, 64, H, dtype=self.storage, device=d.w_qkv.device)
                     b_all = torch.zeros(nL, (nq + 2 * nkv) * hd, 64, dtype=self.storage, device=d.w_qkv.device)
+                    g1_all = torch.empty(nL, 1, H, dtype=torch.float32, device=d.w_qkv.device)
                 d.a_cat, d.b_ext = a_all[nL - 1 - li], b_all[nL - 1 - li]
-                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
-                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
+                g1_all[nL - 1 - li, 0].copy_(d.g1)
+                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
+                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
                 d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
-            d.w_o = _bf16(a.o_proj.weight)
-            d.w_gu = _bf16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()))
-            d.w_d = _bf16(lyr.mlp.down_proj.weight)
-            d.g1, d.g2 = rnd(lyr.input_layernorm.weight), rnd(lyr.post_attention_layernorm.weight)
+            d.w_o = to16(a.o_proj.weight)
+            d.w_gu = to16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()) * d.g2[None, :])
+            d.w_d = to16(lyr.mlp.down_proj.weight)
+            c = carr[li]
+            c.w_qkv, c.w_o, c.w_gu, c.w_d = d.w_qkv.data_ptr(), d.w_o.data_ptr(), d.w_gu.data_ptr(), d.w_d.data_ptr()
+            if self.use_lora:
+                c.a_cat, c.b_ext = d.a_cat.data_ptr(), d.b_ext.data_ptr()
             layers.append(d)
-        return SimpleNamespace(layers=layers, g_final=rnd(self.llama_model.model.norm.weight),
-                               table=_bf16(self.llama_model.model.embed_tokens.weight), a_all=a_all, b_all=b_all)
+        return SimpleNamespace(layers=layers, g_final=f32(self.llama_model.model.norm.weight), carr=carr,
+                               table=to16(self.llama_model.model.embed_tokens.weight), a_all=a_all, b_all=b_all,
+                               g1_all=g1_all)
 
     def prepared_T(self):
-        """Transposed bf16 copies of the frozen weights: the `w` operands of the backward's dgrad GEMMs
-        (g_in = g_out . W  ==  gemm_bf16(g_out, W^T stored [K_in, N_out])).  Built once; refresh_lora() keeps the
+        """Transposed 16-bit copies of the frozen weights: the `w` operands of the backward's dgrad GEMMs
+        (g_in = g_out . W  ==  gemm_bf16(g_out, W^T stored [K_in, N_out])).  PLAIN weights, without the folded gains: the
+        backward walks the un-fused graph (RMSNorm backward is its own kernel).  Built once; refresh_lora() keeps the
         adapter entries current."""
         if self._prep_T is None:
             P = self._prepared()
-            tr = lambda w: w.t().contiguous()
+            ll = self.shape
+            nq, nkv, hd, r = ll.n_q_heads, ll.n_kv_heads, ll.head_dim, self.lora_r
+            to16 = lambda t: _to16(t, self.storage)
+            tr = lambda w: to16(w.detach()).t().contiguous()
             nL = len(P.layers)
-            at_all = P.a_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), H, 64]
-            bt_all = P.b_all.transpose(1, 2).contiguous() if self.use_lora else None  # [layers (last first), 64, nqkv]
-            # with LoRA dropout on, the two adapters' input gradients carry different masks: A_q^T and A_v^T alone
-            # (the other adapter's columns zeroed), each the W operand of its own K = 64 product
-            atq_all = atv_all = None
+            at_all = bt_all = atq_all = atv_all = ap_all = None
             if self.use_lora:
-                atq_all, atv_all = at_all.clone(), at_all.clone()
-                atq_all[:, :, LORA_V:] = 0
-                atv_all[:, :, :LORA_V] = 0
-            self._prep_T = [SimpleNamespace(w_qkv=tr(d.w_qkv), w_o=tr(d.w_o), w_gu=tr(d.w_gu), w_d=tr(d.w_d),
-                                            a_cat=at_all[nL - 1 - li] if self.use_lora else None,
-                                            a_q=atq_all[nL - 1 - li] if self.use_lora else None,
-                                            a_v=atv_all[nL - 1 - li] if self.use_lora else None,
-                                            b_ext=bt_all[nL - 1 - li] if self.use_lora else None)
-                            for li, d in enumerate(P.layers)]
-            self._prep_T_all = (at_all, bt_all, atq_all, atv_all)
+                dev = P.a_all.device
+                at_all = torch.zeros(nL, ll.hidden, 64, dtype=self.storage, device=dev)  # [layers (last first), H, 64]
+                ap_all = torch.zeros(nL, 64, ll.hidden, dtype=self.storage, device=dev)  # plain a_cat (no folded gain)
+                bt_all = P.b_all.transpose(1, 2).contiguous()                             # [layers (last first), 64, nqkv]
+                # with LoRA dropout on, the two adapters' input gradients carry different masks: A_q^T and A_v^T alone
+                # (the other adapter's columns zeroed), each the W operand of its own K = 64 product
+                atq_all, atv_all = torch.zeros_like(at_all), torch.zeros_like(at_all)
+            out = []
+            for li, (d, lyr) in enumerate(zip(P.layers, self.llama_model.model.layers)):
+                a = lyr.self_attn
+                e = SimpleNamespace(w_qkv=tr(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)),
+                                    w_o=tr(a.o_proj.weight), w_d=tr(lyr.mlp.down_proj.weight),
+                                    w_gu=tr(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach())),
+                                    a_cat=None, a_q=None, a_v=None, b_ext=None, a_plain=None)
+                if self.use_lora:
+                    k = nL - 1 - li
+                    e.a_cat, e.a_q, e.a_v, e.b_ext, e.a_plain = at_all[k], atq_all[k], atv_all[k], bt_all[k], ap_all[k]
+                out.append(e)
+            self._prep_T = out
+            self._prep_T_all = (at_all, bt_all, atq_all, atv_all, ap_all)
+            if self.use_lora:
+                self._refresh_lora_T()
         return self._prep_T
+
+    def _refresh_lora_T(self):
+        """The backward's adapter operands from the current parameters: plain A^T (no folded gain) and B^T."""
+        at_all, bt_all, atq_all, atv_all, ap_all = self._prep_T_all
+        P, r, nL = self._prepared(), self.lora_r, len(self._prepared().layers)
+        for li, lyr in enumerate(self.llama_model.model.layers):
+            a, k = lyr.self_attn, nL - 1 - li
+            ap_all[k, :r].copy_(a.q_proj.lora_A.weight.detach())
+            ap_all[k, LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
+        at_all.copy_(ap_all.transpose(1, 2))
+        atq_all[:, :, :LORA_V].copy_(at_all[:, :, :LORA_V])
+        atv_all[:, :, LORA_V:].copy_(at_all[:, :, LORA_V:])
+        bt_all.copy_(P.b_all.transpose(1, 2))
 
     def _invalidate(self):
         self._prep_T = None
         _Prepared._invalidate(self)
 
     def refresh_lora(self, stacked=None):
-        """Re-pack the adapter matrices (a_cat, b_ext and their transposes) from the lora_A / lora_B parameters after
-        an optimizer step; the frozen base weights are left alone.  stacked = (A_q, B_q, A_v, B_v): views of ALL layers'
-        parameters, last layer first ([layers, r, H] / [layers, out, r]; training.Trainer builds them over its flat
-        parameter vector) -- then the whole re-pack is six strided copies instead of six per layer."""
+        """Re-pack the adapter matrices (a_cat with the folded gain, b_ext, and the backward's transposes) from the
+        lora_A / lora_B parameters after an optimizer step; the frozen base weights are left alone.  stacked = (A_q,
+        B_q, A_v, B_v): views of ALL layers' parameters, last layer first ([layers, r, H] / [layers, out, r];
+        training.Trainer builds them over its flat parameter vector) -- then the forward's re-pack is four strided
+        copies instead of four per layer."""
         if not self.use_lora or self._prep is None:
             return
         ll, r = self.shape, self.lora_r
@@ -541,23 +583,19 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         P = self._prepared()
         if stacked is not None:
             aq, bq, av, bv = stacked
-            P.a_all[:, :r].copy_(aq)
-            P.a_all[:, LORA_V:LORA_V + r].copy_(av)
+            P.a_all[:, :r].copy_(aq * P.g1_all)
+            P.a_all[:, LORA_V:LORA_V + r].copy_(av * P.g1_all)
             P.b_all[:, : nq * hd, :r].copy_(bq)
             P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv)
         else:
             for li, lyr in enumerate(self.llama_model.model.layers):
                 a, d = lyr.self_attn, P.layers[li]
-                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach())
-                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
+                d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
+                d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
                 d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
         if self._prep_T is not None:
-            at_all, bt_all, atq_all, atv_all = self._prep_T_all
-            at_all.copy_(P.a_all.transpose(1, 2))
-            bt_all.copy_(P.b_all.transpose(1, 2))
-            atq_all[:, :, :LORA_V].copy_(at_all[:, :, :LORA_V])
-            atv_all[:, :, LORA_V:].copy_(at_all[:, :, LORA_V:])
+            self._refresh_lora_T()
 
     def _rope_tables(self, L, dev):
         key = (L, str(dev))
@@ -567,37 +605,47 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         return self._rope[key]
 
     # ---- the hot loop -------------------------------------------------------------------
-    def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None):
-        """h: fp32 [B*L, H] residual stream (updated in place); kv_len int32 [B]."""
+    def norm_inputs(self, M, dev):
+        """(h16, part): the 16-bit copy of the residual stream and its rows' partial sums of squares [M, H / 64] -- what
+        the fused RMSNorms read (written by tcavt_embed_fuse / ops.rownorm_prep for layer 0, by the residual epilogues
+        afterwards)."""
+        H = self.shape.hidden
+        return (self._ws.get("ll.h16", (M, H), self.storage, dev), self._ws.get("ll.part", (M, H // 64), torch.float32, dev))
+
+    def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None, kv_cache=None):
+        """h: fp32 [B*L, H] residual stream (updated in place unless a tape is kept); its norm_inputs() must have been
+        filled; kv_len int32 [B].  One C call: tcavt_llama_stack_forward (csrc/stack.hip).  kv_cache = (k, v, lmax):
+        16-bit [layers, B, lmax, nkv*64] tensors that receive the rotated keys / values (generation prefill)."""
+        from . import capi
+
         ll, P, ws = self.shape, self._prepared(), self._ws
         dev, M, H = h.device, B * L, ll.hidden
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         nqkv = (nq + 2 * nkv) * hd
+        if hd != 64:
+            raise ValueError("the decoder kernels are built for head_dim 64")
         cos, sin = self._rope_tables(L, dev)
-        xn = ws.get("ll.xn", (M, H), self.storage, dev)
-        qkv = ws.get("ll.qkv", (M, nqkv), self.storage, dev)
+        h16, part = self.norm_inputs(M, dev)
         att = ws.get("ll.att", (M, nq * hd), self.storage, dev)
         act = ws.get("ll.act", (M, ll.inter), self.storage, dev)
-        t = ws.get("ll.lora_t", (M, 64), self.storage, dev, zero=True) if self.use_lora else None
-        scale = 1.0 / math.sqrt(hd)
-        tile = self.gemm_tile
-        tm = self.timer
-        mark = (lambda n: tm.start(n)) if tm else (lambda n: None)
-        done = (lambda n: tm.stop(n)) if tm else (lambda n: None)
+        args = capi.LlamaStackArgs()
+        keep = [cos, sin, h16, part, att, act, h, kv_len, out_f32, out_bf16]  # (tensors named by raw pointers below)
+        dq = _spec(self.dctx, self.lora_dropout) if self.use_lora else None
+        for _ in range(2 * ll.layers - 1 if dq is not None else 0):  # two sites per layer, numbered in layer order
+            _spec(self.dctx, self.lora_dropout)
         tape = None
+        carr = P.carr
         if self.save_for_backward:
             tape = self.tape = SimpleNamespace(layers=[], kv_len=kv_len, B=B, L=L, h_last=None)
-        for li, d in enumerate(P.layers):
-            # PEFT: lora_B(lora_A(dropout(x))) with one dropout module per adapted Linear -> two sites per layer, q_proj
-            # then v_proj (the order modeling_llama.py:254-256 calls them in); the base projection sees x itself
-            dspec = None
-            if self.use_lora:
-                dq, dv = _spec(self.dctx, self.lora_dropout), _spec(self.dctx, self.lora_dropout)
-                dspec = (dq, dv) if dq is not None else None
-            if tape is not None:
+            carr = (capi.LlamaLayer * ll.layers)()
+            h_in = h
+            for li, d in enumerate(P.layers):
                 # per-layer buffers instead of the shared ones: the residual stream is written to a new buffer by each
                 # residual epilogue (no copies), q|k|v and the LoRA down-projection stay where the backward finds them
-                sv = SimpleNamespace(h_in=h, dspec=dspec,
+                dspec = None
+                if dq is not None:
+                    dspec = ((dq[0], dq[1], dq[2] + 2 * li), (dq[0], dq[1], dq[2] + 2 * li + 1))
+                sv = SimpleNamespace(h_in=h_in, dspec=dspec,
                                      h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
                                      h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
                                      qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), self.storage, dev, zero=True),
@@ -605,46 +653,61 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                                      t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev, zero=True) if self.use_lora else None)
                 sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
-                qkv, t, h_mid, h_out = sv.qkv, sv.t, sv.h_mid, sv.h_out
-            else:
-                h_mid = h_out = h
-            sc = self.lora_alpha / self.lora_r
-            if dspec is not None:
+                c, src = carr[li], P.carr[li]
+                for f in ("w_qkv", "a_cat", "b_ext", "w_o", "w_gu", "w_d"):
+                    setattr(c, f, getattr(src, f))
+                c.tape_h_mid, c.tape_h_out = sv.h_mid.data_ptr(), sv.h_out.data_ptr()
+                c.tape_qkv, c.tape_gu = sv.qkv_padded.data_ptr(), sv.gu.data_ptr()
+                if self.use_lora:
+                    c.tape_t = sv.t.data_ptr()
+                h_in = sv.h_out
+            tape.h_last = h_in
+        else:
+            qkv = ws.get("ll.qkv", (M, nqkv), self.storage, dev)
+            args.qkv = qkv.data_ptr()
+            keep.append(qkv)
+        if self.use_lora:
+            t = ws.get("ll.lora_t", (M, 64), self.storage, dev, zero=True)
+            args.t = t.data_ptr()
+            keep.append(t)
+            if dq is not None:
                 xq = ws.get("ll.xn_drop", (M, H), self.storage, dev)
                 xv = ws.get("ll.xn_drop2", (M, H), self.storage, dev)
-                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn, out_drop=xq, dropout=dspec[0])  # both from one pass over h
-                ops.dropout(xn, xv, *dspec[1])
-                ops.gemm_bf16(xq, d.a_cat[:LORA_V], out=t[:, :LORA_V], acc_scale=sc, tile=128)
-                ops.gemm_bf16(xv, d.a_cat[LORA_V:2 * LORA_V], out=t[:, LORA_V:2 * LORA_V], acc_scale=sc, tile=128)
-            else:
-                ops.rmsnorm(h, d.g1, ll.rms_eps, out_bf16=xn)
-                if self.use_lora:
-                    ops.gemm_bf16(xn, d.a_cat, out=t, acc_scale=sc, tile=128)
-            if self.use_lora:
-                mark("qkv")
-                ops.gemm_bf16(xn, d.w_qkv, out=qkv, a2=t, w2=d.b_ext, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
-                done("qkv")
-            else:
-                mark("qkv")
-                ops.gemm_bf16(xn, d.w_qkv, out=qkv, rope=(cos, sin, (nq + nkv) * hd), tile=tile)
-                done("qkv")
-            mark("attn")
-            ops.attn_causal_gqa(qkv, att, kv_len, B, L, nq, nkv, scale)
-            done("attn")
-            mark("o")
-            ops.gemm_bf16(att, d.w_o, out=h_mid, residual=h, tile=tile)
-            done("o")
-            ops.rmsnorm(h_mid, d.g2, ll.rms_eps, out_bf16=xn)
-            mark("gateup")
-            ops.gemm_bf16(xn, d.w_gu, out=act, silu_mul=True, tile=tile, silu_preact=sv.gu if tape is not None else None)
-            done("gateup")
-            mark("down")
-            ops.gemm_bf16(act, d.w_d, out=h_out, residual=h_mid, tile=tile)
-            done("down")
-            h = h_out
-        if tape is not None:
-            tape.h_last = h
-        ops.rmsnorm(h, P.g_final, ll.rms_eps, out_bf16=out_bf16, out_f32=out_f32)
+                args.xq, args.xv = xq.data_ptr(), xv.data_ptr()
+                args.lora_dropout_p, args.dropout_seed, args.lora_first_site = dq[0], dq[1] & 0xFFFFFFFFFFFFFFFF, dq[2]
+                keep += [xq, xv]
+        args.layers = carr
+        args.gamma_final, args.rope_cos, args.rope_sin = P.g_final.data_ptr(), cos.data_ptr(), sin.data_ptr()
+        args.h, args.h16, args.part, args.kv_len = h.data_ptr(), h16.data_ptr(), part.data_ptr(), kv_len.data_ptr()
+        args.att, args.act = att.data_ptr(), act.data_ptr()
+        for t_, nm, n_ in ((out_f32, "out_f32", M * H), (out_bf16, "out_bf16", M * H), (kv_len, "kv_len", B), (h, "h", M * H)):
+            if t_ is not None and t_.numel() < n_:
+                raise capi.TcavtError(f"decoder_stack.{nm}: buffer has {t_.numel()} elements, the stack needs {n_}")
+        if out_f32 is not None:
+            if out_f32.dtype != torch.float32:
+                raise capi.TcavtError("decoder_stack.out_f32: fp32 required")
+            args.out_f32 = out_f32.data_ptr()
+        if out_bf16 is not None:
+            if out_bf16.dtype != self.storage:
+                raise capi.TcavtError(f"decoder_stack.out_bf16: {self.storage} required")
+            args.out16 = out_bf16.data_ptr()
+        if h.dtype != torch.float32 or kv_len.dtype != torch.int32:
+            raise capi.TcavtError("decoder_stack: h fp32 and kv_len int32 required")
+        if kv_cache is not None:
+            kc, vc, lmax = kv_cache
+            need = ll.layers * B * lmax * nkv * hd
+            if kc.dtype != self.storage or vc.dtype != self.storage or kc.numel() < need or vc.numel() < need or lmax < L:
+                raise capi.TcavtError("decoder_stack.kv_cache: two 16-bit [layers, B, lmax, nkv*64] tensors with lmax >= L required")
+            args.k_cache, args.v_cache, args.kv_lmax = kc.data_ptr(), vc.data_ptr(), lmax
+        if self.timer is not None:
+            args.events = self.timer.arr
+        args.n_layers, args.B, args.L, args.H, args.I = ll.layers, B, L, H, ll.inter
+        args.nq, args.nkv, args.dtype16 = nq, nkv, capi.F16 if self.storage == torch.float16 else capi.BF16
+        args.gemm_tile = self.gemm_tile
+        args.rms_eps = ll.rms_eps
+        args.lora_scale = (self.lora_alpha / self.lora_r) if self.use_lora else 0.0
+        ops.llama_stack_forward(args)
+        del keep
 
     def forward(self, inputs_embeds, attention_mask, labels=None, output_hidden_states=False):
         """HF-call-shaped entry (train.py:445-453).  Only ``hidden_states[-1]`` is produced."""
@@ -652,6 +715,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         dev = inputs_embeds.device
         h = self._ws.get("ll.h", (B * L, H), torch.float32, dev)
         h.copy_(inputs_embeds.reshape(B * L, H))
+        ops.rownorm_prep(h, *self.norm_inputs(B * L, dev))
         kv_len = torch.empty(B, dtype=torch.int32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), 0, kv_len, flag)
@@ -758,7 +822,8 @@ class LlamaMultiModal(nn.Module, _Prepared):
         # error flags: the kernels only ever SET them, so they accumulate over forwards until check_flags() reads and
         # clears them (evaluate_model and Trainer.check_flags do; one host sync, off the hot path)
         flags = ws.get("mm.flags", (2,), torch.int32, dev, zero=True)
-        ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1])
+        h16, part = LW.norm_inputs(B * L, dev)
+        ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part)
         if dev.type == "cuda" and self._pf_stream is not None:
             self._img_consumed = torch.cuda.Event()
             self._img_consumed.record()

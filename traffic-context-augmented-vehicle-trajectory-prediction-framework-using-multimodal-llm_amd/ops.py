@@ -260,7 +260,9 @@ def cast_bf16(x, out=None):
     return cast16(x, out, torch.bfloat16)
 
 
-def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag):
+def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=None):
+    """h16 / part (both or neither): the 16-bit copy of h and its rows' partial sums of squares [rows, H / 64] -- the
+    inputs of the first decoder layer's fused RMSNorm (tcavt_llama_stack_forward)."""
     _req16(table, "embed.table")
     _req(ids, torch.int64, "embed.ids")
     _req(img, torch.float32, "embed.img")
@@ -272,8 +274,18 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag):
     _need(vis_mod, H, "embed.vis_mod")
     _need(txt_mod, H, "embed.txt_mod")
     _need(bad_flag, 1, "embed.bad_flag")
+    npart = 0
+    if (h16 is None) != (part is None):
+        raise capi.TcavtError("embed.h16 and embed.part go together")
+    if h16 is not None:
+        _req16(h16, "embed.h16", like=table)
+        _req(part, torch.float32, "embed.part")
+        npart = H // 64
+        _need(h16, B * (Nq + Lt) * H, "embed.h16")
+        _need(part, B * (Nq + Lt) * npart, "embed.part")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
-                                 V, ptr(bad_flag), _DT[table.dtype], stream_ptr()), "tcavt_embed_fuse")
+                                 V, ptr(bad_flag), _DT[table.dtype], ptr(h16), ptr(part), npart, stream_ptr()),
+          "tcavt_embed_fuse")
 
 
 def mask_to_kvlen(mask, Nq, kv_len, flag):
@@ -695,3 +707,54 @@ def adamw_gated(p, g, m, v, lr, beta1, beta2, eps, weight_decay, loss, ctl, grad
         _need(grad_norm, 1, "adamw_gated.grad_norm")
     check(lib().tcavt_adamw_gated(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, weight_decay, grad_scale,
                                   ptr(loss), ptr(grad_norm), ptr(ctl), stream_ptr()), "tcavt_adamw_gated")
+
+
+# ----------------------------------------------------------------------------------------------
+# stage-level entry points (include/tcavt.h "Stage-level entry points")
+# ----------------------------------------------------------------------------------------------
+def llama_stack_forward(args):
+    """args: capi.LlamaStackArgs filled by model.LlamaWithCrossAttnPEFT (which owns and sizes every buffer it names)."""
+    check(lib().tcavt_llama_stack_forward(ctypes.byref(args), stream_ptr()), "tcavt_llama_stack_forward")
+
+
+def rownorm_prep(x, x16, part):
+    """x16 = 16-bit copy of x [M, H]; part [M, H / 64] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm."""
+    _req(x, torch.float32, "rownorm_prep.x")
+    _req16(x16, "rownorm_prep.x16")
+    _req(part, torch.float32, "rownorm_prep.part")
+    M, H = x.shape
+    npart = H // 64
+    _need(x16, M * H, "rownorm_prep.x16")
+    _need(part, M * npart, "rownorm_prep.part")
+    check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], stream_ptr()), "tcavt_rownorm_prep")
+
+
+class StackEvents:
+    """hipEvents for the in-situ kernel timing of tcavt_llama_stack_forward (10 per layer: start / stop around q|k|v,
+    attention, o, gate|up, down)."""
+
+    STAGES = ("qkv", "attn", "o", "gateup", "down")
+
+    def __init__(self, n_layers):
+        self.n = 10 * n_layers
+        self.arr = (ctypes.c_void_p * self.n)()
+        check(lib().tcavt_events_create(self.arr, self.n), "tcavt_events_create")
+
+    def summary(self):
+        """{stage: (launches, mean ms)} of the LAST pass recorded (call after a stream synchronise)."""
+        out = {}
+        for si, name in enumerate(self.STAGES):
+            tot, cnt = 0.0, 0
+            for li in range(self.n // 10):
+                ms = ctypes.c_float(0.0)
+                check(lib().tcavt_event_elapsed_ms(self.arr[li * 10 + 2 * si], self.arr[li * 10 + 2 * si + 1], ctypes.byref(ms)),
+                      "tcavt_event_elapsed_ms")
+                tot += ms.value
+                cnt += 1
+            out[name] = (cnt, tot / max(cnt, 1))
+        return out
+
+    def close(self):
+        if self.arr is not None:
+            lib().tcavt_events_destroy(self.arr, self.n)
+            self.arr = None
