@@ -226,15 +226,20 @@ def test_lora_trainable_step(gpu):
     nqh, nkvh = cfg.llama.n_q_heads * 64, cfg.llama.n_kv_heads * 64
     for li, lyr in enumerate(lw.llama_model.model.layers):
         d, dT, sa = lw._prepared().layers[li], lw.prepared_T()[li], lyr.self_attn
-        assert torch.equal(d.a_cat[:r], sa.q_proj.lora_A.weight.detach().to(torch.bfloat16))
-        assert torch.equal(d.a_cat[LV:LV + r], sa.v_proj.lora_A.weight.detach().to(torch.bfloat16))
+        # the forward's packed adapters carry the folded RMSNorm gain (A * input_layernorm.weight, rounded once) ...
+        g1 = lyr.input_layernorm.weight.detach()[None, :]
+        assert torch.equal(d.a_cat[:r], (sa.q_proj.lora_A.weight.detach() * g1).to(torch.bfloat16))
+        assert torch.equal(d.a_cat[LV:LV + r], (sa.v_proj.lora_A.weight.detach() * g1).to(torch.bfloat16))
         assert torch.equal(d.b_ext[:nqh, :r], sa.q_proj.lora_B.weight.detach().to(torch.bfloat16))
         assert torch.equal(d.b_ext[nqh + nkvh:, LV:LV + r], sa.v_proj.lora_B.weight.detach().to(torch.bfloat16))
         assert d.a_cat[r:LV].abs().max().item() == 0 and d.a_cat[LV + r:].abs().max().item() == 0
         assert d.b_ext[nqh:nqh + nkvh].abs().max().item() == 0
-        assert torch.equal(dT.a_q[:, :LV], d.a_cat[:LV].t()) and dT.a_q[:, LV:].abs().max().item() == 0
-        assert torch.equal(dT.a_v[:, LV:], d.a_cat[LV:].t()) and dT.a_v[:, :LV].abs().max().item() == 0
-        assert torch.equal(dT.a_cat, d.a_cat.t()) and torch.equal(dT.b_ext, d.b_ext.t())
+        # ... the backward's copies are the plain matrices
+        assert torch.equal(dT.a_plain[:r], sa.q_proj.lora_A.weight.detach().to(torch.bfloat16))
+        assert torch.equal(dT.a_plain[LV:LV + r], sa.v_proj.lora_A.weight.detach().to(torch.bfloat16))
+        assert torch.equal(dT.a_q[:, :LV], dT.a_plain[:LV].t()) and dT.a_q[:, LV:].abs().max().item() == 0
+        assert torch.equal(dT.a_v[:, LV:], dT.a_plain[LV:].t()) and dT.a_v[:, :LV].abs().max().item() == 0
+        assert torch.equal(dT.a_cat, dT.a_plain.t()) and torch.equal(dT.b_ext, d.b_ext.t())
     l1, _ = tr.forward_backward(*args)
     torch.cuda.synchronize()
     assert torch.isfinite(l1).item() and l1.item() != l0.item()
