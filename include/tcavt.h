@@ -149,6 +149,9 @@ typedef struct tcavt_gemm_args {
   int32_t rowscale_h;
   float rowscale_eps;
   int32_t reserved1;
+  /* TCAVT_EPI_ROPE, optional: int32 [M] device array, the position of row m (a decode step has one row per sample, each
+   * at its own position; cos / sin tables then hold rope_L >= max position + 1 rows).  NULL: position = m % rope_L */
+  const int32_t* rope_pos;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -508,6 +511,63 @@ int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t
  * tcavt_llama_stack_forward for embeddings that do not come from tcavt_embed_fuse (HF-style inputs_embeds call) */
 int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16,
                        tcavt_stream_t stream);
+
+/* ========================================================================
+ * Autoregressive text generation (LlamaMultiModal.generate_batch, scripts/train.py:577-654;
+ * scripts/check_generation.py:152-222).  Prefill = tcavt_llama_stack_forward with k_cache / v_cache set;
+ * tcavt_gather_last picks every sample's last valid hidden state; one tcavt_llama_decode_step per further token;
+ * tcavt_sample_logits turns logits into the next token and advances the device-resident state, so that a decode
+ * step is a fixed launch sequence (hipGraph-capturable, BASELINE.json configs[4]).
+ * ====================================================================== */
+typedef struct tcavt_sample_params {
+  float temperature;          /* TemperatureLogitsWarper (reference: 0.9); sampling only */
+  float top_p;                /* TopPLogitsWarper (0.9); sampling only; 1 disables */
+  float repetition_penalty;   /* RepetitionPenaltyLogitsProcessor (1.2); 1 disables */
+  int32_t top_k;              /* TopKLogitsWarper (40); sampling only; 1 .. 256 */
+  int32_t no_repeat_ngram_size; /* NoRepeatNGramLogitsProcessor (3); 0 disables */
+  int32_t do_sample;          /* 0: greedy arg-max of the processed scores (first maximum), bit-reproducible */
+  int64_t eos_token_id;       /* < 0: none */
+  int64_t pad_token_id;       /* emitted for samples that have finished */
+  uint64_t seed;              /* Philox key of the sampling draws (counter = step, sample) */
+} tcavt_sample_params;
+
+/* logits fp32 [B][V] (modified in place); history int64 [B][hist_cap] + hist_len int32 [B]: the tokens the repetition
+ * penalty and the n-gram ban look at (prompt ids + generated); *step (device int32): index of the token being chosen --
+ * out_tokens[b][*step] receives it, cur_tok[b] too, the history grows by it, pos[b] += 1 when advance_pos != 0,
+ * finished[b] is set on EOS, and *step is incremented at the end. */
+int tcavt_sample_logits(float* logits, int B, int V, int64_t* history, int hist_cap, int32_t* hist_len,
+                        const tcavt_sample_params* params, int32_t* step, int64_t* cur_tok, int32_t* pos,
+                        int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos, tcavt_stream_t stream);
+
+/* out16[b] = src16[b * L + kv_len[b] - 1]: 16-bit rows of width H */
+int tcavt_gather_last(const void* src16, const int32_t* kv_len, void* out16, int B, int L, int H, tcavt_stream_t stream);
+
+typedef struct tcavt_decode_args {
+  const tcavt_llama_layer* layers; /* HOST array, as for tcavt_llama_stack_forward (tape fields unused) */
+  const float* gamma_final;
+  const float* rope_cos;           /* fp32 [rope_L][32], rope_L >= kv_lmax */
+  const float* rope_sin;
+  const void* table;               /* 16-bit [V][H]: embedding table = lm_head (tied) */
+  const float* txt_mod;            /* fp32 [H]: text_modality_embedding (generated tokens are text tokens, train.py:526-527) */
+  const int64_t* cur_tok;          /* int64 [B]: the token fed in this step */
+  const int32_t* pos;              /* int32 [B]: its position = number of keys already in the cache */
+  float* h;                        /* fp32 [B][H] workspace */
+  void* h16;                       /* 16-bit [B][H] */
+  float* part;                     /* fp32 [B][H / 64] */
+  void* qkv;                       /* 16-bit [B][(nq + 2 nkv) * 64] */
+  void* att;                       /* 16-bit [B][nq * 64] */
+  void* act;                       /* 16-bit [B][I] */
+  void* t;                         /* 16-bit [B][64] (LoRA; zero-initialised once) */
+  void* k_cache;                   /* 16-bit [n_layers][B][kv_lmax][nkv * 64], filled up to pos[b] by the prefill / earlier steps */
+  void* v_cache;
+  void* x16;                       /* 16-bit [B][H]: final-norm output */
+  float* logits;                   /* fp32 [B][V] */
+  int32_t* bad_id_flag;
+  int32_t n_layers, B, H, I, nq, nkv, V, dtype16, kv_lmax, rope_L;
+  float rms_eps, lora_scale;
+} tcavt_decode_args;
+
+int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);
 
 /* hipEvent helpers for tcavt_llama_stack_args.events (timing enabled); elapsed time in milliseconds between two
  * recorded events after the stream has been synchronised by the caller */

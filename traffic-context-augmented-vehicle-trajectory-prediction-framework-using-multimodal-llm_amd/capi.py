@@ -54,6 +54,7 @@ class GemmArgs(ctypes.Structure):
         ("norm_h16", c_void_p), ("norm_part", c_void_p), ("rowscale_part", c_void_p),
         ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
         ("reserved1", ctypes.c_int32),
+        ("rope_pos", c_void_p),
     ]
 
 
@@ -81,6 +82,24 @@ class LlamaStackArgs(ctypes.Structure):
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
         ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
     ]
+
+
+class SampleParams(ctypes.Structure):
+    """Mirror of ``tcavt_sample_params`` (include/tcavt.h)."""
+
+    _fields_ = [("temperature", c_float), ("top_p", c_float), ("repetition_penalty", c_float), ("top_k", ctypes.c_int32),
+                ("no_repeat_ngram_size", ctypes.c_int32), ("do_sample", ctypes.c_int32), ("eos_token_id", c_int64),
+                ("pad_token_id", c_int64), ("seed", ctypes.c_uint64)]
+
+
+class DecodeArgs(ctypes.Structure):
+    """Mirror of ``tcavt_decode_args`` (include/tcavt.h)."""
+
+    _fields_ = [("layers", ctypes.POINTER(LlamaLayer))] + [(n, c_void_p) for n in (
+        "gamma_final", "rope_cos", "rope_sin", "table", "txt_mod", "cur_tok", "pos", "h", "h16", "part", "qkv", "att", "act",
+        "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
+            "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
+        ("rms_eps", c_float), ("lora_scale", c_float)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)
@@ -153,6 +172,10 @@ _SIGNATURES = {
     "tcavt_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                     c_int, c_float, c_void_p],
     "tcavt_llama_stack_forward": [ctypes.POINTER(LlamaStackArgs), c_void_p],
+    "tcavt_sample_logits": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.POINTER(SampleParams), c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "tcavt_gather_last": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_llama_decode_step": [ctypes.POINTER(DecodeArgs), c_void_p],
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

@@ -57,6 +57,7 @@ struct GemmP {
   const float* rs_part;   // ROWSCALE: [M][rs_npart] sums of squares of the row the A operand was rounded from
   int rs_npart;
   float rs_eps, rs_inv_h;
+  const int* rope_pos;    // ROPE: position of row m (decode step: one row per sample); NULL: m % rope_L
 };
 
 // 1 / rms of row m from its partial sums of squares, added in index order (bit-reproducible; rs_npart % 4 == 0)
@@ -112,9 +113,44 @@ __device__ __forceinline__ float silu_mul(float g, float u) {
 // WHOLE_ONLY: the caller guarantees whole tiles (the 4-wave kernel); the bounds-checked paths are compiled out where
 // a fast path covers the form.
 // F16: the operands' 16-bit type; the fast paths below write 16-bit outputs of that same type (OUT16).
+// rs_lds (ROWSCALE, optional): the row scales of this wave's rows already in LDS (rs_lds[16 j + (lane & 15)] for m-tile j;
+// the 4-wave kernel computes them once per output tile while the first operands are in flight); otherwise they are
+// summed here from the partials, all TM rows' loads in flight together.
 template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane,
+                                              const float* rs_lds = nullptr) {
   constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
+  float rsv[TM];
+  if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE || EPI == EPI_ROPE) {
+    if (rs_lds) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) rsv[j] = rs_lds[j * 16 + (lane & 15)];
+    } else if (p.rs_part) {
+      // same summation order as row_rscale (four partials per step, in index order): bit-identical to the LDS path
+      float ss[TM];
+      const f32x4* q[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        ss[j] = 0.f;
+        q[j] = reinterpret_cast<const f32x4*>(p.rs_part + (long)min(m_base + j * 16 + (lane & 15), p.M - 1) * p.rs_npart);
+      }
+      for (int i = 0; i < (p.rs_npart >> 2); ++i) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const f32x4 v = q[j][i];
+          ss[j] += v[0];
+          ss[j] += v[1];
+          ss[j] += v[2];
+          ss[j] += v[3];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) rsv[j] = rsqrtf(ss[j] * p.rs_inv_h + p.rs_eps);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) rsv[j] = 1.f;
+    }
+  }
   // ---- epilogue: lane holds features n..n+3 of token m in acc[i][j]
   const int nq = 4 * (lane >> 4);
   const int ml = lane & 15;
@@ -195,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       for (int j = 0; j < TM; ++j) {
         const long m = m_base + j * 16 + ml;
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + (n_base >> 1) + nq;
-        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;  // fused RMSNorm: 1 / rms of the row (gamma is in W)
+        const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
         for (int i = 0; i < TN; i += 2) {
           const f32x4 g = acc[i][j] * rs, u = acc[i + 1][j] * rs;
@@ -217,11 +253,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int m = m_base + j * 16 + ml;
-        const int pos = m % p.rope_L;
+        const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
         const float* crp = p.cosT + pos * 32 + nq;
         const float* srp = p.sinT + pos * 32 + nq;
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base + nq;
-        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;  // fused RMSNorm: 1 / rms of the row (gamma is in W)
+        const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
         for (int hh = 0; hh < TN / 4; ++hh) {
           const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
@@ -294,7 +330,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       for (int i = 0; i < TN; i += 2) {
         if (n_base + i * 16 >= p.N) continue;  // partial last tile column
         const int n = ((n_base) >> 1) + (i >> 1) * 16 + nq;
-        const float rs = p.rs_part ? row_rscale(p, m) : 1.f;
+        const float rs = rsv[j];
         const f32x4 g = acc[i][j] * rs, u = acc[i + 1][j] * rs;
         if constexpr (EPI == EPI_SILU_SAVE) {
           bf16_t* arow = p.aux + (long)m * p.ldaux + n_base + i * 16 + nq;
@@ -312,7 +348,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
     for (int j = 0; j < TM; ++j) {
       const int m = m_base + j * 16 + ml;
       if (m >= p.M) continue;
-      const int pos = m % p.rope_L;
+      const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
 #pragma unroll
       for (int hh = 0; hh < TN / 4; ++hh) {
         const int nb = n_base + hh * 64;
@@ -321,7 +357,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int d = i * 16 + nq;
-          const float rs = p.rs_part ? row_rscale(p, m) : 1.f;
+          const float rs = rsv[j];
           f32x4 lo = acc[hh * 4 + i][j] * rs, hi = acc[hh * 4 + i + 2][j] * rs;
           if (rot) {
             const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
@@ -806,6 +842,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / WN_, wn = wave % WN_;
+  // fused RMSNorm (TCAVT_EPI_ROWSCALE): the 256 row scales of the output tile, behind the two tile buffers
+  constexpr bool RS = EPI == EPI_SILU || EPI == EPI_SILU_SAVE || EPI == EPI_ROPE;
+  float* rs_tile = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
   // Persistent form (p.pers_tiles > 0): this workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... as ONE stream of
   // K-tiles -- the look-ahead of the pipeline (fragments of the next K-tile, DMA of the next two) simply continues into
   // the next output tile, so its first operands arrive while this tile's epilogue runs (no per-tile prologue).
@@ -924,6 +963,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   auto ldw = [&](const char* base, int off, int i) { return *reinterpret_cast<const bf16x8*>(base + wrow + i * 2048 + off); };
 
   // ---- prologue: tile 0 (burst), publish, first pieces of tile 1, fragments F0(0)
+  if constexpr (RS) {  // (the partial-sum loads are in flight together with tile 0's DMA; written before the barrier below)
+    if (p.rs_part) rs_tile[threadIdx.x] = row_rscale(p, m0 + threadIdx.x);
+  }
   {
     const Src s0 = tsrc(0);
 #pragma unroll
@@ -1063,10 +1105,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-    gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane);
+    gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane,
+                                          (RS && p.rs_part) ? rs_tile + wm * TM * 16 : nullptr);
     if (!PERS_OK || !has_next) break;  // (uniform) non-persistent launches leave here
     // ---- next output tile: F0 already holds its first fragments, its second K-tile is in flight
     vb += gridDim.x;
+    if constexpr (RS) {
+      if (p.rs_part && nm0 != m0) {  // the next tile's rows differ: its scales replace this tile's once every wave has read them
+        asm volatile("s_barrier" ::: "memory");
+        rs_tile[threadIdx.x] = row_rscale(p, nm0 + threadIdx.x);  // (published by the first K-tile barrier of the next tile)
+      }
+    }
     m0 = nm0;
     n0 = nn0;
     srcA = nxtA;
@@ -1096,7 +1145,7 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
   p.xcd_gx = choose_xcd_partition(p);
-  constexpr int lds = 2 * (256 + BN) * 128;
+  constexpr int lds = 2 * (256 + BN) * 128 + 1024;  // two tile buffers + 256 row scales (TCAVT_EPI_ROWSCALE)
   auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF, BN, F16>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1345,6 +1394,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.norm_h16 = nullptr;
   p.norm_part = nullptr;
   p.rs_part = nullptr;
+  p.rope_pos = (epi & TCAVT_EPI_ROPE) ? a->rope_pos : nullptr;
   p.rs_npart = 0;
   p.rs_eps = p.rs_inv_h = 0.f;
   if (epi & TCAVT_EPI_NORM_OUT) {

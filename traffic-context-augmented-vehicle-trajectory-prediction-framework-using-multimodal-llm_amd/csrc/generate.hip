@@ -1,0 +1,378 @@
+// Autoregressive text generation on the decoder stack (reference: LlamaMultiModal.generate_batch,
+// scripts/train.py:577-654, and scripts/check_generation.py:152-222).
+//
+// The reference hands HF `generate` a prefix of image tokens + prompt embeddings through a patched embedding layer and
+// samples with temperature 0.9, top-k 40, top-p 0.9, repetition penalty 1.2 and no-repeat-3-grams (train.py:628-642).
+// Here the prefix is a first-class argument: the PREFILL is the ordinary batched forward (tcavt_llama_stack_forward
+// with k_cache / v_cache set), and every following token is ONE call of tcavt_llama_decode_step:
+//
+//   embed (table[id] + text modality embedding)  ->  16 x [ LoRA down | q|k|v + RoPE at the sample's own position |
+//   append k, v to the cache | attention of the one query over the cached keys | o_proj | gate|up | down ]  ->
+//   final RMSNorm  ->  lm_head (tied embedding table)  ->  logits processors + token selection (tcavt_sample_logits)
+//
+// All per-step state (positions, current tokens, token history, step counter, finished flags) lives on the device and
+// is advanced by the selection kernel, so the launch sequence of a step never changes: it is captured in a hipGraph
+// once and replayed per token (BASELINE.json configs[4] "hipGraph-captured decode").
+// The projections reuse the MFMA GEMM (M = batch rows: weight-streaming, HBM-bound); RMSNorm is fused exactly as in the
+// prefill (csrc/stack.hip).
+#include "common.hpp"
+#include "philox.hpp"
+
+namespace tcavt {
+
+// k, v of the new token (row b of qkv) -> cache position pos[b]
+__global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
+                                                        bf16_t* __restrict__ vc, const int* __restrict__ pos, int lmax,
+                                                        int nq, int nkv) {
+  const int b = blockIdx.x, ld = (nq + 2 * nkv) * 64, w = nkv * 64;
+  const int p = min(pos[b], lmax - 1);
+  const bf16_t* src = qkv + (long)b * ld + nq * 64;
+  bf16_t* kd = kc + ((long)b * lmax + p) * w;
+  bf16_t* vd = vc + ((long)b * lmax + p) * w;
+  for (int c = threadIdx.x * 8; c < w; c += 256 * 8) {
+    *reinterpret_cast<u32x4*>(kd + c) = *reinterpret_cast<const u32x4*>(src + c);
+    *reinterpret_cast<u32x4*>(vd + c) = *reinterpret_cast<const u32x4*>(src + w + c);
+  }
+}
+
+// One query per (sample, query head) over the cached keys 0 .. pos[b] (the new token's own key included).
+// One workgroup per (sample, kv head), one wave per query head of the group; lane = head dimension.
+template <bool F16>
+__global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ vc, const int* __restrict__ pos,
+                                                          bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale) {
+  extern __shared__ float sc[];  // [group][lmax] scores / probabilities
+  const int group = nq / nkv;
+  const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv >= group) return;
+  const int head = kvh * group + wv;
+  const int n = min(pos[b] + 1, lmax);
+  const int ld = (nq + 2 * nkv) * 64, w = nkv * 64;
+  const float q = from16<F16>(qkv[(long)b * ld + head * 64 + lane]);
+  const bf16_t* kb = kc + (long)b * lmax * w + kvh * 64;
+  const bf16_t* vb = vc + (long)b * lmax * w + kvh * 64;
+  float* s = sc + wv * lmax;
+  float mx = -1e30f;
+  for (int j = 0; j < n; ++j) {
+    const float d = wave_sum(q * from16<F16>(kb[(long)j * w + lane])) * scale;
+    if (lane == 0) s[j] = d;
+    mx = fmaxf(mx, d);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float e = __expf(s[j] - mx);
+    s[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  const float inv = 1.f / sum;
+  float o = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const float p = f16_to_f32(f32_to_f16(s[j] * inv));  // probabilities are carried in fp16, as in the prefill kernel
+    o = fmaf(p, from16<F16>(vb[(long)j * w + lane]), o);
+  }
+  out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
+}
+
+// out[b] = src[b * L + kv_len[b] - 1]  (the last valid position's hidden state of each sample after the prefill)
+__global__ __launch_bounds__(256) void gather_last_kernel(const bf16_t* __restrict__ src, const int* __restrict__ kv_len,
+                                                          bf16_t* __restrict__ out, int L, int H) {
+  const int b = blockIdx.x;
+  const int l = min(max(kv_len[b], 1), L) - 1;
+  const bf16_t* s = src + ((long)b * L + l) * H;
+  for (int c = threadIdx.x * 8; c < H; c += 256 * 8)
+    *reinterpret_cast<u32x4*>(out + (long)b * H + c) = *reinterpret_cast<const u32x4*>(s + c);
+}
+
+// ---------------------------------------------------------------------------
+// Logits processors + token selection, one workgroup per sample (HF generation: RepetitionPenaltyLogitsProcessor,
+// NoRepeatNGramLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, in that order; the warpers
+// only when sampling).  `logits` is modified in place (penalty / bans).  The candidates that survive top-k are gathered
+// in descending (value, then ascending index) order by k rounds of a block-wide arg-max "next after the previous one" --
+// exact ties at the k-th value are all kept, as `scores < topk[-1]` keeps them.
+// ---------------------------------------------------------------------------
+struct SampleP {
+  float temperature, top_p, rep_penalty;
+  int top_k, no_repeat_ngram, do_sample;
+  long eos, pad;
+  unsigned int seed_lo, seed_hi;
+};
+
+constexpr int SMP_T = 1024;   // threads
+constexpr int SMP_CAP = 256;  // candidate list capacity (top_k + ties)
+
+__device__ __forceinline__ bool after(float v, int i, float pv, int pi) {  // (v, i) comes after (pv, pi) in (value desc, index asc) order
+  return v < pv || (v == pv && i > pi);
+}
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) {  // (v, i) precedes (bv, bi)
+  return v > bv || (v == bv && i < bi);
+}
+
+__global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logits, int V, long* __restrict__ history,
+                                                       int hist_cap, int* __restrict__ hist_len, SampleP sp,
+                                                       int* __restrict__ step_p, long* __restrict__ cur_tok,
+                                                       int* __restrict__ pos, int* __restrict__ finished,
+                                                       long* __restrict__ out_tokens, int out_cap, int advance_pos) {
+  __shared__ float cv[SMP_CAP];
+  __shared__ int ci[SMP_CAP];
+  __shared__ float rv[SMP_T / 64];
+  __shared__ int ri[SMP_T / 64];
+  __shared__ float bestv;
+  __shared__ int besti;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* x = logits + (long)b * V;
+  long* hist = history + (long)b * hist_cap;
+  const int hl = min(hist_len[b], hist_cap);
+  const int step = *step_p;
+  // ---- repetition penalty: once per distinct token of the history (scatter semantics of the reference processor)
+  if (sp.rep_penalty != 1.f) {
+    for (int i = tid; i < hl; i += SMP_T) {
+      const long t = hist[i];
+      bool first = t >= 0 && t < V;
+      for (int j = 0; j < i && first; ++j) first = hist[j] != t;
+      if (first) {
+        const float s = x[t];
+        x[t] = s < 0.f ? s * sp.rep_penalty : s / sp.rep_penalty;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- no-repeat n-gram: ban every token that would complete an n-gram already in the history
+  const int ng = sp.no_repeat_ngram;
+  if (ng > 0 && hl + 1 >= ng) {
+    for (int i = tid; i + ng - 1 < hl; i += SMP_T) {
+      bool match = true;
+      for (int k = 0; k < ng - 1 && match; ++k) match = hist[i + k] == hist[hl - (ng - 1) + k];
+      const long t = hist[i + ng - 1];
+      if (match && t >= 0 && t < V) x[t] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  // block-wide arg-max of the elements that come after (pv, pi) in (value desc, index asc) order
+  auto next_best = [&](float pv, int pi, float scale) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += SMP_T) {
+      const float v = x[i] * scale;
+      if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = rv[0];
+      int i = ri[0];
+      for (int k = 1; k < SMP_T / 64; ++k)
+        if (better(rv[k], ri[k], v, i)) { v = rv[k]; i = ri[k]; }
+      bestv = v;
+      besti = i;
+    }
+    __syncthreads();
+  };
+  long tok;
+  if (!sp.do_sample) {  // greedy: arg-max of the processed scores, first maximum wins (torch.argmax)
+    next_best(INFINITY, -1, 1.f);
+    tok = besti;
+  } else {
+    const float invT = 1.f / sp.temperature;
+    int n = 0;
+    float pv = INFINITY;
+    int pi = -1;
+    const int k = min(max(sp.top_k, 1), SMP_CAP);
+    for (;;) {
+      next_best(pv, pi, invT);
+      const float v = bestv;
+      const int i = besti;
+      if (i == 0x7fffffff || v == -INFINITY) break;        // nothing (finite) left
+      if (n >= k && !(v == cv[k - 1])) break;               // beyond top-k and not a tie with the k-th value
+      if (n >= SMP_CAP) break;
+      if (tid == 0) { cv[n] = v; ci[n] = i; }
+      ++n;
+      pv = v;
+      pi = i;
+      __syncthreads();
+    }
+    if (tid == 0) {
+      // softmax over the kept candidates (descending), top-p: drop the low tail whose cumulative probability, counted
+      // from the bottom and including the item, is <= 1 - top_p (keep at least one)
+      const float m = cv[0];
+      float tot = 0.f;
+      for (int j = 0; j < n; ++j) tot += __expf(cv[j] - m);
+      int keep = n;
+      if (sp.top_p < 1.f) {
+        float tail = 0.f;
+        for (int j = n - 1; j >= 1; --j) {
+          tail += __expf(cv[j] - m) / tot;
+          if (tail <= 1.f - sp.top_p) keep = j;
+          else break;
+        }
+      }
+      float kt = 0.f;
+      for (int j = 0; j < keep; ++j) kt += __expf(cv[j] - m);
+      unsigned int r[4];
+      philox4x32_10((unsigned int)step, (unsigned int)b, 0x5A3Bu, 0u, sp.seed_lo, sp.seed_hi, r);
+      const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f) * kt;
+      float acc = 0.f;
+      int pick = keep - 1;
+      for (int j = 0; j < keep; ++j) {
+        acc += __expf(cv[j] - m);
+        if (u < acc) { pick = j; break; }
+      }
+      besti = n > 0 ? ci[pick] : 0;
+    }
+    __syncthreads();
+    tok = besti;
+  }
+  if (tid == 0) {
+    // a finished sample keeps emitting the pad token (HF generate pads finished rows)
+    const bool fin = finished[b] != 0;
+    const long outt = fin ? sp.pad : tok;
+    if (step < out_cap) out_tokens[(long)b * out_cap + step] = outt;
+    if (!fin && sp.eos >= 0 && tok == sp.eos) finished[b] = 1;
+    cur_tok[b] = outt;
+    if (hl < hist_cap) {
+      hist[hl] = outt;
+      hist_len[b] = hl + 1;
+    }
+    if (advance_pos) pos[b] += 1;
+  }
+  if (b == 0 && tid == 0) {
+    __threadfence();
+  }
+}
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+}  // namespace tcavt
+
+using namespace tcavt;
+
+#define TCAVT_TRY(call)              \
+  do {                               \
+    const int rc_ = (call);          \
+    if (rc_ != TCAVT_OK) return rc_; \
+  } while (0)
+
+extern "C" int tcavt_sample_logits(float* logits, int B, int V, int64_t* history, int hist_cap, int32_t* hist_len,
+                                   const tcavt_sample_params* sp, int32_t* step, int64_t* cur_tok, int32_t* pos,
+                                   int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos,
+                                   tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(logits && history && hist_len && sp && step && cur_tok && pos && finished && out_tokens && B > 0 && V > 0 &&
+                      hist_cap > 0 && out_cap > 0,
+                  "sample_logits: bad args");
+  TCAVT_CHECK_ARG(!sp->do_sample || (sp->temperature > 0.f && sp->top_k >= 1 && sp->top_k <= SMP_CAP && sp->top_p > 0.f && sp->top_p <= 1.f),
+                  "sample_logits: sampling needs temperature > 0, 1 <= top_k <= %d, 0 < top_p <= 1", SMP_CAP);
+  TCAVT_CHECK_ARG(sp->repetition_penalty > 0.f && sp->no_repeat_ngram_size >= 0, "sample_logits: bad repetition_penalty / no_repeat_ngram_size");
+  SampleP p;
+  p.temperature = sp->temperature; p.top_p = sp->top_p; p.rep_penalty = sp->repetition_penalty;
+  p.top_k = sp->top_k; p.no_repeat_ngram = sp->no_repeat_ngram_size; p.do_sample = sp->do_sample;
+  p.eos = sp->eos_token_id; p.pad = sp->pad_token_id;
+  p.seed_lo = (unsigned int)(sp->seed & 0xffffffffu); p.seed_hi = (unsigned int)(sp->seed >> 32);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_T), 0, st, logits, V, reinterpret_cast<long*>(history), hist_cap,
+                     hist_len, p, step, reinterpret_cast<long*>(cur_tok), pos, finished, reinterpret_cast<long*>(out_tokens),
+                     out_cap, advance_pos);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+  TCAVT_CHECK_LAUNCH("sample_logits");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_gather_last(const void* src16, const int32_t* kv_len, void* out16, int B, int L, int H,
+                                 tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(src16 && kv_len && out16 && B > 0 && L > 0 && H > 0 && H % 8 == 0, "gather_last: bad args");
+  hipLaunchKernelGGL(gather_last_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(src16), kv_len, static_cast<bf16_t*>(out16), L, H);
+  TCAVT_CHECK_LAUNCH("gather_last");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->layers && a->gamma_final && a->rope_cos && a->rope_sin && a->table && a->txt_mod && a->cur_tok && a->pos &&
+                      a->h && a->h16 && a->part && a->qkv && a->att && a->act && a->k_cache && a->v_cache && a->x16 && a->logits &&
+                      a->bad_id_flag,
+                  "llama_decode_step: null pointer");
+  TCAVT_CHECK_ARG(a->n_layers > 0 && a->B > 0 && a->H % 256 == 0 && a->I > 0 && a->nq > 0 && a->nkv > 0 && a->nq % a->nkv == 0 &&
+                      a->nq / a->nkv <= 8 && a->V > 0 && a->V % 16 == 0 && a->kv_lmax > 0 && a->rope_L >= a->kv_lmax && is16(a->dtype16),
+                  "llama_decode_step: bad shape (H %% 256, V %% 16, nq / nkv <= 8, rope_L >= kv_lmax)");
+  const int B = a->B, H = a->H, I = a->I, nq = a->nq, nkv = a->nkv, dt = a->dtype16;
+  const int nqkv = (nq + 2 * nkv) * 64, npart = H / 64;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
+  // norm's inputs
+  TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->h /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
+                             a->bad_id_flag, dt, a->h16, a->part, npart, stream));
+  const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
+  const size_t lds = (size_t)(nq / nkv) * a->kv_lmax * sizeof(float);
+  TCAVT_CHECK_ARG(lds <= 64 * 1024, "llama_decode_step: kv_lmax = %d too long for the decode attention's score buffer", a->kv_lmax);
+  for (int li = 0; li < a->n_layers; ++li) {
+    const tcavt_llama_layer& w = a->layers[li];
+    TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (!w.a_cat || (w.b_ext && a->t)), "llama_decode_step: layer %d: null weight", li);
+    if (w.a_cat) {
+      tcavt_gemm_args g = {};
+      g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
+      g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+    {
+      tcavt_gemm_args g = {};
+      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv;
+      g.M = B; g.N = nqkv; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
+      if (w.a_cat) { g.A2 = a->t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
+      g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
+      g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->rope_L; g.rope_cols = (nq + nkv) * 64;
+      g.rope_pos = a->pos;
+      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+    bf16_t* kc = static_cast<bf16_t*>(a->k_cache) + li * per_layer;
+    bf16_t* vc = static_cast<bf16_t*>(a->v_cache) + li * per_layer;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(B), dim3(256), 0, st, static_cast<const bf16_t*>(a->qkv), kc, vc, a->pos,
+                       a->kv_lmax, nq, nkv);
+    if (dt == TCAVT_F16)
+      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nkv), dim3((nq / nkv) * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f);
+    else
+      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nkv), dim3((nq / nkv) * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f);
+    TCAVT_CHECK_LAUNCH("attn_decode");
+    {
+      tcavt_gemm_args g = {};
+      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H;
+      g.M = B; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
+      g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
+      g.norm_h16 = a->h16; g.norm_part = a->part;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+    {
+      tcavt_gemm_args g = {};
+      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
+      g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
+      g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
+      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+    {
+      tcavt_gemm_args g = {};
+      g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H;
+      g.M = B; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
+      g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
+      g.norm_h16 = a->h16; g.norm_part = a->part;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+  }
+  TCAVT_TRY(tcavt_rmsnorm(a->h, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, nullptr, 0.f, 0, 0, dt, stream));
+  // lm_head: tied to the embedding table (Llama-3.2-1B: tie_word_embeddings)
+  tcavt_gemm_args g = {};
+  g.A = a->x16; g.lda = H; g.W = a->table; g.ldw = H; g.C = a->logits; g.ldc = a->V;
+  g.M = B; g.N = a->V; g.K = H; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
+  return tcavt_gemm_bf16(&g, stream);
+}

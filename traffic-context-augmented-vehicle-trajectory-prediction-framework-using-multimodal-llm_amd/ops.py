@@ -717,6 +717,37 @@ def llama_stack_forward(args):
     check(lib().tcavt_llama_stack_forward(ctypes.byref(args), stream_ptr()), "tcavt_llama_stack_forward")
 
 
+def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finished, out_tokens, advance_pos):
+    """Logits processors + token selection (tcavt_sample_logits); every tensor is device state that the call advances."""
+    B, V = logits.shape
+    _req(logits, torch.float32, "sample_logits.logits")
+    for t, dt, n, nm in ((history, torch.int64, B, "history"), (hist_len, torch.int32, B, "hist_len"), (step, torch.int32, 1, "step"),
+                         (cur_tok, torch.int64, B, "cur_tok"), (pos, torch.int32, B, "pos"), (finished, torch.int32, B, "finished"),
+                         (out_tokens, torch.int64, B, "out_tokens")):
+        _req(t, dt, "sample_logits." + nm)
+        _need(t, n, "sample_logits." + nm)
+    if history.shape[0] != B or out_tokens.shape[0] != B:
+        raise capi.TcavtError("sample_logits: history / out_tokens need one row per sample")
+    check(lib().tcavt_sample_logits(ptr(logits), B, V, ptr(history), history.shape[1], ptr(hist_len), ctypes.byref(params),
+                                    ptr(step), ptr(cur_tok), ptr(pos), ptr(finished), ptr(out_tokens), out_tokens.shape[1],
+                                    int(advance_pos), stream_ptr()), "tcavt_sample_logits")
+
+
+def gather_last(src16, kv_len, out16, B, L, H):
+    _req16(src16, "gather_last.src16")
+    _req16(out16, "gather_last.out16", like=src16)
+    _req(kv_len, torch.int32, "gather_last.kv_len")
+    _need(src16, B * L * H, "gather_last.src16")
+    _need(out16, B * H, "gather_last.out16")
+    _need(kv_len, B, "gather_last.kv_len")
+    check(lib().tcavt_gather_last(ptr(src16), ptr(kv_len), ptr(out16), B, L, H, stream_ptr()), "tcavt_gather_last")
+
+
+def llama_decode_step(args):
+    """args: capi.DecodeArgs filled by model.LlamaMultiModal.generate_batch (which owns and sizes every buffer)."""
+    check(lib().tcavt_llama_decode_step(ctypes.byref(args), stream_ptr()), "tcavt_llama_decode_step")
+
+
 def rownorm_prep(x, x16, part):
     """x16 = 16-bit copy of x [M, H]; part [M, H / 64] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm."""
     _req(x, torch.float32, "rownorm_prep.x")
