@@ -252,6 +252,74 @@ def run_train_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_ev
         print("   ", s_)
 
 
+def run_generation_case(ref):
+    """tests/golden/tiny_generation.npz -- the text-generation row (scripts/train.py:577-654):
+      * greedy continuation of the tiny LoRA case's prompts by the reference model's own HF LlamaForCausalLM
+        (`logits[:, -1]` of a full forward on the growing sequence; prefix = image tokens + valid prompt tokens built by
+        the reference's Q-Former / q_proj / embedding modules as train.py:519-528 does; a generated token is embedded
+        as a text token), with the top-1 / top-2 margin of every step;
+      * transformers' own logits processors in generate()'s order -- RepetitionPenalty(1.2), NoRepeatNGram(3),
+        Temperature(0.9), TopK(40), TopP(0.9) (train.py:628-642) -- applied to fixed random scores and histories."""
+    from transformers.generation.logits_process import (NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
+                                                        TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+
+    name, preset, T, To, lora, B, text_len, ragged, empty_every, seed = CASES[0]
+    cfg = tconfig.PRESETS[preset](seq_len=T, out_len=To, use_lora=lora)
+    weights = make_weights(cfg, seed)
+    model = build_reference_model(ref, cfg, weights)
+    batch = synth.make_batch(cfg, B, text_len=text_len, seed=seed, ragged=ragged, min_text=4, empty_polygon_every=empty_every)
+    vision, ids, mask = (torch.from_numpy(batch[k]) for k in ("vision_emb", "input_ids", "attention_mask"))
+    mm = model.mllm
+    llama = mm.llama_wrapper.llama_model
+    emb = llama.get_input_embeddings()
+    N = 12
+    toks = np.zeros((2, B, N), np.int64)       # [plain arg-max | with the reference's repetition penalty + 3-gram ban]
+    margins = np.zeros((2, B, N), np.float32)
+    rep, ngram = RepetitionPenaltyLogitsProcessor(1.2), NoRepeatNGramLogitsProcessor(3)
+    with torch.no_grad():
+        img = mm.q_proj(mm.qformer(vision)) + mm.vision_modality_embedding
+        for mode in (0, 1):
+            for b in range(B):
+                n = int(mask[b].sum())
+                seq = torch.cat([img[b:b + 1], emb(ids[b:b + 1, :n]) + mm.text_modality_embedding], dim=1)
+                hist_ids = ids[b:b + 1, :n].clone()  # generate(input_ids=prompt_ids, ...): the processors see prompt + generated
+                for i in range(N):
+                    lg = llama(inputs_embeds=seq, attention_mask=torch.ones(1, seq.shape[1], dtype=torch.long)).logits[:, -1]
+                    if mode == 1:
+                        lg = ngram(hist_ids, rep(hist_ids, lg))
+                    top = torch.topk(lg[0], 2)
+                    toks[mode, b, i], margins[mode, b, i] = int(top.indices[0]), float(top.values[0] - top.values[1])
+                    hist_ids = torch.cat([hist_ids, top.indices[:1][None]], dim=1)
+                    seq = torch.cat([seq, emb(top.indices[:1])[None] + mm.text_modality_embedding], dim=1)
+    # ---- processors on fixed scores
+    g = torch.Generator().manual_seed(77)
+    V, R = cfg.llama.vocab, 6
+    scores = torch.randn(R, V, generator=g) * 3.0
+    lens = [0, 1, 2, 5, 30, 60]
+    hist = np.full((R, 64), -1, np.int64)
+    processed, warped = np.zeros((R, V), np.float32), np.zeros((R, V), np.float32)
+    for r_, n in enumerate(lens):
+        h = torch.randint(0, 40, (n,), generator=g)  # a small alphabet: repeated tokens and repeated bigrams occur
+        hist[r_, :n] = h.numpy()
+        x = scores[r_:r_ + 1].clone()
+        ids_row = h[None].to(torch.long)
+        if n > 0:
+            x = RepetitionPenaltyLogitsProcessor(1.2)(ids_row, x)
+        x = NoRepeatNGramLogitsProcessor(3)(ids_row, x)
+        processed[r_] = x[0].numpy()
+        x = TemperatureLogitsWarper(0.9)(ids_row, x)
+        x = TopKLogitsWarper(40)(ids_row, x)
+        x = TopPLogitsWarper(0.9)(ids_row, x)
+        warped[r_] = x[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_generation.npz"), case=np.array(name), greedy_tokens=toks[0],
+                        greedy_margins=margins[0], greedy_proc_tokens=toks[1], greedy_proc_margins=margins[1],
+                        scores=scores.numpy(), hist=hist, hist_len=np.array(lens, np.int32),
+                        processed=processed, warped=warped)
+    print(f"[golden] tiny_generation: greedy tokens {toks[0].tolist()} / with processors {toks[1].tolist()}, min margin "
+          f"{margins[0].min():.3e} / {margins[1].min():.3e}; "
+          f"kept candidates per row {[int(np.isfinite(w).sum()) for w in warped]}")
+
+
 def run_cv_case():
     """Config 1 (baseline_cv.py): dataset builder + collate + CV predictor + evaluate_cv's printed
     minADE/minFDE/minRMSE on 64 synthetic tracks (pickle written to a temp dir)."""
@@ -316,6 +384,7 @@ def main():
         run_model_case(ref, *case)
     for case in CASES[:2]:  # the ragged LoRA case and the ragged no-LoRA (train.py) case
         run_train_case(ref, *case)
+    run_generation_case(ref)
     run_cv_case()
 
 

@@ -1082,6 +1082,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
         if (!DEEP && dma && more2 && (idx & 3) == 3 && (idx >> 2) < EARLY) piece(cur, sn2, idx >> 2);
       }
     }
+    // Last K-tile of an output tile: the accumulators are read next (the epilogue's v_accvgpr_read, but also AGPR-to-AGPR
+    // copies the register allocator may place on the loop-exit edge, BEFORE any statement that follows the loop).  The
+    // compiler cannot see the MFMA write latency behind the inline asm, so the wait states sit here, inside the loop
+    // body, where nothing can be scheduled between them and the last MFMA (one scalar compare + branch per K-tile).
+    if (t == nt - 1) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     cur ^= 1;
     sn1 = sn2;
   };

@@ -850,8 +850,120 @@ class LlamaMultiModal(nn.Module, _Prepared):
         if f[1]:
             raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
 
-    def generate_batch(self, *a, **k):
-        raise NotImplementedError("text generation (train.py:577-654) is outside the trajectory hot path (SURVEY 8f.4)")
+    def generate_batch(self, vision_embs_batch, context_str_list=None, max_new_tokens=50, input_ids=None,
+                       attention_mask=None, do_sample=True, temperature=0.9, top_k=40, top_p=0.9, repetition_penalty=1.2,
+                       no_repeat_ngram_size=3, eos_token_id=None, pad_token_id=0, seed=0, use_graph=True):
+        """Autoregressive text generation (train.py:577-654; scripts/check_generation.py:152-222) on the HIP path.
+
+        Same leading arguments as the reference; the prompt arrives as ``input_ids`` / ``attention_mask`` (right padded,
+        as custom_collate_fn produces them) because no tokenizer can be fetched offline -- with ``self.tokenizer`` set,
+        ``context_str_list`` is tokenised as the reference does and the result is decoded to strings.  Sampling defaults
+        are the reference's (train.py:628-642); ``do_sample=False`` is greedy and bit-reproducible.
+
+        Semantics (DESIGN.md "text generation"): prefix = [16 image tokens | the prompt's valid tokens]; every generated
+        token is embedded as a text token (embed_tokens(id) + text_modality_embedding) at the sample's next position.
+        Prefill = the ordinary batched decoder pass writing a KV cache; then one tcavt_llama_decode_step +
+        tcavt_sample_logits per token, all state on the device, the step replayed as a hipGraph (use_graph).
+        Returns int64 [B, max_new_tokens] token ids (pad_token_id after EOS), or a list of strings with a tokenizer."""
+        from . import capi
+
+        if input_ids is None:
+            if self.tokenizer is None or context_str_list is None:
+                raise NotImplementedError(
+                    "generate_batch needs input_ids / attention_mask: no tokenizer can be fetched offline (train.py:500,590-598)")
+            enc = self.tokenizer(["<image> " + c for c in context_str_list], padding=True, truncation=True, max_length=256,
+                                 return_tensors="pt")
+            input_ids, attention_mask = enc["input_ids"], enc["attention_mask"]
+        dev = vision_embs_batch.device
+        input_ids = input_ids.to(dev).contiguous()
+        attention_mask = (attention_mask if attention_mask is not None else torch.ones_like(input_ids)).to(dev)
+        B, Lt = input_ids.shape
+        LW, ws, P = self.llama_wrapper, self._ws, self._prepared()
+        ll, PL = LW.shape, LW._prepared()
+        H, Nq, N = self.llama_hidden_size, self.qformer.num_query_tokens, int(max_new_tokens)
+        if N < 1:
+            raise ValueError("max_new_tokens must be >= 1")
+        L = Nq + Lt
+        Lmax = L + N
+        nkvw = ll.n_kv_heads * ll.head_dim
+        nqkv = (ll.n_q_heads + 2 * ll.n_kv_heads) * ll.head_dim
+        st = LW.storage
+        i32, i64 = torch.int32, torch.int64
+        with torch.no_grad():
+            was_dctx, LW.dctx, self.qformer.dctx = LW.dctx, None, None  # generation runs eval arithmetic (model.eval() at train.py:581)
+            was_saving, LW.save_for_backward = LW.save_for_backward, False
+            try:
+                # ---- prefill: image tokens + prompt through the decoder, keys / values of every layer into the cache
+                img = self._image_tokens(vision_embs_batch)
+                h = ws.get("gen.h", (B * L, H), torch.float32, dev)
+                flags = ws.get("mm.flags", (2,), i32, dev, zero=True)
+                h16, part = LW.norm_inputs(B * L, dev)
+                ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part)
+                kv_len = ws.get("gen.kvlen", (B,), i32, dev)
+                ops.mask_to_kvlen(attention_mask.to(i64).contiguous(), Nq, kv_len, flags[1:2])
+                self._last_flags = flags
+                kc = ws.get("gen.kc", (ll.layers, B, Lmax, nkvw), st, dev)
+                vc = ws.get("gen.vc", (ll.layers, B, Lmax, nkvw), st, dev)
+                final16 = ws.get("gen.final16", (B * L, H), st, dev)
+                LW.decoder_stack(h, kv_len, B, L, out_bf16=final16, kv_cache=(kc, vc, Lmax))
+                x16 = ws.get("gen.x16", (B, H), st, dev)
+                ops.gather_last(final16, kv_len, x16, B, L, H)
+                logits = ws.get("gen.logits", (B, ll.vocab), torch.float32, dev)
+                ops.gemm_bf16(x16, PL.table, out=logits)  # lm_head, tied to embed_tokens
+                # ---- device-resident generation state
+                history = torch.zeros(B, Lt + N, dtype=i64, device=dev)
+                history[:, :Lt] = input_ids
+                hist_len = (kv_len - Nq).to(i32)
+                step = torch.zeros(1, dtype=i32, device=dev)
+                cur = torch.zeros(B, dtype=i64, device=dev)
+                pos = kv_len.clone()
+                finished = torch.zeros(B, dtype=i32, device=dev)
+                out = torch.full((B, N), int(pad_token_id), dtype=i64, device=dev)
+                sp = capi.SampleParams(float(temperature), float(top_p), float(repetition_penalty), int(top_k),
+                                       int(no_repeat_ngram_size), int(bool(do_sample)),
+                                       -1 if eos_token_id is None else int(eos_token_id), int(pad_token_id),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF)
+                ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=False)
+                if N > 1:
+                    cos, sin = LW._rope_tables(Lmax, dev)
+                    a = capi.DecodeArgs()
+                    bufs = dict(h=ws.get("gen.dh", (B, H), torch.float32, dev), h16=ws.get("gen.dh16", (B, H), st, dev),
+                                part=ws.get("gen.dpart", (B, H // 64), torch.float32, dev),
+                                qkv=ws.get("gen.dqkv", (B, nqkv), st, dev), att=ws.get("gen.datt", (B, ll.n_q_heads * ll.head_dim), st, dev),
+                                act=ws.get("gen.dact", (B, ll.inter), st, dev), t=ws.get("gen.dt", (B, 64), st, dev, zero=True))
+                    for k_, v_ in bufs.items():
+                        setattr(a, k_, v_.data_ptr())
+                    a.layers, a.gamma_final = PL.carr, PL.g_final.data_ptr()
+                    a.rope_cos, a.rope_sin, a.rope_L = cos.data_ptr(), sin.data_ptr(), Lmax
+                    a.table, a.txt_mod = PL.table.data_ptr(), P.txt.data_ptr()
+                    a.cur_tok, a.pos = cur.data_ptr(), pos.data_ptr()
+                    a.k_cache, a.v_cache, a.kv_lmax = kc.data_ptr(), vc.data_ptr(), Lmax
+                    a.x16, a.logits, a.bad_id_flag = x16.data_ptr(), logits.data_ptr(), flags.data_ptr()
+                    a.n_layers, a.B, a.H, a.I, a.nq, a.nkv, a.V = ll.layers, B, H, ll.inter, ll.n_q_heads, ll.n_kv_heads, ll.vocab
+                    a.dtype16 = capi.F16 if st == torch.float16 else capi.BF16
+                    a.rms_eps, a.lora_scale = ll.rms_eps, (LW.lora_alpha / LW.lora_r) if LW.use_lora else 0.0
+
+                    def one_step():
+                        ops.llama_decode_step(a)
+                        ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=True)
+
+                    one_step()  # token 2 eagerly (also the warm-up of every kernel form the step uses)
+                    if N > 2:
+                        if use_graph and dev.type == "cuda":
+                            torch.cuda.synchronize()
+                            graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph):  # capture launches nothing: the N - 2 replays are tokens 3 .. N
+                                one_step()
+                            for _ in range(N - 2):
+                                graph.replay()
+                        else:
+                            for _ in range(N - 2):
+                                one_step()
+            finally:
+                LW.dctx, LW.save_for_backward = was_dctx, was_saving
+        if self.tokenizer is not None:
+            return [self.tokenizer.decode(row, skip_special_tokens=True) for row in out.tolist()]
+        return out
 
 
 # --------------------------------------------------------------------------------------
