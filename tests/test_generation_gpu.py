@@ -1,0 +1,124 @@
+"""Text generation on the HIP path (scripts/train.py:577-654, scripts/check_generation.py:152-222):
+prefill with KV cache + one decode step per token + device-side logits processors / selection, hipGraph replay.
+Token ids are held BIT-EXACT against (1) the continuation the reference model's own HF LlamaForCausalLM produces
+(tests/golden/tiny_generation.npz) and (2) the oracle (oracle/generation.py) -- "bit-exact for token/index selection"."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import GOLDEN, batch_tensors, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev):
+    from tcavt_amd import model
+
+    fx = dict(np.load(os.path.join(GOLDEN, "tiny_generation.npz"), allow_pickle=False))
+    cfg, weights, case = load_case(str(fx["case"]))
+    t = batch_tensors(case)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+    g = {k: v.to(dev) for k, v in t.items()}
+    return fx, cfg, weights, t, g, m
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_greedy_tokens_match_reference_model(gpu, use_graph):
+    fx, cfg, weights, t, g, m = _setup(gpu["device"])
+    N = fx["greedy_tokens"].shape[1]
+    out = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=N, input_ids=g["input_ids"],
+                                attention_mask=g["attention_mask"], do_sample=False, repetition_penalty=1.0,
+                                no_repeat_ngram_size=0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    m.mllm.check_flags()
+    assert out.dtype == torch.int64 and tuple(out.shape) == fx["greedy_tokens"].shape
+    assert np.array_equal(out.cpu().numpy(), fx["greedy_tokens"])  # plain arg-max (margins >= 1.5 in the fixture)
+    # the reference's processors in greedy mode: repetition penalty 1.2 + no-repeat-3-gram (train.py:639-640)
+    out2 = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=N, input_ids=g["input_ids"],
+                                 attention_mask=g["attention_mask"], do_sample=False, repetition_penalty=1.2,
+                                 no_repeat_ngram_size=3, use_graph=use_graph)
+    assert np.array_equal(out2.cpu().numpy(), fx["greedy_proc_tokens"])
+
+
+def test_decode_step_logits_match_oracle_on_growing_sequence(gpu):
+    """The logits of the LAST decode step (KV cache, per-sample RoPE positions, ragged prompts) against the oracle decoder
+    re-run on the whole sequence [image tokens | valid prompt | generated tokens], fp16 contract."""
+    from oracle import generation as G
+
+    dev = gpu["device"]
+    fx, cfg, weights, t, g, m = _setup(dev)
+    N = 7
+    out = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=N, input_ids=g["input_ids"],
+                                attention_mask=g["attention_mask"], do_sample=False, repetition_penalty=1.0,
+                                no_repeat_ngram_size=0, use_graph=True).cpu()
+    B = out.shape[0]
+    logits = m.mllm._ws.get("gen.logits", (B, cfg.llama.vocab), torch.float32, dev).cpu()
+    for b in range(B):
+        n_text = int(t["attention_mask"][b].sum())
+        seq = G.prefix_embeds(weights, cfg, t["vision_emb"], t["input_ids"], "fp16", b, n_text)
+        for tok in out[b, : N - 1]:
+            seq = torch.cat([seq, G.token_embed(weights, tok, "fp16")[None, None]], dim=1)
+        with torch.no_grad():
+            ref = G.next_logits(weights, cfg, seq, "fp16")
+        e = rel_err(logits[b], ref)
+        assert e < 2e-3, (b, e)
+        assert int(ref.argmax()) == int(out[b, N - 1])
+
+
+def test_sampler_kernel_matches_oracle_and_reference_processors(gpu):
+    """tcavt_sample_logits on fixed scores / histories: the token it draws equals the oracle's draw (same Philox uniform,
+    same candidate order) for every (seed, step), and always lies in the set transformers' processors keep."""
+    from oracle import generation as G
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    fx = dict(np.load(os.path.join(GOLDEN, "tiny_generation.npz"), allow_pickle=False))
+    R, V = fx["scores"].shape
+    cap = fx["hist"].shape[1] + 4
+    n_bad = 0
+    for seed in (1, 2, 3):
+        for step0 in (0, 5, 11, 40):
+            logits = torch.from_numpy(fx["scores"]).to(dev).clone()
+            hist = torch.zeros(R, cap, dtype=torch.int64, device=dev)
+            hist[:, : fx["hist"].shape[1]] = torch.from_numpy(np.maximum(fx["hist"], 0)).to(dev)
+            hist_len = torch.from_numpy(fx["hist_len"]).to(dev)
+            step = torch.full((1,), step0, dtype=torch.int32, device=dev)
+            cur = torch.zeros(R, dtype=torch.int64, device=dev)
+            pos = torch.zeros(R, dtype=torch.int32, device=dev)
+            fin = torch.zeros(R, dtype=torch.int32, device=dev)
+            out = torch.full((R, 64), -1, dtype=torch.int64, device=dev)
+            sp = capi.SampleParams(0.9, 0.9, 1.2, 40, 3, 1, -1, 0, seed)
+            ops.sample_logits(logits, hist, hist_len, sp, step, cur, pos, fin, out, advance_pos=True)
+            torch.cuda.synchronize()
+            assert step.item() == step0 + 1 and (pos == 1).all() and (hist_len.cpu().numpy() == fx["hist_len"] + 1).all()
+            for r in range(R):
+                h = fx["hist"][r, : int(fx["hist_len"][r])]
+                x = G.process_logits(fx["scores"][r], h, 1.2, 3)
+                want = G.select_token(x, True, 0.9, 40, 0.9, seed=seed, step=step0, row=r)
+                got = int(out[r, step0].item())
+                assert np.isfinite(fx["warped"][r][got]), (r, got)  # inside the set the reference's warpers keep
+                assert got == int(cur[r].item()) == int(hist[r, int(fx["hist_len"][r])].item())
+                n_bad += got != want
+            # the penalty / bans were applied to the logits in place exactly as transformers applies them
+            proc = logits.cpu().numpy()
+            assert np.array_equal(np.isinf(proc), np.isinf(fx["processed"]))
+            assert np.allclose(proc[np.isfinite(proc)], fx["processed"][np.isfinite(proc)], rtol=1e-6)
+    assert n_bad == 0
+
+
+def test_eos_pads_the_rest_and_sampling_is_reproducible(gpu):
+    fx, cfg, weights, t, g, m = _setup(gpu["device"])
+    kw = dict(max_new_tokens=10, input_ids=g["input_ids"], attention_mask=g["attention_mask"])
+    ref = m.mllm.generate_batch(g["vision_emb"], None, do_sample=False, repetition_penalty=1.2, no_repeat_ngram_size=3, **kw).cpu()
+    eos = int(ref[0, 2])  # the third token of sample 0 becomes EOS: everything after it is the pad token
+    out = m.mllm.generate_batch(g["vision_emb"], None, do_sample=False, repetition_penalty=1.2, no_repeat_ngram_size=3,
+                                eos_token_id=eos, pad_token_id=7, **kw).cpu()
+    first = int((ref[0] == eos).nonzero()[0])
+    assert torch.equal(out[0, : first + 1], ref[0, : first + 1]) and (out[0, first + 1:] == 7).all()
+    a = m.mllm.generate_batch(g["vision_emb"], None, do_sample=True, seed=5, **kw).cpu()
+    b = m.mllm.generate_batch(g["vision_emb"], None, do_sample=True, seed=5, use_graph=False, **kw).cpu()
+    c = m.mllm.generate_batch(g["vision_emb"], None, do_sample=True, seed=6, **kw).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)  # a pure function of the seed; graph replay == eager
+    assert ((a >= 0) & (a < cfg.llama.vocab)).all()
