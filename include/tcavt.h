@@ -477,7 +477,7 @@ typedef struct tcavt_llama_stack_args {
   const float* rope_sin;
   float* h;                        /* fp32 [M][H]: the fused input embeddings; updated in place unless a tape is kept */
   void* h16;                       /* 16-bit [M][H]: copy of h (tcavt_embed_fuse writes it); rewritten by every residual epilogue */
-  float* part;                     /* fp32 [M][H / 64]: partial sums of squares of h's rows (same producers) */
+  float* part;                     /* fp32 [M][>= npart_in], at least [M][H / 16]: partial sums of squares of h's rows (same producers) */
   const int32_t* kv_len;           /* int32 [B] */
   /* workspaces, 16-bit */
   void* qkv;                       /* [M][(nq + 2 nkv) * 64] (unused when the layers carry tape_qkv) */
@@ -499,6 +499,8 @@ typedef struct tcavt_llama_stack_args {
   int32_t n_layers, B, L, H, I, nq, nkv, dtype16;
   int32_t kv_lmax;
   int32_t gemm_tile;               /* tcavt_gemm_args.tile for the four big projections (0 = auto) */
+  int32_t npart_in;                /* partials per row in `part` on entry: must equal tcavt_norm_npart(M, H, I) */
+  int32_t reserved0;
   float rms_eps, lora_scale;       /* lora_scale = alpha / r */
   float lora_dropout_p;            /* > 0: train mode; sites first_site + 2 l (q_proj), first_site + 2 l + 1 (v_proj) */
   uint32_t lora_first_site;
@@ -506,6 +508,11 @@ typedef struct tcavt_llama_stack_args {
 } tcavt_llama_stack_args;
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
+
+/* Number of partial sums of squares per row that a TCAVT_EPI_NORM_OUT product [M][N] over K writes (N / 64, or N / 16 in the
+ * skinny form tcavt_gemm_bf16 selects for M <= 32, K % 256 == 0) -- the `npart` to give tcavt_embed_fuse / tcavt_rownorm_prep
+ * so that the first fused norm of tcavt_llama_stack_forward / tcavt_llama_decode_step reads what it expects (N = H, K = I) */
+int tcavt_norm_npart(int M, int N, int K);
 
 /* x16 = 16-bit copy of x fp32 [M][H], part[M][npart] = (sum of squares of the row, 0, 0, ...): the h16 / part inputs of
  * tcavt_llama_stack_forward for embeddings that do not come from tcavt_embed_fuse (HF-style inputs_embeds call) */
@@ -553,7 +560,7 @@ typedef struct tcavt_decode_args {
   const int32_t* pos;              /* int32 [B]: its position = number of keys already in the cache */
   float* h;                        /* fp32 [B][H] workspace */
   void* h16;                       /* 16-bit [B][H] */
-  float* part;                     /* fp32 [B][H / 64] */
+  float* part;                     /* fp32 [B][H / 16] */
   void* qkv;                       /* 16-bit [B][(nq + 2 nkv) * 64] */
   void* att;                       /* 16-bit [B][nq * 64] */
   void* act;                       /* 16-bit [B][I] */

@@ -415,3 +415,71 @@ def test_gemm_timing_experiment_codes_are_refused(gpu):
     for code in (261, 264, 267):
         with pytest.raises(capi.TcavtError):
             ops.gemm_bf16(a, w, out_dtype=torch.bfloat16, silu_mul=True, tile=code)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 7, 16, 32])
+def test_skinny_gemm_matches_tile_kernels(gpu, M, dt):
+    """The skinny form tcavt_gemm_bf16 selects for M <= 32 rows (decode step of text generation: weights streamed once,
+    eight waves split K) against the tiled kernels (forced tile) on every epilogue the decode step uses: fused-RMSNorm
+    row scale + RoPE at per-row positions + LoRA second K source; row scale + SiLU*up; residual + 16-bit copy + partial
+    sums of squares (one per 16 columns here, one per 64 there: the row sums must agree); plain fp32 (lm_head)."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(100 + M)
+    K, H = 512, 256
+    x = (torch.randn(M, K, generator=g)).to(dt).to(dev)
+    part = (torch.rand(M, 8, generator=g) * 40 + 10).to(dev)
+
+    def run(tile, N, epi, w, out, **kw):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), out.stride(0)
+        a.M, a.N, a.K, a.tile, a.epilogue = M, N, K, tile, epi
+        a.in_dtype, a.out_dtype = ops._DT[dt], ops._DT[out.dtype]
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+        capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()), "gemm")
+        return out
+
+    rs = dict(rowscale_part=part, rowscale_npart=8, rowscale_h=K, rowscale_eps=1e-5)
+    # q|k|v: RoPE at per-row positions, LoRA second source, row scale
+    N = 384
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    t2 = torch.randn(M, 64, generator=g).to(dt).to(dev)
+    w2 = (torch.randn(N, 64, generator=g) * 0.05).to(dt).to(dev)
+    cos, sin = torch.rand(50, 32, generator=g).to(dev), torch.rand(50, 32, generator=g).to(dev)
+    pos = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(dev)
+    kw = dict(A2=t2, lda2=64, W2=w2, ldw2=64, K2=64, rope_cos=cos, rope_sin=sin, rope_L=50, rope_cols=320, rope_pos=pos, **rs)
+    a_ = run(0, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, w, torch.empty(M, N, dtype=dt, device=dev), **kw)
+    b_ = run(128, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, w, torch.empty(M, N, dtype=dt, device=dev), **kw)
+    assert _rel(a_.float(), b_.float()) < (2e-3 if dt == torch.float16 else 8e-3)
+    # gate|up: SiLU * up with row scale
+    N = 512
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    a_ = run(0, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, w, torch.empty(M, N // 2, dtype=dt, device=dev), **rs)
+    b_ = run(128, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, w, torch.empty(M, N // 2, dtype=dt, device=dev), **rs)
+    assert _rel(a_.float(), b_.float()) < (2e-3 if dt == torch.float16 else 8e-3)
+    # o / down: residual + 16-bit copy + partial sums of squares
+    N = H
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for tile, npart in ((0, ops.norm_npart(M, N, K)), (128, N // 64)):
+        assert npart == (N // 16 if tile == 0 else N // 64)
+        h16 = torch.zeros(M, N, dtype=dt, device=dev)
+        pt = torch.zeros(M, npart, device=dev)
+        c = run(tile, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, w, torch.empty(M, N, device=dev), residual=res, ldr=N,
+                norm_h16=h16, norm_part=pt)
+        outs.append((c, h16, pt))
+    (c0, h0, p0), (c1, h1, p1) = outs
+    assert _rel(c0, c1) < 1e-5 and _rel(h0.float(), h1.float()) < 5e-3
+    assert _rel(p0.sum(1), c0.pow(2).sum(1)) < 1e-5 and _rel(p1.sum(1), p0.sum(1)) < 1e-5
+    assert _rel(c0, x.float() @ w.float().T + res) < 1e-5
+    # lm_head: plain fp32 output, N not a multiple of the big tiles
+    N = 1008
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    a_ = run(0, N, 0, w, torch.empty(M, N, device=dev))
+    assert _rel(a_, x.float() @ w.float().T) < 1e-5

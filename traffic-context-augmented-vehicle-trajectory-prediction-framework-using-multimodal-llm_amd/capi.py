@@ -78,7 +78,7 @@ class LlamaStackArgs(ctypes.Structure):
         ("events", ctypes.POINTER(c_void_p)),
         ("n_layers", ctypes.c_int32), ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
         ("I", ctypes.c_int32), ("nq", ctypes.c_int32), ("nkv", ctypes.c_int32), ("dtype16", ctypes.c_int32),
-        ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32),
+        ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32), ("npart_in", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
         ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
     ]
@@ -176,6 +176,7 @@ _SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_gather_last": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_llama_decode_step": [ctypes.POINTER(DecodeArgs), c_void_p],
+    "tcavt_norm_npart": [c_int, c_int, c_int],
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

@@ -86,6 +86,12 @@ __device__ __forceinline__ float from16_hi(unsigned int w) { return from16<F16>(
 
 static inline bool is16(int dtype) { return dtype == TCAVT_BF16 || dtype == TCAVT_F16; }
 
+// tcavt_gemm_bf16 runs its skinny form (csrc/gemm_bf16.hip) for these shapes when no tile is forced ...
+static inline bool skinny_shape(int M, int K) { return M <= 32 && K % 256 == 0; }
+// ... and TCAVT_EPI_NORM_OUT then writes one partial sum of squares per 16 output columns instead of one per 64:
+// the number of partials per row a consumer (TCAVT_EPI_ROWSCALE: rowscale_npart) has to add up
+static inline int norm_out_npart(int M, int N, int K) { return skinny_shape(M, K) ? N / 16 : N / 64; }
+
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

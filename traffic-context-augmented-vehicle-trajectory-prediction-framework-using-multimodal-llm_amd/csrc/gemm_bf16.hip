@@ -1310,6 +1310,166 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
   }
 }
 
+// ===========================================================================
+// Skinny form (M <= 32 rows: the decode step of text generation, one row per sample).  The contraction is a stream of
+// the weight matrix through the chip, HBM-bound; the 256-row tiles above would leave all but a handful of CUs idle
+// (N / 128 workgroups) and spend 8x the MFMA work on padding rows.  Here a workgroup owns NCB blocks of 16 output
+// columns and ALL rows; its eight waves split K, each streaming its slice of the 16 x K weight panel straight from
+// global memory into MFMA A fragments (16 bytes per lane, 64 contiguous bytes per weight row and instruction), with the
+// <= 32 activation rows (L2-resident) as B fragments; the eight partial accumulators meet in LDS and are added in wave
+// order (bit-reproducible).  Epilogues as above; TCAVT_EPI_NORM_OUT writes one partial sum of squares per workgroup
+// (16 columns): norm_out_npart() in common.hpp tells producers and consumers the count.
+// ===========================================================================
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+constexpr int SK_WAVES = 8;
+
+template <int EPI, int NCB, bool F16>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
+  __shared__ f32x4 red[SK_WAVES][NCB * 2][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * (16 * NCB);
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4 acc[NCB][2];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // this wave's K slice: K / 8 (K % 256 == 0), 32 per MFMA step
+  const int kper = p.K / SK_WAVES;
+  const bf16_t* wp[NCB];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(n0 + c * 16 + r16) * p.ldw + wave * kper + kq * 8;
+  const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + wave * kper + kq * 8;
+  const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + wave * kper + kq * 8;
+  const bool two = p.M > 16;
+  constexpr int U = 4;  // k-steps in flight
+  for (int k = 0; k < kper; k += 32 * U) {
+    u32x4 wf[U][NCB], x0[U], x1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + 32 * u < kper) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + k + 32 * u);
+        x0[u] = *reinterpret_cast<const u32x4*>(xp0 + k + 32 * u);
+        if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + k + 32 * u);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + 32 * u < kper) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          acc[c][0] = mfma16<F16>(wf[u][c], x0[u], acc[c][0]);
+          if (two) acc[c][1] = mfma16<F16>(wf[u][c], x1[u], acc[c][1]);
+        }
+      }
+    }
+  }
+  if constexpr (EPI == EPI_ROPE) {  // LoRA second K source (K2 = 64: two steps), done by wave 0
+    if (p.K2 > 0 && wave == 0) {
+      for (int k = 0; k < p.K2; k += 32) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(r16, p.M - 1) * p.lda2 + k + kq * 8);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + k + kq * 8);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          const u32x4 w2 = *reinterpret_cast<const u32x4*>(p.W2 + (long)(n0 + c * 16 + r16) * p.ldw2 + k + kq * 8);
+          acc[c][0] = mfma16<F16>(w2, a0, acc[c][0]);
+          if (two) acc[c][1] = mfma16<F16>(w2, a1, acc[c][1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) {
+    red[wave][c * 2][lane] = acc[c][0];
+    red[wave][c * 2 + 1][lane] = acc[c][1];
+  }
+  __syncthreads();
+  if (wave >= 2 || (wave == 1 && !two)) return;
+  // ---- wave mb (0 / 1) finishes token block mb: lane holds features 4 (lane >> 4) .. + 3 of every column block for
+  // token m = 16 mb + (lane & 15); the partials are added in wave order
+  const int mb = wave;
+  const int m = mb * 16 + r16, nq = 4 * kq;
+  const bool rowok = m < p.M;
+  const long mm = rowok ? m : 0;
+  f32x4 v[NCB];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) {
+    f32x4 t = red[0][c * 2 + mb][lane];
+#pragma unroll
+    for (int w = 1; w < SK_WAVES; ++w) t += red[w][c * 2 + mb][lane];
+    v[c] = t;
+  }
+  float rs = 1.f;
+  if constexpr (EPI == EPI_SILU || EPI == EPI_ROPE) {
+    if (p.rs_part) rs = row_rscale(p, mm);
+  }
+  constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
+  if constexpr (EPI == EPI_GENERIC) {
+    if (!rowok) return;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) store_quad(p, m, n0 + c * 16 + nq, v[c] * p.acc_scale);
+  } else if constexpr (EPI == EPI_NORM) {
+    const bool res = p.flags & TCAVT_EPI_RESIDUAL;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+      f32x4 o = v[c];
+      const long off = mm * p.ldc + n0 + c * 16 + nq;
+      if (res) o += *reinterpret_cast<const f32x4*>(p.residual + mm * p.ldr + n0 + c * 16 + nq);
+      if (rowok) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
+        *reinterpret_cast<u32x2*>(p.norm_h16 + off) = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+      }
+      ss += o[0] * o[0];
+      ss += o[1] * o[1];
+      ss += o[2] * o[2];
+      ss += o[3] * o[3];
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (lane < 16 && rowok) p.norm_part[(long)m * gridDim.x + blockIdx.x] = ss;
+  } else if constexpr (EPI == EPI_SILU) {
+    static_assert(EPI != EPI_SILU || NCB == 2, "gate block + up block");
+    if (!rowok) return;
+    const f32x4 g = v[0] * rs, u = v[NCB - 1] * rs;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = silu_mul(g[e], u[e]);
+    store_quad(p, m, (n0 >> 1) + nq, o);
+  } else {  // EPI_ROPE: 64 columns = one head
+    static_assert(EPI != EPI_ROPE || NCB == 4, "one head per workgroup");
+    if (!rowok) return;
+    const bool rot = n0 < p.rope_cols;
+    const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 lo = v[i] * rs, hi = v[(i + 2) % NCB] * rs;
+      if (rot) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + i * 16 + nq);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + i * 16 + nq);
+        const f32x4 l2 = lo * c - hi * sn, h2 = hi * c + lo * sn;
+        lo = l2;
+        hi = h2;
+      }
+      store_quad(p, m, n0 + i * 16 + nq, lo);
+      store_quad(p, m, n0 + 32 + i * 16 + nq, hi);
+    }
+  }
+  (void)OUT16;
+}
+
+template <int EPI, int NCB, bool F16>
+static int launch_skinny(const GemmP& p, hipStream_t stream) {
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(p.N / (16 * NCB)), dim3(SK_WAVES * 64), 0, stream, p);
+  TCAVT_CHECK_LAUNCH("gemm_bf16(skinny)");
+  return TCAVT_OK;
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -1429,6 +1589,19 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   if (epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE))
     TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
 
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // ---- skinny form: M <= 32 rows (decode step), auto-selected only (tile == 0); norm_out_npart() mirrors this rule
+  if (a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f && a->lda >= a->K) {
+    const int e0 = a->epilogue & ~TCAVT_EPI_ROWSCALE;
+    if (e0 == TCAVT_EPI_ROPE && a->N % 64 == 0 && (K2 == 0 || K2 % 32 == 0))
+      return f16 ? launch_skinny<EPI_ROPE, 4, true>(p, s) : launch_skinny<EPI_ROPE, 4, false>(p, s);
+    if (e0 == TCAVT_EPI_SILU_MUL && !a->silu_preact && a->N % 32 == 0)
+      return f16 ? launch_skinny<EPI_SILU, 2, true>(p, s) : launch_skinny<EPI_SILU, 2, false>(p, s);
+    if ((e0 & TCAVT_EPI_NORM_OUT) && a->N % 16 == 0)
+      return f16 ? launch_skinny<EPI_NORM, 1, true>(p, s) : launch_skinny<EPI_NORM, 1, false>(p, s);
+    if (e0 == 0 && K2 == 0 && a->N % 16 == 0)
+      return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
+  }
   int tile = a->tile;
   if (tile == 0) {
     // 256x256 tiles when whole waves of 256 workgroups stay >= 75 % full (the fused q|k|v projection,
@@ -1452,7 +1625,6 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       if (tile == 257 && !(epi & TCAVT_EPI_ROPE) && a->K >= 4096) tile = 272;
     }
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (epi & TCAVT_EPI_SILU_MUL) {
     if (a->silu_preact) {
       TCAVT_CHECK_ARG(aligned16(a->silu_preact) && a->ld_preact >= a->N && a->ld_preact % 4 == 0,

@@ -104,6 +104,8 @@ struct SampleP {
 
 constexpr int SMP_T = 1024;   // threads
 constexpr int SMP_CAP = 256;  // candidate list capacity (top_k + ties)
+constexpr int SMP_BINS = 2048;  // histogram of (max - score) * 64: covers 32 units below the maximum
+constexpr int SMP_LIST = 1024;  // pre-selected scores (everything down to the threshold bin)
 
 __device__ __forceinline__ bool after(float v, int i, float pv, int pi) {  // (v, i) comes after (pv, pi) in (value desc, index asc) order
   return v < pv || (v == pv && i > pi);
@@ -123,6 +125,10 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   __shared__ int ri[SMP_T / 64];
   __shared__ float bestv;
   __shared__ int besti;
+  __shared__ int hist_bins[SMP_BINS];
+  __shared__ float list_v[SMP_LIST];
+  __shared__ int list_i[SMP_LIST];
+  __shared__ int list_n, thr_bin;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* x = logits + (long)b * V;
   long* hist = history + (long)b * hist_cap;
@@ -183,23 +189,91 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     next_best(INFINITY, -1, 1.f);
     tok = besti;
   } else {
+    // Candidate collection in three passes over the vocabulary instead of one pass per candidate: (1) the maximum,
+    // (2) a histogram of (max - score) in 1/64-wide bins (integer counts: order-independent), from which the narrowest
+    // threshold that keeps at least top_k scores follows, (3) everything at or above that threshold goes to an LDS list
+    // (top_k + the rest of the threshold bin; insertion order does not matter, the selection below orders by
+    // (value, index)).  The list is then ordered by top_k rounds of a wave-level arg-max over <= SMP_LIST entries.
     const float invT = 1.f / sp.temperature;
-    int n = 0;
-    float pv = INFINITY;
-    int pi = -1;
+    next_best(INFINITY, -1, invT);
+    const float gmax = bestv;
     const int k = min(max(sp.top_k, 1), SMP_CAP);
-    for (;;) {
-      next_best(pv, pi, invT);
-      const float v = bestv;
-      const int i = besti;
-      if (i == 0x7fffffff || v == -INFINITY) break;        // nothing (finite) left
-      if (n >= k && !(v == cv[k - 1])) break;               // beyond top-k and not a tie with the k-th value
-      if (n >= SMP_CAP) break;
-      if (tid == 0) { cv[n] = v; ci[n] = i; }
-      ++n;
-      pv = v;
-      pi = i;
+    for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
+    if (tid == 0) list_n = 0;
+    __syncthreads();
+    for (int i = tid; i < V; i += SMP_T) {
+      const float d = (gmax - x[i] * invT) * 64.f;
+      if (d < (float)SMP_BINS) atomicAdd(&hist_bins[(int)d], 1);  // (-inf scores: d = +inf, skipped)
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, tb = SMP_BINS - 1;
+      for (int i = 0; i < SMP_BINS; ++i) {
+        cum += hist_bins[i];
+        if (cum >= k) { tb = i; break; }
+      }
+      thr_bin = (cum >= k && cum <= SMP_LIST) ? tb : -1;  // -1: too few scores in range or too many in the bin -> exact fallback
+    }
+    __syncthreads();
+    int n = 0;
+    if (thr_bin >= 0) {
+      const float lim = (float)(thr_bin + 1);
+      for (int i = tid; i < V; i += SMP_T) {
+        const float v = x[i] * invT;
+        if ((gmax - v) * 64.f < lim) {
+          const int slot = atomicAdd(&list_n, 1);
+          if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = i; }
+        }
+      }
       __syncthreads();
+      const int ln = min(list_n, SMP_LIST);
+      if (wv == 0) {  // one wave orders the list: round r picks the next entry in (value desc, index asc) order
+        float pv = INFINITY;
+        int pi = -1;
+        for (;;) {
+          float bv = -INFINITY;
+          int bi = 0x7fffffff;
+          for (int j = lane; j < ln; j += 64) {
+            const float v = list_v[j];
+            const int i = list_i[j];
+            if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+          }
+          if (bi == 0x7fffffff) break;
+          if (n >= k && !(bv == cv[k - 1])) break;  // beyond top-k and not a tie with the k-th value
+          if (n >= SMP_CAP) break;
+          if (lane == 0) { cv[n] = bv; ci[n] = bi; }
+          ++n;
+          pv = bv;
+          pi = bi;
+          __builtin_amdgcn_s_waitcnt(0);
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) list_n = n;
+      }
+      __syncthreads();
+      n = list_n;
+    } else {  // exact fallback: one pass over the vocabulary per candidate
+      float pv = INFINITY;
+      int pi = -1;
+      for (;;) {
+        next_best(pv, pi, invT);
+        const float v = bestv;
+        const int i = besti;
+        if (i == 0x7fffffff || v == -INFINITY) break;        // nothing (finite) left
+        if (n >= k && !(v == cv[k - 1])) break;               // beyond top-k and not a tie with the k-th value
+        if (n >= SMP_CAP) break;
+        if (tid == 0) { cv[n] = v; ci[n] = i; }
+        ++n;
+        pv = v;
+        pi = i;
+        __syncthreads();
+      }
     }
     if (tid == 0) {
       // softmax over the kept candidates (descending), top-p: drop the low tail whose cumulative probability, counted
@@ -304,12 +378,13 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
                       a->nq / a->nkv <= 8 && a->V > 0 && a->V % 16 == 0 && a->kv_lmax > 0 && a->rope_L >= a->kv_lmax && is16(a->dtype16),
                   "llama_decode_step: bad shape (H %% 256, V %% 16, nq / nkv <= 8, rope_L >= kv_lmax)");
   const int B = a->B, H = a->H, I = a->I, nq = a->nq, nkv = a->nkv, dt = a->dtype16;
-  const int nqkv = (nq + 2 * nkv) * 64, npart = H / 64;
+  const int nqkv = (nq + 2 * nkv) * 64;
+  const int np_in = norm_out_npart(B, H, I), np_post = norm_out_npart(B, H, nq * 64);  // see csrc/stack.hip
   hipStream_t st = static_cast<hipStream_t>(stream);
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
   TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->h /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
-                             a->bad_id_flag, dt, a->h16, a->part, npart, stream));
+                             a->bad_id_flag, dt, a->h16, a->part, np_in, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
   const size_t lds = (size_t)(nq / nkv) * a->kv_lmax * sizeof(float);
   TCAVT_CHECK_ARG(lds <= 64 * 1024, "llama_decode_step: kv_lmax = %d too long for the decode attention's score buffer", a->kv_lmax);
@@ -330,7 +405,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->rope_L; g.rope_cols = (nq + nkv) * 64;
       g.rope_pos = a->pos;
-      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     bf16_t* kc = static_cast<bf16_t*>(a->k_cache) + li * per_layer;
@@ -357,7 +432,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
       g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
-      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {

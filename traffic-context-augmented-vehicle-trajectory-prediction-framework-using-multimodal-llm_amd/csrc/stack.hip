@@ -63,7 +63,12 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
   TCAVT_CHECK_ARG((a->k_cache == nullptr) == (a->v_cache == nullptr) && (!a->k_cache || a->kv_lmax >= a->L),
                   "llama_stack_forward: k_cache / v_cache go together, kv_lmax >= L");
   const int M = a->B * a->L, H = a->H, I = a->I, nq = a->nq, nkv = a->nkv;
-  const int nqkv = (nq + 2 * nkv) * 64, npart = H / 64, dt = a->dtype16;
+  const int nqkv = (nq + 2 * nkv) * 64, dt = a->dtype16;
+  // partial sums of squares per row: what the producer of each fused norm's input writes (embedding kernel and down_proj
+  // for the input norm, o_proj for the post-attention norm); tiny shapes (M <= 32) run the skinny GEMM form, which writes
+  // one per 16 columns instead of one per 64
+  const int np_in = norm_out_npart(M, H, I), np_post = norm_out_npart(M, H, nq * 64);
+  TCAVT_CHECK_ARG(a->npart_in == np_in, "llama_stack_forward: npart_in = %d, but h16 / part must carry tcavt_norm_npart(M, H, I) = %d partials per row", a->npart_in, np_in);
   const float scale = 0.125f;  // 1 / sqrt(head_dim 64)
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* h = a->h;
@@ -110,7 +115,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       if (w.a_cat) { g.A2 = t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->L; g.rope_cols = (nq + nkv) * 64;
-      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
       ev.rec(0);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
       ev.rec(1);
@@ -143,7 +148,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
       g.M = M; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
-      g.rowscale_part = a->part; g.rowscale_npart = npart; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
       if (tape) { g.silu_preact = w.tape_gu; g.ld_preact = 2 * I; }
       ev.rec(6);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -165,6 +170,8 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
   // final RMSNorm: its fp32 result is hidden_states[-1] (scripts/train.py:553), the 16-bit copy feeds the head's K / V projections
   return tcavt_rmsnorm(h, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, nullptr, 0.f, 0, 0, dt, stream);
 }
+
+extern "C" int tcavt_norm_npart(int M, int N, int K) { return norm_out_npart(M, N, K); }
 
 extern "C" int tcavt_events_create(void** events, int n) {
   TCAVT_CHECK_ARG(events && n > 0, "events_create: bad args");

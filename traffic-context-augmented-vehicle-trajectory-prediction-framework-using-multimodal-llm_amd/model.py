@@ -610,7 +610,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         the fused RMSNorms read (written by tcavt_embed_fuse / ops.rownorm_prep for layer 0, by the residual epilogues
         afterwards)."""
         H = self.shape.hidden
-        return (self._ws.get("ll.h16", (M, H), self.storage, dev), self._ws.get("ll.part", (M, H // 64), torch.float32, dev))
+        return (self._ws.get("ll.h16", (M, H), self.storage, dev), self._ws.get("ll.part", (M, H // 16), torch.float32, dev))
+
+    def norm_npart(self, M):
+        """Partials per row the first fused norm of a pass over M rows reads (what embed_fuse / rownorm_prep must write)."""
+        return ops.norm_npart(M, self.shape.hidden, self.shape.inter)
 
     def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None, kv_cache=None):
         """h: fp32 [B*L, H] residual stream (updated in place unless a tape is kept); its norm_inputs() must have been
@@ -704,6 +708,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         args.n_layers, args.B, args.L, args.H, args.I = ll.layers, B, L, H, ll.inter
         args.nq, args.nkv, args.dtype16 = nq, nkv, capi.F16 if self.storage == torch.float16 else capi.BF16
         args.gemm_tile = self.gemm_tile
+        args.npart_in = self.norm_npart(M)
         args.rms_eps = ll.rms_eps
         args.lora_scale = (self.lora_alpha / self.lora_r) if self.use_lora else 0.0
         ops.llama_stack_forward(args)
@@ -715,7 +720,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         dev = inputs_embeds.device
         h = self._ws.get("ll.h", (B * L, H), torch.float32, dev)
         h.copy_(inputs_embeds.reshape(B * L, H))
-        ops.rownorm_prep(h, *self.norm_inputs(B * L, dev))
+        ops.rownorm_prep(h, *self.norm_inputs(B * L, dev), npart=self.norm_npart(B * L))
         kv_len = torch.empty(B, dtype=torch.int32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), 0, kv_len, flag)
@@ -823,7 +828,8 @@ class LlamaMultiModal(nn.Module, _Prepared):
         # clears them (evaluate_model and Trainer.check_flags do; one host sync, off the hot path)
         flags = ws.get("mm.flags", (2,), torch.int32, dev, zero=True)
         h16, part = LW.norm_inputs(B * L, dev)
-        ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part)
+        ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part,
+                       npart=LW.norm_npart(B * L))
         if dev.type == "cuda" and self._pf_stream is not None:
             self._img_consumed = torch.cuda.Event()
             self._img_consumed.record()
@@ -898,7 +904,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 h = ws.get("gen.h", (B * L, H), torch.float32, dev)
                 flags = ws.get("mm.flags", (2,), i32, dev, zero=True)
                 h16, part = LW.norm_inputs(B * L, dev)
-                ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part)
+                ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part, npart=LW.norm_npart(B * L))
                 kv_len = ws.get("gen.kvlen", (B,), i32, dev)
                 ops.mask_to_kvlen(attention_mask.to(i64).contiguous(), Nq, kv_len, flags[1:2])
                 self._last_flags = flags
@@ -928,7 +934,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     cos, sin = LW._rope_tables(Lmax, dev)
                     a = capi.DecodeArgs()
                     bufs = dict(h=ws.get("gen.dh", (B, H), torch.float32, dev), h16=ws.get("gen.dh16", (B, H), st, dev),
-                                part=ws.get("gen.dpart", (B, H // 64), torch.float32, dev),
+                                part=ws.get("gen.dpart", (B, H // 16), torch.float32, dev),
                                 qkv=ws.get("gen.dqkv", (B, nqkv), st, dev), att=ws.get("gen.datt", (B, ll.n_q_heads * ll.head_dim), st, dev),
                                 act=ws.get("gen.dact", (B, ll.inter), st, dev), t=ws.get("gen.dt", (B, 64), st, dev, zero=True))
                     for k_, v_ in bufs.items():

@@ -260,7 +260,12 @@ def cast_bf16(x, out=None):
     return cast16(x, out, torch.bfloat16)
 
 
-def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=None):
+def norm_npart(M, N, K):
+    """Partial sums of squares per row that a NORM_OUT product [M, N] over K writes (tcavt_norm_npart)."""
+    return int(lib().tcavt_norm_npart(int(M), int(N), int(K)))
+
+
+def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=None, npart=None):
     """h16 / part (both or neither): the 16-bit copy of h and its rows' partial sums of squares [rows, H / 64] -- the
     inputs of the first decoder layer's fused RMSNorm (tcavt_llama_stack_forward)."""
     _req16(table, "embed.table")
@@ -280,7 +285,7 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=No
     if h16 is not None:
         _req16(h16, "embed.h16", like=table)
         _req(part, torch.float32, "embed.part")
-        npart = H // 64
+        npart = npart or H // 64
         _need(h16, B * (Nq + Lt) * H, "embed.h16")
         _need(part, B * (Nq + Lt) * npart, "embed.part")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
@@ -748,13 +753,13 @@ def llama_decode_step(args):
     check(lib().tcavt_llama_decode_step(ctypes.byref(args), stream_ptr()), "tcavt_llama_decode_step")
 
 
-def rownorm_prep(x, x16, part):
-    """x16 = 16-bit copy of x [M, H]; part [M, H / 64] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm."""
+def rownorm_prep(x, x16, part, npart=None):
+    """x16 = 16-bit copy of x [M, H]; part [M, npart] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm."""
     _req(x, torch.float32, "rownorm_prep.x")
     _req16(x16, "rownorm_prep.x16")
     _req(part, torch.float32, "rownorm_prep.part")
     M, H = x.shape
-    npart = H // 64
+    npart = npart or H // 64
     _need(x16, M * H, "rownorm_prep.x16")
     _need(part, M * npart, "rownorm_prep.part")
     check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], stream_ptr()), "tcavt_rownorm_prep")
