@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 }
 
 // One query per (sample, query head) over the cached keys 0 .. pos[b] (the new token's own key included).
-// One workgroup per (sample, kv head), one wave per query head of the group; lane = head dimension.
+// One workgroup per (sample, kv head), one wave per query head of the group.  Scores: lane = key (each lane reads its
+// key's 128-byte row and keeps the whole query in registers), softmax across the lanes; output: lane = head dimension,
+// one coalesced 128-byte value row per key with the probability broadcast from LDS.
 template <bool F16>
 __global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ vc, const int* __restrict__ pos,
@@ -49,18 +51,39 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restri
   const int head = kvh * group + wv;
   const int n = min(pos[b] + 1, lmax);
   const int ld = (nq + 2 * nkv) * 64, w = nkv * 64;
-  const float q = from16<F16>(qkv[(long)b * ld + head * 64 + lane]);
   const bf16_t* kb = kc + (long)b * lmax * w + kvh * 64;
   const bf16_t* vb = vc + (long)b * lmax * w + kvh * 64;
   float* s = sc + wv * lmax;
+  float q[64];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(qkv + (long)b * ld + head * 64);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 t = qp[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q[c * 8 + 2 * e] = from16_lo<F16>(t[e]) * scale;
+        q[c * 8 + 2 * e + 1] = from16_hi<F16>(t[e]) * scale;
+      }
+    }
+  }
   float mx = -1e30f;
-  for (int j = 0; j < n; ++j) {
-    const float d = wave_sum(q * from16<F16>(kb[(long)j * w + lane])) * scale;
-    if (lane == 0) s[j] = d;
+  for (int j = lane; j < n; j += 64) {
+    const u32x4* kp = reinterpret_cast<const u32x4*>(kb + (long)j * w);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 t = kp[c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d = fmaf(q[c * 8 + 2 * e], from16_lo<F16>(t[e]), d);
+        d = fmaf(q[c * 8 + 2 * e + 1], from16_hi<F16>(t[e]), d);
+      }
+    }
+    s[j] = d;
     mx = fmaxf(mx, d);
   }
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
+  mx = wave_max(mx);
   float sum = 0.f;
   for (int j = lane; j < n; j += 64) {
     const float e = __expf(s[j] - mx);
@@ -68,14 +91,20 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restri
     sum += e;
   }
   sum = wave_sum(sum);
+  __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   const float inv = 1.f / sum;
-  float o = 0.f;
-  for (int j = 0; j < n; ++j) {
-    const float p = f16_to_f32(f32_to_f16(s[j] * inv));  // probabilities are carried in fp16, as in the prefill kernel
-    o = fmaf(p, from16<F16>(vb[(long)j * w + lane]), o);
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;  // four independent chains over the keys
+  int j = 0;
+  for (; j + 3 < n; j += 4) {
+    // probabilities are carried in fp16, as in the prefill kernel
+    o0 = fmaf(f16_to_f32(f32_to_f16(s[j] * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
+    o1 = fmaf(f16_to_f32(f32_to_f16(s[j + 1] * inv)), from16<F16>(vb[(long)(j + 1) * w + lane]), o1);
+    o2 = fmaf(f16_to_f32(f32_to_f16(s[j + 2] * inv)), from16<F16>(vb[(long)(j + 2) * w + lane]), o2);
+    o3 = fmaf(f16_to_f32(f32_to_f16(s[j + 3] * inv)), from16<F16>(vb[(long)(j + 3) * w + lane]), o3);
   }
-  out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
+  for (; j < n; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(s[j] * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
+  out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>((o0 + o1) + (o2 + o3));
 }
 
 // out[b] = src[b * L + kv_len[b] - 1]  (the last valid position's hidden state of each sample after the prefill)
@@ -189,20 +218,37 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     next_best(INFINITY, -1, 1.f);
     tok = besti;
   } else {
-    // Candidate collection in three passes over the vocabulary instead of one pass per candidate: (1) the maximum,
-    // (2) a histogram of (max - score) in 1/64-wide bins (integer counts: order-independent), from which the narrowest
+    // Candidate collection in four passes over the vocabulary instead of one pass per candidate: (1) the maximum and the
+    // minimum, (2) a histogram of (max - score) in SMP_BINS bins over that range (integer counts: order-independent), from which the narrowest
     // threshold that keeps at least top_k scores follows, (3) everything at or above that threshold goes to an LDS list
     // (top_k + the rest of the threshold bin; insertion order does not matter, the selection below orders by
     // (value, index)).  The list is then ordered by top_k rounds of a wave-level arg-max over <= SMP_LIST entries.
     const float invT = 1.f / sp.temperature;
     next_best(INFINITY, -1, invT);
     const float gmax = bestv;
+    // bin width from the spread of the finite scores: SMP_BINS bins between the maximum and the minimum
+    float lmin = INFINITY;
+    for (int i = tid; i < V; i += SMP_T) {
+      const float v = x[i] * invT;
+      if (v > -INFINITY) lmin = fminf(lmin, v);
+    }
+    lmin = -wave_max(-lmin);
+    if (lane == 0) rv[wv] = lmin;
+    __syncthreads();
+    if (tid == 0) {
+      float m_ = rv[0];
+      for (int q_ = 1; q_ < SMP_T / 64; ++q_) m_ = fminf(m_, rv[q_]);
+      bestv = m_;
+    }
+    __syncthreads();
+    const float bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - bestv, 1e-20f);
+    __syncthreads();
     const int k = min(max(sp.top_k, 1), SMP_CAP);
     for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
     if (tid == 0) list_n = 0;
     __syncthreads();
     for (int i = tid; i < V; i += SMP_T) {
-      const float d = (gmax - x[i] * invT) * 64.f;
+      const float d = (gmax - x[i] * invT) * bscale;
       if (d < (float)SMP_BINS) atomicAdd(&hist_bins[(int)d], 1);  // (-inf scores: d = +inf, skipped)
     }
     __syncthreads();
@@ -220,7 +266,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       const float lim = (float)(thr_bin + 1);
       for (int i = tid; i < V; i += SMP_T) {
         const float v = x[i] * invT;
-        if ((gmax - v) * 64.f < lim) {
+        if ((gmax - v) * bscale < lim) {
           const int slot = atomicAdd(&list_n, 1);
           if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = i; }
         }
