@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-2 evidence in one GPU call: the driver-style bench line, the rocprofv3 --kernel-trace --stats summary of the SAME
+# command, and the PMC passes (separate runs, --pmc with --kernel-trace only) of the dominant kernel.  Everything lands
+# under gpurun_out/r02/; the summaries that are cited get copied to profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r02; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -2 $O/bench_default.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_step.log 2>&1; echo "rocprof rc=$?"
+for sh in gateup down o; do
+  D=/tmp/pmc_r02_$sh; rm -rf $D; i=0
+  for c in "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout -k 10 120 rocprofv3 --pmc $c --kernel-trace -d $D/p$i -o p -- python3 $R/tools/pmc_gemm.py 0 $sh > $D.log 2>&1 || echo "pass failed: $sh $c"
+  done
+  python3 $R/tools/pmc_parse.py $D > $O/pmc_$sh.json; echo "pmc $sh done"
+done

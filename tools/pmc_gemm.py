@@ -20,16 +20,40 @@ if shape == "attn":  # the decoder attention kernel on the bench shape: B=32, L=
     print("done")
     sys.exit(0)
 M, N, K = {"gateup": (8192, 16384, 2048), "down": (8192, 2048, 8192), "o": (8192, 2048, 2048)}[shape]
-a = torch.randn(M, K, device=dev).to(torch.bfloat16)
-ws = [(torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16) for _ in range(4)]
-out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev) if shape == "gateup" else torch.randn(M, N, device=dev)
+# round 2: the decoder's forms -- fp16 operands, gate|up with the fused-RMSNorm row scale, o / down with the NORM_OUT
+# epilogue (fp32 residual stream + 16-bit copy + partial sums of squares); "plain" as argv[3] gives round 1's forms
+import ctypes
+dt = torch.bfloat16 if "bf16" in sys.argv[3:] else torch.float16
+plain = "plain" in sys.argv[3:]
+a = torch.randn(M, K, device=dev).to(dt)
+ws = [(torch.randn(N, K, device=dev) * 0.02).to(dt) for _ in range(4)]
+out = torch.empty(M, N // 2, dtype=dt, device=dev) if shape == "gateup" else torch.randn(M, N, device=dev)
+part = torch.rand(M, K // 64, device=dev) + 0.5
+h16 = torch.empty(M, N, dtype=dt, device=dev)
+pout = torch.empty(M, N // 64, device=dev)
+
+
+def raw(w, epi, **kw):
+    g = capi.GemmArgs()
+    g.A, g.lda, g.W, g.ldw, g.C, g.ldc = a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), out.stride(0)
+    g.M, g.N, g.K, g.tile, g.epilogue = M, N, K, int(which), epi
+    g.in_dtype, g.out_dtype = ops._DT[dt], ops._DT[out.dtype]
+    for k_, v_ in kw.items():
+        setattr(g, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+    capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(g), capi.stream_ptr()), "gemm")
+
+
 for i in range(8):
     if which == "lib":
         torch.nn.functional.linear(a, ws[i % 4])
-    else:
-        if shape == "gateup":
-            ops.gemm_bf16(a, ws[i % 4], out=out, tile=int(which), silu_mul=True)
+    elif shape == "gateup":
+        if plain:
+            raw(ws[i % 4], capi.EPI_SILU_MUL)
         else:
-            ops.gemm_bf16(a, ws[i % 4], out=out, residual=out, tile=int(which))
+            raw(ws[i % 4], capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, rowscale_part=part, rowscale_npart=K // 64, rowscale_h=K, rowscale_eps=1e-5)
+    elif plain:
+        raw(ws[i % 4], capi.EPI_RESIDUAL, residual=out, ldr=N)
+    else:
+        raw(ws[i % 4], capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, residual=out, ldr=N, norm_h16=h16, norm_part=pout)
 torch.cuda.synchronize()
 print("done")

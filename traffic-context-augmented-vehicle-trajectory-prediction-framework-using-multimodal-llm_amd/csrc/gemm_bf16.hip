@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + wave * kper + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + wave * kper + kq * 8;
   const bool two = p.M > 16;
-  constexpr int U = 8;  // k-steps in flight (8 x 16 bytes per lane and operand)
+  constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms)
   for (int k = 0; k < kper; k += 32 * U) {
     u32x4 wf[U][NCB], x0[U], x1[U];
 #pragma unroll
