@@ -484,7 +484,7 @@ typedef struct tcavt_llama_stack_args {
   void* att;                       /* [M][nq * 64] */
   void* act;                       /* [M][I] */
   void* t;                         /* [M][64], zero-initialised once by the caller (columns >= 32 are never written) */
-  void* xq;                        /* [M][H] x 2 (lora_dropout_p > 0 only): dropped copies of h16 for the two adapters */
+  void* xq;                        /* unused (kept for layout stability): the adapters' dropout masks are applied inside tcavt_lora_down */
   void* xv;
   /* outputs */
   float* out_f32;                  /* fp32 [M][H] or NULL: hidden_states[-1] (scripts/train.py:553) */
@@ -508,6 +508,14 @@ typedef struct tcavt_llama_stack_args {
 } tcavt_llama_stack_args;
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
+
+/* LoRA down-projection of both adapters in one pass over x16 [M][H] (the 16-bit residual-stream copy):
+ *   t[m][0:16] = scale * (mask_q o x16[m]) . a_cat[0:16]^T,   t[m][16:32] = scale * (mask_v o x16[m]) . a_cat[16:32]^T
+ * t is 16-bit [M][64] (columns >= 32 untouched).  dropout_p > 0: PEFT's per-adapter lora_dropout (scripts/train.py:433-439)
+ * with the Philox masks of (dropout_seed, site_q / site_v, element m * H + k), the masked operand rounded as tcavt_dropout
+ * rounds it; dropout_p == 0: no masks. */
+int tcavt_lora_down(const void* x16, const void* a_cat, void* t, int M, int H, float scale, float dropout_p,
+                    uint64_t dropout_seed, uint32_t site_q, uint32_t site_v, int dtype16, tcavt_stream_t stream);
 
 /* Number of partial sums of squares per row that a TCAVT_EPI_NORM_OUT product [M][N] over K writes (N / 64, or N / 16 in the
  * skinny form tcavt_gemm_bf16 selects for M <= 32, K % 256 == 0) -- the `npart` to give tcavt_embed_fuse / tcavt_rownorm_prep

@@ -160,3 +160,36 @@ def test_k_candidates_reuse_llm_prefix(gpu):
     assert m._llm_cache is None and not m.training
     for k in ("ADE", "FDE", "RMSE"):
         assert abs(full[k] - fast[k]) <= 1e-6 * abs(full[k]), (k, full[k], fast[k])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_lora_down_fused_masks(gpu, dt, p):
+    """tcavt_lora_down: both adapters' down-projections in one pass, each under its own Philox site (PEFT: one lora_dropout
+    module per adapted Linear, scripts/train.py:433-439) -- against dropout(x) rounded to 16 bits, then the fp32 product."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(8)
+    M, H, r, s = 100, 256, 8, 4.0
+    x = torch.randn(M, H, generator=g).to(dt).to(dev)
+    a_cat = torch.zeros(64, H, dtype=dt, device=dev)
+    a_cat[:r] = (torch.randn(r, H, generator=g) * 0.05).to(dt).to(dev)
+    a_cat[16:16 + r] = (torch.randn(r, H, generator=g) * 0.05).to(dt).to(dev)
+    t = torch.zeros(M, 64, dtype=dt, device=dev)
+    seed, site = 0xABCDEF12345, 77
+    ops.lora_down(x, a_cat, t, s, dropout=(p, seed, site) if p > 0 else None)
+    torch.cuda.synchronize()
+    for blk, st in ((0, site), (16, site + 1)):
+        if p > 0:
+            keep = _mask(M * H, p, seed, st, dev).view(M, H)
+            xd = (x.float() * keep / (1 - p)).to(dt).float()
+        else:
+            xd = x.float()
+        ref = s * (xd @ a_cat[blk:blk + 16].float().T)
+        got = t[:, blk:blk + 16].float()
+        assert (got - ref.to(dt).float()).abs().max().item() <= 2e-2 * ref.abs().max().item() * (1 if dt == torch.bfloat16 else 0.2)
+        assert ((got - ref).norm() / ref.norm()).item() < (4e-3 if dt == torch.bfloat16 else 5e-4)
+    assert (t[:, 32:] == 0).all()
+    if p > 0:  # the two adapters really see different masks
+        assert not torch.equal(_mask(M * H, p, seed, site, dev), _mask(M * H, p, seed, site + 1, dev))

@@ -13,6 +13,7 @@
 // and gate|up epilogues add the partials in index order and apply the row scale (TCAVT_EPI_NORM_OUT / _ROWSCALE).
 // Only the final norm, whose fp32 result is an output, is a launch of tcavt_rmsnorm.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace tcavt {
 
@@ -28,6 +29,72 @@ __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict_
   for (int c = threadIdx.x * 8; c < w; c += 256 * 8) {
     *reinterpret_cast<u32x4*>(kd + c) = *reinterpret_cast<const u32x4*>(src + c);
     *reinterpret_cast<u32x4*>(vd + c) = *reinterpret_cast<const u32x4*>(src + w + c);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LoRA down-projection of both adapters in one pass over the 16-bit residual-stream copy:
+//     t[m][0:16]  = s * (mask_q o x[m]) . A_q'^T        t[m][16:32] = s * (mask_v o x[m]) . A_v'^T
+// (A' = the packed a_cat rows, gain folded in; PEFT: lora_B(lora_A(lora_dropout(x))) with one dropout module per adapted
+// Linear -> two independent Philox sites in train mode, no mask in eval).  x is read ONCE (32 MB at B*L = 8192): the two
+// dropped copies that tcavt_dropout would write and two skinny GEMMs would read back never exist.  The masked operand is
+// rounded exactly as tcavt_dropout rounds it (to16(x * keep / (1 - p))).  One wave per 16 tokens, K in 32-deep MFMA steps.
+// ---------------------------------------------------------------------------
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16s(const u32x4& a, const u32x4& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ u32x4 masked8(const u32x4& x, const DropoutP& d, unsigned long long quad) {
+  float s0[4], s1[4];
+  dropout_quad(d, quad, s0);
+  dropout_quad(d, quad + 1, s1);
+  u32x4 o;
+  o[0] = pack16x2<F16>(from16_lo<F16>(x[0]) * s0[0], from16_hi<F16>(x[0]) * s0[1]);
+  o[1] = pack16x2<F16>(from16_lo<F16>(x[1]) * s0[2], from16_hi<F16>(x[1]) * s0[3]);
+  o[2] = pack16x2<F16>(from16_lo<F16>(x[2]) * s1[0], from16_hi<F16>(x[2]) * s1[1]);
+  o[3] = pack16x2<F16>(from16_lo<F16>(x[3]) * s1[2], from16_hi<F16>(x[3]) * s1[3]);
+  return o;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ a_cat,
+                                                        bf16_t* __restrict__ t, int M, int H, float scale, DropoutP dq,
+                                                        DropoutP dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wave) * 16;
+  if (m0 >= M) return;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const long m = min(m0 + r16, M - 1);
+  const bf16_t* xp = x + m * H + kq * 8;
+  const bf16_t* aq = a_cat + (long)r16 * H + kq * 8;
+  const bf16_t* av = a_cat + (long)(16 + r16) * H + kq * 8;
+  f32x4 cq = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+  const bool drop = dq.p > 0.f;
+  for (int k = 0; k < H; k += 64) {  // two MFMA steps per iteration: 2 x 3 loads in flight
+    const u32x4 x0 = *reinterpret_cast<const u32x4*>(xp + k), x1 = *reinterpret_cast<const u32x4*>(xp + k + 32);
+    const u32x4 q0 = *reinterpret_cast<const u32x4*>(aq + k), q1 = *reinterpret_cast<const u32x4*>(aq + k + 32);
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(av + k), v1 = *reinterpret_cast<const u32x4*>(av + k + 32);
+    if (drop) {
+      const unsigned long long e0 = ((unsigned long long)m * (unsigned long long)H + (unsigned long long)(k + kq * 8)) >> 2;
+      cq = mfma16s<F16>(q0, masked8<F16>(x0, dq, e0), cq);
+      cv = mfma16s<F16>(v0, masked8<F16>(x0, dv, e0), cv);
+      cq = mfma16s<F16>(q1, masked8<F16>(x1, dq, e0 + 8), cq);
+      cv = mfma16s<F16>(v1, masked8<F16>(x1, dv, e0 + 8), cv);
+    } else {
+      cq = mfma16s<F16>(q0, x0, cq);
+      cv = mfma16s<F16>(v0, x0, cv);
+      cq = mfma16s<F16>(q1, x1, cq);
+      cv = mfma16s<F16>(v1, x1, cv);
+    }
+  }
+  // lane: features 4 kq .. + 3 of token m0 + r16 in each 16-column group
+  if (m0 + r16 < M) {
+    bf16_t* row = t + (long)(m0 + r16) * 64 + 4 * kq;
+    *reinterpret_cast<u32x2*>(row) = u32x2{pack16x2<F16>(cq[0] * scale, cq[1] * scale), pack16x2<F16>(cq[2] * scale, cq[3] * scale)};
+    *reinterpret_cast<u32x2*>(row + 16) = u32x2{pack16x2<F16>(cv[0] * scale, cv[1] * scale), pack16x2<F16>(cv[2] * scale, cv[3] * scale)};
   }
 }
 
@@ -85,27 +152,11 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     TCAVT_CHECK_ARG(qkv && (!w.a_cat || t), "llama_stack_forward: qkv / t workspace missing");
     const Ev ev{a->events, st, li};
     // ---- LoRA down-projection: t = (alpha / r) * dropout(x16) . (A * gamma)^T, un-normalised (the row scale is applied
-    // to the whole q|k|v accumulator, the adapter update included)
+    // to the whole q|k|v accumulator, the adapter update included); one fused kernel for both adapters and their masks
     if (w.a_cat) {
-      tcavt_gemm_args g = {};
-      g.W = w.a_cat; g.ldw = H; g.C = t; g.ldc = 64; g.M = M; g.K = H;
-      g.out_dtype = dt; g.in_dtype = dt; g.tile = 128; g.acc_scale = a->lora_scale;
-      if (a->lora_dropout_p > 0.f) {  // PEFT: one lora_dropout module per adapted Linear -> two masks, q_proj then v_proj
-        TCAVT_CHECK_ARG(a->xq && a->xv, "llama_stack_forward: xq / xv workspaces are needed with lora_dropout_p > 0");
-        const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
-        TCAVT_TRY(tcavt_dropout(a->h16, a->xq, (int64_t)M * H, dt, a->lora_dropout_p, a->dropout_seed, site, nullptr, stream));
-        TCAVT_TRY(tcavt_dropout(a->h16, a->xv, (int64_t)M * H, dt, a->lora_dropout_p, a->dropout_seed, site + 1, nullptr, stream));
-        g.N = 16;
-        g.A = a->xq; g.lda = H;
-        TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
-        g.A = a->xv;
-        g.W = static_cast<const bf16_t*>(w.a_cat) + (size_t)16 * H;
-        g.C = static_cast<bf16_t*>(t) + 16;
-        TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
-      } else {
-        g.A = a->h16; g.lda = H; g.N = 64;
-        TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
-      }
+      const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
+      TCAVT_TRY(tcavt_lora_down(a->h16, w.a_cat, t, M, H, a->lora_scale, a->lora_dropout_p, a->dropout_seed, site, site + 1, dt,
+                                stream));
     }
     // ---- q|k|v = rs * (x16 . (W_qkv * gamma1)^T + t . B_ext^T), RoPE on q and k
     {
@@ -172,6 +223,23 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
 }
 
 extern "C" int tcavt_norm_npart(int M, int N, int K) { return norm_out_npart(M, N, K); }
+
+extern "C" int tcavt_lora_down(const void* x16, const void* a_cat, void* t, int M, int H, float scale, float dropout_p,
+                               uint64_t dropout_seed, uint32_t site_q, uint32_t site_v, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x16 && a_cat && t && M > 0 && H > 0 && H % 64 == 0 && is16(dtype16) && dropout_p >= 0.f && dropout_p < 1.f,
+                  "lora_down: bad args (H %% 64 == 0, 0 <= dropout_p < 1)");
+  TCAVT_CHECK_ARG(aligned16(x16) && aligned16(a_cat) && aligned16(t), "lora_down: 16-byte alignment required");
+  const DropoutP dq = make_dropout(dropout_p, dropout_seed, site_q), dv = make_dropout(dropout_p, dropout_seed, site_v);
+  const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+  if (dtype16 == TCAVT_F16)
+    hipLaunchKernelGGL(lora_down_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16),
+                       static_cast<const bf16_t*>(a_cat), static_cast<bf16_t*>(t), M, H, scale, dq, dv);
+  else
+    hipLaunchKernelGGL(lora_down_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16),
+                       static_cast<const bf16_t*>(a_cat), static_cast<bf16_t*>(t), M, H, scale, dq, dv);
+  TCAVT_CHECK_LAUNCH("lora_down");
+  return TCAVT_OK;
+}
 
 extern "C" int tcavt_events_create(void** events, int n) {
   TCAVT_CHECK_ARG(events && n > 0, "events_create: bad args");

@@ -674,12 +674,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             t = ws.get("ll.lora_t", (M, 64), self.storage, dev, zero=True)
             args.t = t.data_ptr()
             keep.append(t)
-            if dq is not None:
-                xq = ws.get("ll.xn_drop", (M, H), self.storage, dev)
-                xv = ws.get("ll.xn_drop2", (M, H), self.storage, dev)
-                args.xq, args.xv = xq.data_ptr(), xv.data_ptr()
+            if dq is not None:  # (masks are applied inside tcavt_lora_down: no dropped copies of the stream)
                 args.lora_dropout_p, args.dropout_seed, args.lora_first_site = dq[0], dq[1] & 0xFFFFFFFFFFFFFFFF, dq[2]
-                keep += [xq, xv]
         args.layers = carr
         args.gamma_final, args.rope_cos, args.rope_sin = P.g_final.data_ptr(), cos.data_ptr(), sin.data_ptr()
         args.h, args.h16, args.part, args.kv_len = h.data_ptr(), h16.data_ptr(), part.data_ptr(), kv_len.data_ptr()

@@ -722,6 +722,20 @@ def llama_stack_forward(args):
     check(lib().tcavt_llama_stack_forward(ctypes.byref(args), stream_ptr()), "tcavt_llama_stack_forward")
 
 
+def lora_down(x16, a_cat, t, scale, dropout=None, site_v=None):
+    """t[:, 0:16] | t[:, 16:32] = scale * dropout_q / dropout_v (x16) . a_cat[0:16 | 16:32]^T in one pass (tcavt_lora_down);
+    dropout = (p, seed, site_q) with site_v = site_q + 1 unless given."""
+    _req16(x16, "lora_down.x16")
+    _req16(a_cat, "lora_down.a_cat", like=x16)
+    _req16(t, "lora_down.t", like=x16)
+    M, H = x16.shape
+    _need(a_cat, 32 * H, "lora_down.a_cat")
+    _need(t, M * 64, "lora_down.t")
+    p, seed, site = _drop(dropout)
+    check(lib().tcavt_lora_down(ptr(x16), ptr(a_cat), ptr(t), M, H, float(scale), p, seed, site,
+                                (site + 1) if site_v is None else int(site_v), _DT[x16.dtype], stream_ptr()), "tcavt_lora_down")
+
+
 def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finished, out_tokens, advance_pos):
     """Logits processors + token selection (tcavt_sample_logits); every tensor is device state that the call advances."""
     B, V = logits.shape
