@@ -611,12 +611,14 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void gemm_bf16_kernel(GemmP 
   gemm_epilogue<TM, TN, EPI, false, F16>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
-// (gx, gy) minimising gy * |A| + 3 * gx * |W| among the partitions the tile grid divides evenly into
-// whole super rows.  The factor 3 is measured: inside the model the weights W are read from HBM (1.9 GB of
-// weights per step never stay in the 256 MiB Infinity Cache) while the activations A were just written
-// by the previous kernel and are served from the Infinity Cache, so a redundant W read costs about three
-// times a redundant A read (gate|up, cold weights: 467 us with row bands gx=8, 435 us with gx=1; down:
-// 203 us gx=8/4, 242 us gx=1).  TCAVT_GEMM_XCD_GX=<1|2|4|8> forces a partition (A/B runs).
+// (gx, gy) minimising gy * |A| + gx * |W| -- the bytes the eight XCDs pull over the fabric -- among the partitions the
+// tile grid divides evenly into whole super rows; ties go to the larger gx (row bands).  Round 1 weighted W three times
+// (HBM-cold weights vs activations served from the Infinity Cache); re-measured in the model in round 2 with the fused-norm
+// epilogues (forward pass, one box, us per launch for gx = 1 / 2 / 4 / 8):
+//     q|k|v 116.2 / 113.4 / 112.5 / 118.1    o 104.4 / 97.2 / 96.1 / 89.5    gate|up 448.7 / 441.0 / 439.9 / 440.0
+//     down 249.4 / 245.9 / 245.6 / 243.8
+// which the unweighted byte count reproduces (q|k|v -> 4, o -> 8, gate|up -> 2, down -> 8).
+// TCAVT_GEMM_XCD_GX=<1|2|4|8> forces a partition (A/B runs).
 static int choose_xcd_partition(const GemmP& p) {
   static const int forced = [] {
     const char* e = getenv("TCAVT_GEMM_XCD_GX");
@@ -624,14 +626,13 @@ static int choose_xcd_partition(const GemmP& p) {
   }();
   const double a_bytes = (double)p.M * p.K, w_bytes = (double)p.N * p.K;
   int best = 8;
-  constexpr double kColdW = 3.0;
-  double best_cost = 1.0 * a_bytes + kColdW * 8.0 * w_bytes;
-  for (int gx = 1; gx <= 4; gx *= 2) {
+  double best_cost = 1.0 * a_bytes + 8.0 * w_bytes;
+  for (int gx = 4; gx >= 1; gx /= 2) {
     const int gy = 8 / gx;
     if (p.tiles_m % gx || p.tiles_n % gy || (p.tiles_m / gx) % 4 || (long)p.tiles_m * p.tiles_n % 8) continue;
     if (forced == gx) return gx;
-    const double cost = gy * a_bytes + kColdW * gx * w_bytes;
-    if (cost < 0.9 * best_cost) {
+    const double cost = gy * a_bytes + gx * w_bytes;
+    if (cost < best_cost) {
       best_cost = cost;
       best = gx;
     }
