@@ -403,6 +403,14 @@ int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* s
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);
+/* Weight gradient with a skinny output, no physical transposes (LoRA adapters: dA = g_t^T x, dB^T = t^T g_qkv):
+ *   C[i][h] += sum_m G[m][g_col0 + i] * X[m][h]     i < n (16, 32, 48 or 64), h < H, contraction over the M tokens
+ * G bf16 [M][ldg] (a gradient), X 16-bit [M][ldx] of x_dtype (an fp16 forward activation is converted to bf16 on the way),
+ * C fp32, ACCUMULATED into with float atomics (zero it or let it hold an earlier contribution): [n][ldc], or, with
+ * trans_out != 0, the transpose [H][ldc]. */
+int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
+                   int64_t ldc, int M, int H, int trans_out, tcavt_stream_t stream);
+
 /* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192):
      g *= grad_scale;  g *= min(1, max_norm / (||g|| + 1e-6))
    grad_scale = 1 / world turns a SUM-all-reduced data-parallel gradient into the DDP-averaged one the reference clips

@@ -386,3 +386,26 @@ def test_adamw_gated_skips_nonfinite_loss(gpu):
     ops.adamw_gated(p, torch.ones(n, device=dev), m, v, 5e-4, 0.9, 0.999, 1e-8, 1e-4,
                     torch.ones(1, device=dev), ctl, grad_norm=torch.full((1,), float("nan"), device=dev))
     assert torch.equal(p, before) and ctl[:3].tolist() == [3, 3, 1]
+
+
+@pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16])
+def test_wgrad_tn_matches_transposed_product(gpu, xdt):
+    """tcavt_wgrad_tn: C[i, h] += sum_m G[m, g0 + i] X[m, h] on token-major operands (no physical transposes), both
+    output layouts, accumulation into a non-zero C, ragged M / H."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(21)
+    M, H = 1000, 712
+    G = torch.randn(M, 64, generator=g).to(torch.bfloat16).to(dev)
+    X = torch.randn(M, H, generator=g).to(xdt).to(dev)
+    Xb = X.float().to(torch.bfloat16).float() if xdt == torch.float16 else X.float()
+    for g0, n in ((0, 32), (16, 16), (0, 64)):
+        ref = G[:, g0:g0 + n].float().T @ Xb
+        base = torch.randn(n, H, generator=g).to(dev)
+        out = base.clone()
+        ops.wgrad_tn(G, g0, n, X, out)
+        assert rel_err(out.cpu(), (base + ref).cpu()) < 2e-6
+        outT = torch.zeros(H, 64, device=dev)
+        ops.wgrad_tn(G, g0, n, X, outT, trans_out=True)
+        assert rel_err(outT[:, :n].cpu(), ref.T.cpu()) < 2e-6 and (outT[:, n:] == 0).all()

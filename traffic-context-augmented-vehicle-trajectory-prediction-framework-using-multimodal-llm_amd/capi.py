@@ -154,6 +154,7 @@ _SIGNATURES = {
     "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_wgrad_tn": [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     "tcavt_clip_grad_norm": [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

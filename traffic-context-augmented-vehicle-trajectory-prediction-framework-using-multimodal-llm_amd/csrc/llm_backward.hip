@@ -859,6 +859,100 @@ static size_t attn_bwd_lds(int T) {
   return (size_t)2 * AB_QB * T * 4 + (size_t)2 * AB_QB * (AB_HD + 1) * 4 + (size_t)2 * T * AB_LDK * 2;
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient with a SKINNY output, without physical transposes:
+//     C[n][h] (+)= sum_m G[m][g0 + n] * X[m][h]          n < 16 * NB (NB <= 4),  h < H,  contraction over the M tokens
+// (LoRA: dA = g_t^T x with n = 16 per adapter, dB^T = t^T g_qkv with n = 32).  Both operands are token-major, so the
+// MFMA's K index (the token) runs DOWN their rows; round 1 transposed both with tcavt_transpose16 first (a 32 MB read +
+// write per operand and layer).  Here a workgroup stages 32 tokens x 256 columns of X and 32 x 16 NB of G per step and
+// writes them into LDS already transposed ([column][token], 16-bit scattered stores), so the fragments are plain
+// 16-byte row reads; X is read exactly once.  The token range is split over gridDim.y workgroups, whose partial sums
+// meet in C through fp32 atomics (C zeroed or holding an earlier contribution; same reproducibility class as the other
+// weight gradients: up to the float summation order).  trans_out: store C^T ([h][ldc] layout) instead.
+// ---------------------------------------------------------------------------
+template <bool XF16>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ G, long ldg, int g0, int NB,
+                                                       const bf16_t* __restrict__ X, long ldx, float* __restrict__ C,
+                                                       long ldc, int M, int H, int m_per_wg, int trans_out) {
+  constexpr int XS = 40;  // LDS row stride in 16-bit elements (32 tokens + pad; 80 bytes: 16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) bf16_t xt[256 * XS];
+  __shared__ __attribute__((aligned(16))) bf16_t gt[64 * XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h0 = blockIdx.x * 256;
+  const int mbeg = blockIdx.y * m_per_wg, mend = min(mbeg + m_per_wg, M);
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xrow = tid >> 3, xc0 = (tid & 7) * 32;  // this thread stages token xrow, columns xc0 .. xc0 + 31
+  const int grow = tid >> 3, gc0 = (tid & 7) * 8;   // ... and token grow, G columns gc0 .. gc0 + 7 (when < 16 NB)
+  for (int m0 = mbeg; m0 < mend; m0 += 32) {
+    {
+      const int m = m0 + xrow;
+      const bool ok = m < mend;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int col = h0 + xc0 + c * 8;
+        if (ok && col < H) v = *reinterpret_cast<const u32x4*>(X + (long)m * ldx + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16_t lo = static_cast<bf16_t>(v[e] & 0xffffu), hi = static_cast<bf16_t>(v[e] >> 16);
+          if constexpr (XF16) {  // forward activation in fp16, gradient operand in bf16: one type for the MFMA
+            lo = f32_to_bf16(f16_to_f32(lo));
+            hi = f32_to_bf16(f16_to_f32(hi));
+          }
+          xt[(xc0 + c * 8 + 2 * e) * XS + xrow] = lo;
+          xt[(xc0 + c * 8 + 2 * e + 1) * XS + xrow] = hi;
+        }
+      }
+      if (gc0 < 16 * NB) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const int mg = m0 + grow;
+        if (mg < mend) v = *reinterpret_cast<const u32x4*>(G + (long)mg * ldg + g0 + gc0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          gt[(gc0 + 2 * e) * XS + grow] = static_cast<bf16_t>(v[e] & 0xffffu);
+          gt[(gc0 + 2 * e + 1) * XS + grow] = static_cast<bf16_t>(v[e] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    // wave: columns h0 + 64 wave .. + 63 (four 16-column blocks); A = G^T rows (n), B = X^T rows (h), K = 32 tokens
+    u32x4 bf[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bf[b] = *reinterpret_cast<const u32x4*>(&xt[(wave * 64 + b * 16 + r16) * XS + kq * 8]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a < NB) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(&gt[(a * 16 + r16) * XS + kq * 8]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // acc[a][b]: rows n = 16 a + 4 kq .. + 3, column h = h0 + 64 wave + 16 b + r16
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (a >= NB) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int h = h0 + wave * 64 + b * 16 + r16;
+      if (h >= H) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = a * 16 + 4 * kq + e;
+        float* dst = trans_out ? C + (long)h * ldc + n : C + (long)n * ldc + h;
+        atomicAdd(dst, acc[a][b][e]);
+      }
+    }
+  }
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -1003,5 +1097,27 @@ extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float g
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, (long)n, scratch + CLIP_BLOCKS);
   TCAVT_CHECK_LAUNCH("clip_grad_norm");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
+                              int64_t ldc, int M, int H, int trans_out, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(G && X && C && M > 0 && H > 0 && n > 0 && n <= 64 && n % 16 == 0 && g_col0 >= 0 && g_col0 % 8 == 0 &&
+                      ldg % 8 == 0 && ldx % 8 == 0 && H % 8 == 0 && is16(x_dtype),
+                  "wgrad_tn: n in {16, 32, 48, 64}, g_col0 / ldg / ldx / H multiples of 8");
+  TCAVT_CHECK_ARG(aligned16(G) && aligned16(X), "wgrad_tn: 16-byte alignment required");
+  const int gx = (H + 255) / 256;
+  int split = 256 / gx;  // ~one workgroup per CU
+  if (split < 1) split = 1;
+  int m_per_wg = ((M + split - 1) / split + 31) / 32 * 32;
+  split = (M + m_per_wg - 1) / m_per_wg;
+  const dim3 grid(gx, split), block(256);
+  if (x_dtype == TCAVT_F16)
+    hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+  else
+    hipLaunchKernelGGL(wgrad_tn_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+  TCAVT_CHECK_LAUNCH("wgrad_tn");
   return TCAVT_OK;
 }

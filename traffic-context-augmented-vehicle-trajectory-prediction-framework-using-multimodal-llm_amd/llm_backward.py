@@ -114,18 +114,6 @@ class LoraBackward:
     def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):  # noqa: D401 (scratch from the decoder's workspace)
         return self.ws.get("llbw." + name, shape, dtype, self.book.grads.device, zero=zero)
 
-    def _wgrad(self, tag, x, y, out):
-        """out[n, m] (fp32) = x^T y for bf16 x [M, n], y [M, m]: contraction over rows, both operands transposed
-        (rows zero-padded to a multiple of 64, the GEMM's K granule)."""
-        M, n = x.shape
-        m = y.shape[1]
-        Mp = _rup(M, 64)
-        xT = self._buf(tag + ".xT", (n, Mp))
-        yT = self._buf(tag + ".yT", (m, Mp))
-        ops.transpose16(x, xT, M, n, Mp)
-        ops.transpose16(y, yT, M, m, Mp)
-        ops.gemm_bf16(xT, yT, out=out)
-
     def run(self, g_final_a, g_final_b=None):
         """g_final_a (+ g_final_b): bf16 [B*L, H] gradient of the post-final-norm hidden states."""
         lw, G = self.lw, self.book.g
@@ -189,18 +177,19 @@ class LoraBackward:
             def adapter_grads(li=li, d=d, sv=sv, g_qkv=g_qkv, g_t=g_t):
                 # the adapter branches' inputs and down-projections in the un-fused form the backward walks (the forward
                 # kept only the un-normalised t of its fused RMSNorm): xn = rmsnorm(h_in), t = s * dropout(xn) A^T
+                dA.zero_()
+                dB.zero_()
                 if sv.dspec is not None:  # ... with the forward's two masks
                     ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
                     ops.dropout(xn, xl2, *sv.dspec[1])
-                    ops.gemm_bf16(xl, dT.a_plain[:LORA_V], out=t_re[:, :LORA_V], acc_scale=s, tile=128)
-                    ops.gemm_bf16(xl2, dT.a_plain[LORA_V:2 * LORA_V], out=t_re[:, LORA_V:2 * LORA_V], acc_scale=s, tile=128)
-                    self._wgrad("dAq", g_t[:, :LORA_V], xl, dA[:LORA_V])
-                    self._wgrad("dAv", g_t[:, LORA_V:2 * LORA_V], xl2, dA[LORA_V:2 * LORA_V])
+                    ops.lora_down(xn, dT.a_plain, t_re, s, dropout=sv.dspec[0], site_v=sv.dspec[1][2])
+                    ops.wgrad_tn(g_t, 0, LORA_V, xl, dA)               # dA_q = g_tq^T drop_q(xn): token-major operands as they are
+                    ops.wgrad_tn(g_t, LORA_V, LORA_V, xl2, dA[LORA_V:])
                 else:
                     ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
-                    ops.gemm_bf16(xn, dT.a_plain, out=t_re, acc_scale=s, tile=128)
-                    self._wgrad("dA", g_t, xn, dA)
-                self._wgrad("dB", g_qkv, t_re, dB)
+                    ops.lora_down(xn, dT.a_plain, t_re, s)
+                    ops.wgrad_tn(g_t, 0, 2 * LORA_V, xn, dA)
+                ops.wgrad_tn(t_re, 0, 2 * LORA_V, g_qkv, dB, trans_out=True)  # dB = g_qkv^T t, stored as [nqkv, 64]
                 p = f"{pre}{li}.self_attn."
                 G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
                 G[p + "v_proj.lora_A.weight"].copy_(dA[LORA_V:LORA_V + r])

@@ -553,14 +553,18 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 self._refresh_lora_T()
         return self._prep_T
 
-    def _refresh_lora_T(self):
+    def _refresh_lora_T(self, stacked=None):
         """The backward's adapter operands from the current parameters: plain A^T (no folded gain) and B^T."""
         at_all, bt_all, atq_all, atv_all, ap_all = self._prep_T_all
         P, r, nL = self._prepared(), self.lora_r, len(self._prepared().layers)
-        for li, lyr in enumerate(self.llama_model.model.layers):
-            a, k = lyr.self_attn, nL - 1 - li
-            ap_all[k, :r].copy_(a.q_proj.lora_A.weight.detach())
-            ap_all[k, LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
+        if stacked is not None:  # all layers at once from the trainer's stacked views (last layer first, as ap_all is)
+            ap_all[:, :r].copy_(stacked[0])
+            ap_all[:, LORA_V:LORA_V + r].copy_(stacked[2])
+        else:
+            for li, lyr in enumerate(self.llama_model.model.layers):
+                a, k = lyr.self_attn, nL - 1 - li
+                ap_all[k, :r].copy_(a.q_proj.lora_A.weight.detach())
+                ap_all[k, LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach())
         at_all.copy_(ap_all.transpose(1, 2))
         atq_all[:, :, :LORA_V].copy_(at_all[:, :, :LORA_V])
         atv_all[:, :, LORA_V:].copy_(at_all[:, :, LORA_V:])
@@ -595,7 +599,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
                 d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
         if self._prep_T is not None:
-            self._refresh_lora_T()
+            self._refresh_lora_T(stacked)
 
     def _rope_tables(self, L, dev):
         key = (L, str(dev))

@@ -676,6 +676,21 @@ def masked_mean_bwd(gemb, lens, genc, B, P, D):
     check(lib().tcavt_masked_mean_bwd(ptr(gemb), ptr(lens), ptr(genc), B, P, D, stream_ptr()), "tcavt_masked_mean_bwd")
 
 
+def wgrad_tn(g, g_col0, n, x, out, trans_out=False):
+    """out[i, h] += sum_m g[m, g_col0 + i] * x[m, h] (i < n; trans_out: out[h, i]) -- skinny weight gradient without
+    transposes (tcavt_wgrad_tn).  g bf16 [M, >= g_col0 + n], x fp16 / bf16 [M, H], out fp32, accumulated into."""
+    if g.dtype != torch.bfloat16 or x.dtype not in _H16 or out.dtype != torch.float32:
+        raise capi.TcavtError("wgrad_tn: g bf16, x fp16 / bf16, out fp32 required")
+    M, H = x.shape
+    if g.shape[0] < M or g.shape[1] < g_col0 + n or g.stride(1) != 1 or x.stride(1) != 1 or out.stride(1) != 1:
+        raise capi.TcavtError("wgrad_tn: operand shapes / strides")
+    rows, cols = (H, n) if trans_out else (n, H)
+    if out.shape[0] < rows or out.shape[1] < cols:
+        raise capi.TcavtError(f"wgrad_tn.out: needs at least ({rows}, {cols})")
+    check(lib().tcavt_wgrad_tn(ptr(g), g.stride(0), int(g_col0), int(n), ptr(x), x.stride(0), _DT[x.dtype], ptr(out), out.stride(0),
+                               M, H, int(trans_out), stream_ptr()), "tcavt_wgrad_tn")
+
+
 def clip_grad_norm(g, max_norm, scratch, grad_scale=1.0):
     """In-place g *= grad_scale, then clip of the flat gradient vector to max_norm (torch.nn.utils.clip_grad_norm_
     semantics); scratch: fp32, >= 1026 elements; afterwards scratch[1025] holds the norm of the scaled gradient before
