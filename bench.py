@@ -344,16 +344,22 @@ def main():
 
         graph = None
         if args.launch == "graph" and not args.no_graph and world == 1:  # multi-rank: RCCL all-reduces are launched eagerly
-            # hipGraph capture of the whole step (all launches are stream-ordered, allocation-free
-            # after the first call): removes per-launch host cost from the timed loop
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                g_loss, g_decoded = step()
+            # hipGraph of the whole step (all launches are stream-ordered and allocation-free after the first call).  In train
+            # mode Trainer.capture moves the per-step host state to the device (optimizer step count, dropout epoch): every
+            # replay is a full train.py step with fresh dropout masks.
+            if trainer is not None:
+                graph, (g_loss, g_decoded) = trainer.capture(
+                    g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
+                    g["input_ids"], g["attention_mask"], g["labels"])
+            else:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    g_loss, g_decoded = step()
 
         prefetch = graph is None and not args.no_prefetch
 
@@ -362,6 +368,7 @@ def main():
         def run_step():
             if graph is not None:
                 graph.replay()
+                last["loss"] = g_loss
             else:
                 if trainer is not None:  # batch i+1's Q-Former goes to a side stream and runs under step i's decoder
                     last["loss"] = step(g["vision_emb"] if prefetch else None)[0]
@@ -406,6 +413,8 @@ def main():
         timer.close()
         ksum = {k: (c, t / c) for k, (c, t) in acc.items()}
 
+    if trainer is not None:
+        trainer.release_graph()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -187,6 +187,14 @@ int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, float p, uint6
                   const void* add /* optional, same dtype: out[i] = dropout(x)[i] + add[i] (two masked gradient addends) */,
                   tcavt_stream_t stream);
 
+/* Dropout masks under hipGraph replay.  Every dropout site takes (p, seed, site) as launch arguments, which a captured
+ * graph bakes in.  tcavt_set_dropout_epoch(ptr) registers a device-resident uint64 (process-wide; NULL = off, the default)
+ * whose value every kernel launched afterwards ADDS to its seed when it runs; tcavt_dropout_epoch_advance (one tiny launch,
+ * put it at the head of the captured step) increments it.  Each replay of a captured train-mode step then draws fresh
+ * masks, while forward and backward of one step still regenerate the same ones. */
+int tcavt_set_dropout_epoch(const uint64_t* epoch_dev);
+int tcavt_dropout_epoch_advance(uint64_t* epoch_dev, tcavt_stream_t stream);
+
 /* fp32 -> fp16 / bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */
 int tcavt_cast_f32_16(const float* x, void* out16, int64_t n, int dtype16, tcavt_stream_t stream);
 

@@ -368,3 +368,71 @@ def test_step_with_qformer_prefetch_is_equivalent(gpu):
     # (lr * g / (|g| + eps): a sign decision where g ~ 0) and the 16-bit forward amplify step by step -- two runs WITHOUT
     # prefetch differ by the same amount.  (With bf16 storage the forward's coarser rounding hid it on step 2.)
     assert np.allclose(la[:2], lb[:2], rtol=2e-4) and np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
+
+
+def test_dropout_epoch_shifts_the_seed(gpu):
+    """tcavt_set_dropout_epoch: a device-resident value added to every dropout seed at run time (fresh masks under hipGraph
+    replay).  Mask with (seed, epoch e) == the oracle's mask of seed + e; epoch cleared -> the plain seed again."""
+    from oracle import philox
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    n, p, seed, site = 40001, 0.1, 0xFEEDFACE12345, 5
+    x = torch.ones(n, device=dev)
+    epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+    try:
+        ops.set_dropout_epoch(epoch)
+        for e in (0, 1, 2):
+            y = torch.empty_like(x)
+            ops.dropout(x, y, p, seed, site)
+            keep = torch.from_numpy(philox.keep_mask(n, p, seed + e, site)).to(dev)
+            assert torch.equal(y != 0, keep)
+            ops.dropout_epoch_advance(epoch)
+        assert epoch.item() == 3
+    finally:
+        ops.set_dropout_epoch(None)
+    y = torch.empty_like(x)
+    ops.dropout(x, y, p, seed, site)
+    assert torch.equal(y != 0, torch.from_numpy(philox.keep_mask(n, p, seed, site)).to(dev))
+
+
+def test_captured_step_replays_like_eager_steps(gpu):
+    """Trainer.capture: the whole train.py step as a hipGraph.  Eval arithmetic: N replays land where N eager steps land
+    (optimizer step count on the device: the bias corrections follow the replays).  Train mode: every replay draws fresh
+    masks (losses differ at lr = 0), and the epoch is released afterwards."""
+    from tcavt_amd import model, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    args = (g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
+            g["input_ids"], g["attention_mask"], g["labels"])
+
+    def make(train, lr):
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev)
+        m.train(train)
+        return m, training.Trainer(m, lr=lr)
+
+    m1, tr1 = make(False, 1e-4)
+    losses1 = [tr1.step(*args)[0].item() for _ in range(5)]
+    m2, tr2 = make(False, 1e-4)
+    graph, (gl, gd) = tr2.capture(*args)       # (capture's warm-up is step 1)
+    losses2 = []
+    for _ in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        losses2.append(gl.item())
+    tr2.release_graph()
+    assert tr2.optimizer_counters() == (5, 0)
+    assert np.allclose(losses1[1:], losses2, rtol=5e-3)
+    assert rel_err(tr2.book.params.cpu(), tr1.book.params.cpu()) < 1e-3
+    m3, tr3 = make(True, 0.0)
+    graph3, (gl3, _) = tr3.capture(*args)
+    seen = []
+    for _ in range(3):
+        graph3.replay()
+        torch.cuda.synchronize()
+        seen.append(gl3.item())
+    tr3.release_graph()
+    assert len(set(seen)) == 3 and all(np.isfinite(seen))  # lr = 0: only the masks change from replay to replay

@@ -116,6 +116,8 @@ _SIGNATURES = {
                          c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,
                            ctypes.c_uint32, c_void_p],
+    "tcavt_set_dropout_epoch": [c_void_p],
+    "tcavt_dropout_epoch_advance": [c_void_p, c_void_p],
     "tcavt_dropout": [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p, c_void_p],
     "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],

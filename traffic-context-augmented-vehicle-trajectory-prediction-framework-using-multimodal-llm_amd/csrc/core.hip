@@ -11,6 +11,11 @@ namespace tcavt {
 
 static thread_local char g_err[512] = "";
 
+static const unsigned long long* g_dropout_epoch = nullptr;
+const unsigned long long* dropout_epoch_ptr() { return g_dropout_epoch; }
+
+__global__ void epoch_advance_kernel(unsigned long long* e) { *e += 1ull; }
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -367,6 +372,19 @@ extern "C" int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, i
   hipLaunchKernelGGL(mask_to_kvlen_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), mask, Lt, Nq,
                      kv_len, not_prefix_flag);
   TCAVT_CHECK_LAUNCH("mask_to_kvlen");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_set_dropout_epoch(const uint64_t* epoch_dev) {
+  g_dropout_epoch = reinterpret_cast<const unsigned long long*>(epoch_dev);
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_dropout_epoch_advance(uint64_t* epoch_dev, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(epoch_dev, "dropout_epoch_advance: null pointer");
+  hipLaunchKernelGGL(epoch_advance_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<unsigned long long*>(epoch_dev));
+  TCAVT_CHECK_LAUNCH("dropout_epoch_advance");
   return TCAVT_OK;
 }
 

@@ -14,15 +14,24 @@ struct DropoutP {
   float p;              // 0 => disabled
   float inv_keep;       // 1 / (1 - p)
   unsigned int seed_lo, seed_hi, site;
+  // optional: a device-resident 64-bit "epoch" that is ADDED to the seed when the kernel runs.  A hipGraph bakes kernel
+  // arguments, so a captured training step would replay one set of masks forever; with the epoch (advanced by a node of
+  // the same graph, tcavt_dropout_epoch_advance) every replay draws fresh masks, and forward and backward of one step
+  // still agree.  NULL (the default) = epoch 0: masks are a function of (seed, site, element) alone.
+  const unsigned long long* epoch;
 };
 
-__host__ __device__ inline DropoutP make_dropout(float p, uint64_t seed, uint32_t site) {
+// the library-wide epoch pointer (tcavt_set_dropout_epoch, csrc/core.hip)
+const unsigned long long* dropout_epoch_ptr();
+
+inline DropoutP make_dropout(float p, uint64_t seed, uint32_t site) {
   DropoutP d;
   d.p = p;
   d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   d.seed_lo = (unsigned int)(seed & 0xffffffffu);
   d.seed_hi = (unsigned int)(seed >> 32);
   d.site = site;
+  d.epoch = p > 0.f ? dropout_epoch_ptr() : nullptr;
   return d;
 }
 
@@ -43,7 +52,13 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
 // keep-scales (0 or 1/(1-p)) of the four elements 4q .. 4q+3 of a site's flat index space
 __device__ __forceinline__ void dropout_quad(const DropoutP& d, unsigned long long quad, float (&scale)[4]) {
   unsigned int r[4];
-  philox4x32_10((unsigned int)(quad & 0xffffffffu), (unsigned int)(quad >> 32), d.site, 0u, d.seed_lo, d.seed_hi, r);
+  unsigned int k0 = d.seed_lo, k1 = d.seed_hi;
+  if (d.epoch) {  // (uniform) seed + epoch as one 64-bit sum
+    const unsigned long long s = (((unsigned long long)k1 << 32) | k0) + *d.epoch;
+    k0 = (unsigned int)(s & 0xffffffffu);
+    k1 = (unsigned int)(s >> 32);
+  }
+  philox4x32_10((unsigned int)(quad & 0xffffffffu), (unsigned int)(quad >> 32), d.site, 0u, k0, k1, r);
 #pragma unroll
   for (int i = 0; i < 4; ++i) scale[i] = ((float)(r[i] >> 8) * (1.0f / 16777216.0f) >= d.p) ? d.inv_keep : 0.f;
 }

@@ -192,6 +192,20 @@ def softmax_rows(s, p, rows, n_valid, n_out, lds, ldp, dropout=None):
                                    stream_ptr()), "tcavt_softmax_rows")
 
 
+def set_dropout_epoch(epoch):
+    """Register (or, with None, clear) the device-resident int64 that every dropout kernel adds to its seed when it runs
+    (fresh masks under hipGraph replay, tcavt_set_dropout_epoch).  The tensor must outlive its registration."""
+    if epoch is not None:
+        _req(epoch, torch.int64, "set_dropout_epoch.epoch")
+        _need(epoch, 1, "set_dropout_epoch.epoch")
+    check(lib().tcavt_set_dropout_epoch(ptr(epoch)), "tcavt_set_dropout_epoch")
+
+
+def dropout_epoch_advance(epoch):
+    _req(epoch, torch.int64, "dropout_epoch_advance.epoch")
+    check(lib().tcavt_dropout_epoch_advance(ptr(epoch), stream_ptr()), "tcavt_dropout_epoch_advance")
+
+
 def dropout_(x, spec):
     """In-place dropout with a (p, seed, site) spec, no-op for None: how the backward re-applies a forward mask to a
     gradient of the same shape."""

@@ -85,6 +85,10 @@ class Trainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
         self._ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # device-side step counters of the gated optimizer
         self._last_loss = None
+        # hipGraph replay of the whole step (capture()): the optimizer's step count and the dropout epoch live on the device
+        self.device_step = False
+        self._finite = torch.zeros(1, dtype=torch.float32, device=dev)  # an always-finite "loss" for the un-gated loop
+        self._epoch = None
         if self.world > 1 and sync_initial_state:
             self.broadcast_state()
         model.invalidate_prepared()
@@ -200,7 +204,12 @@ class Trainer:
                 norm = self.clip_grad_norm_(self.max_grad_norm, grad_scale=grad_scale)  # mean first, then clip
                 grad_scale = 1.0
             self.step_count += 1
-            if self.skip_nonfinite:
+            if self.device_step and not self.skip_nonfinite:
+                # train.py's loop has no finite-loss test: the gate sees a constant, only the device-side step counter
+                # (bias corrections that follow the replay count) is used
+                ops.adamw_gated(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                                self.eps, self.wd, self._finite, self._ctl, grad_scale=grad_scale, grad_norm=None)
+            elif self.skip_nonfinite:
                 if self._last_loss is None:
                     raise RuntimeError("optimizer_step(skip_nonfinite=True) needs the loss of forward_backward()")
                 ops.adamw_gated(self.book.params, self.book.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1],
@@ -218,10 +227,44 @@ class Trainer:
         """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
         self.model.prefetch(vision_embs, ready=ready)
 
+    def capture(self, *args, **kw):
+        """One whole step (zero_grad + forward + backward + AdamW) as a hipGraph: returns (graph, (loss, decoded)) with
+        static result tensors; every graph.replay() is one step on the CURRENT contents of the argument tensors.
+        Host-side per-step state moves to the device: the optimizer's step count (tcavt_adamw_gated's counter) and, in
+        train mode, a dropout epoch that the first node of the graph advances and every mask generator adds to its seed
+        (tcavt_set_dropout_epoch), so each replay draws fresh masks and its backward regenerates the same ones.
+        Single process only (the gradient all-reduce is not captured); call release_graph() when done."""
+        if self.world != 1:
+            raise RuntimeError("Trainer.capture: data-parallel steps launch their all-reduces eagerly")
+        if self.device_step is False and self.step_count > 0 and not self.skip_nonfinite:
+            self._ctl[0] = self.step_count  # continue the bias-correction count of the eager steps taken so far
+        self.device_step = True
+        if self.model.training:
+            self._epoch = torch.zeros(1, dtype=torch.int64, device=self.book.grads.device)
+            ops.set_dropout_epoch(self._epoch)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up under the final configuration: allocations, packed weights, kernel attributes
+            self.step(*args, **kw)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if self._epoch is not None:
+                ops.dropout_epoch_advance(self._epoch)
+            out = self.step(*args, **kw)
+        return graph, out
+
+    def release_graph(self):
+        if self._epoch is not None:
+            ops.set_dropout_epoch(None)
+            self._epoch = None
+
     def optimizer_counters(self):
         """(applied, skipped) updates of the gated optimizer (one host sync)."""
         c = self._ctl.tolist()
-        return (c[0], c[1]) if self.skip_nonfinite else (self.step_count, 0)
+        return (c[0], c[1]) if (self.skip_nonfinite or self.device_step) else (self.step_count, 0)
 
     def check_flags(self):
         """Raise if any forward since the last check saw input_ids outside the vocabulary or a mask that is not a
