@@ -8,6 +8,10 @@ O=$R/gpurun_out/r02; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -2 $O/bench_default.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -o step -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_step.log 2>&1; echo "rocprof rc=$?"
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lora-trainable > $O/bench_lora.json 2> $O/bench_lora.err; tail -1 $O/bench_lora.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --mode forward > $O/bench_forward.json 2> $O/bench_forward.err; tail -1 $O/bench_forward.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --launch graph > $O/bench_graph.json 2> $O/bench_graph.err; tail -1 $O/bench_graph.err
+for bs in 8 32; do python3 $R/tools/bench_generate.py --batch $bs 2>/dev/null | tail -1 > $O/generate_b$bs.json; cut -c180-400 $O/generate_b$bs.json; done
 for sh in gateup down o; do
   D=/tmp/pmc_r02_$sh; rm -rf $D; i=0
   for c in "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
