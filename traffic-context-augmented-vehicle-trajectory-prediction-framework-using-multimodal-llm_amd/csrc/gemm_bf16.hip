@@ -1336,6 +1336,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = blockIdx.x * (16 * NCB);
   const int r16 = lane & 15, kq = lane >> 4;
+  // first output column of column block c.  RoPE: a workgroup owns the two 16-column blocks of one head that rotate
+  // together (dimensions d and d + 32), so that two workgroups share a head (96 workgroups for the fused q|k|v instead of 48)
+  int ncol[NCB];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+    ncol[c] = EPI == EPI_ROPE ? (blockIdx.x >> 1) * 64 + (blockIdx.x & 1) * 16 + c * 32 : n0 + c * 16;
   f32x4 acc[NCB][2];
 #pragma unroll
   for (int c = 0; c < NCB; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1343,7 +1349,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const int kper = p.K / SK_WAVES;
   const bf16_t* wp[NCB];
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(n0 + c * 16 + r16) * p.ldw + wave * kper + kq * 8;
+  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(ncol[c] + r16) * p.ldw + wave * kper + kq * 8;
   const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + wave * kper + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + wave * kper + kq * 8;
   const bool two = p.M > 16;
@@ -1377,7 +1383,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + k + kq * 8);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
-          const u32x4 w2 = *reinterpret_cast<const u32x4*>(p.W2 + (long)(n0 + c * 16 + r16) * p.ldw2 + k + kq * 8);
+          const u32x4 w2 = *reinterpret_cast<const u32x4*>(p.W2 + (long)(ncol[c] + r16) * p.ldw2 + k + kq * 8);
           acc[c][0] = mfma16<F16>(w2, a0, acc[c][0]);
           if (two) acc[c][1] = mfma16<F16>(w2, a1, acc[c][1]);
         }
@@ -1442,31 +1448,29 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = silu_mul(g[e], u[e]);
     store_quad(p, m, (n0 >> 1) + nq, o);
-  } else {  // EPI_ROPE: 64 columns = one head
-    static_assert(EPI != EPI_ROPE || NCB == 4, "one head per workgroup");
+  } else {  // EPI_ROPE: dimensions d = 16 half + nq .. + 3 and d + 32 of one head
+    static_assert(EPI != EPI_ROPE || NCB == 2, "two partner blocks per workgroup");
     if (!rowok) return;
-    const bool rot = n0 < p.rope_cols;
+    const bool rot = ncol[0] < p.rope_cols;
     const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4 lo = v[i] * rs, hi = v[(i + 2) % NCB] * rs;
-      if (rot) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + i * 16 + nq);
-        const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + i * 16 + nq);
-        const f32x4 l2 = lo * c - hi * sn, h2 = hi * c + lo * sn;
-        lo = l2;
-        hi = h2;
-      }
-      store_quad(p, m, n0 + i * 16 + nq, lo);
-      store_quad(p, m, n0 + 32 + i * 16 + nq, hi);
+    const int d = (blockIdx.x & 1) * 16 + nq;
+    f32x4 lo = v[0] * rs, hi = v[NCB - 1] * rs;
+    if (rot) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
+      const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
+      const f32x4 l2 = lo * c - hi * sn, h2 = hi * c + lo * sn;
+      lo = l2;
+      hi = h2;
     }
+    store_quad(p, m, ncol[0] + nq, lo);
+    store_quad(p, m, ncol[NCB - 1] + nq, hi);
   }
   (void)OUT16;
 }
 
 template <int EPI, int NCB, bool F16>
 static int launch_skinny(const GemmP& p, hipStream_t stream) {
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(p.N / (16 * NCB)), dim3(SK_WAVES * 64), 0, stream, p);
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(p.N / (16 * NCB)), dim3(SK_WAVES * 64), 0, stream, p);  // (RoPE: N / 64 heads x 2 halves = N / 32)
   TCAVT_CHECK_LAUNCH("gemm_bf16(skinny)");
   return TCAVT_OK;
 }
@@ -1595,7 +1599,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   if (a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f && a->lda >= a->K) {
     const int e0 = a->epilogue & ~TCAVT_EPI_ROWSCALE;
     if (e0 == TCAVT_EPI_ROPE && a->N % 64 == 0 && (K2 == 0 || K2 % 32 == 0))
-      return f16 ? launch_skinny<EPI_ROPE, 4, true>(p, s) : launch_skinny<EPI_ROPE, 4, false>(p, s);
+      return f16 ? launch_skinny<EPI_ROPE, 2, true>(p, s) : launch_skinny<EPI_ROPE, 2, false>(p, s);
     if (e0 == TCAVT_EPI_SILU_MUL && !a->silu_preact && a->N % 32 == 0)
       return f16 ? launch_skinny<EPI_SILU, 2, true>(p, s) : launch_skinny<EPI_SILU, 2, false>(p, s);
     if ((e0 & TCAVT_EPI_NORM_OUT) && a->N % 16 == 0)

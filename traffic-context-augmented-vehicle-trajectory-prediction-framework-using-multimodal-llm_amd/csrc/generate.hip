@@ -36,24 +36,30 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict
 }
 
 // One query per (sample, query head) over the cached keys 0 .. pos[b] (the new token's own key included).
-// One workgroup per (sample, kv head), one wave per query head of the group.  Scores: lane = key (each lane reads its
-// key's 128-byte row and keeps the whole query in registers), softmax across the lanes; output: lane = head dimension,
-// one coalesced 128-byte value row per key with the probability broadcast from LDS.
+// One workgroup per (sample, kv head); KS waves per query head of the group split the keys.  Scores: lane = key (each lane
+// reads its key's 128-byte row and keeps the whole query in registers); the KS (max, sum) pairs of a head meet in LDS, the
+// probabilities are normalised with the head's global sum and carried in fp16 as in the prefill kernel; output: lane =
+// head dimension over the wave's key range, the KS partial outputs are added in split order.
 template <bool F16>
-__global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ vc, const int* __restrict__ pos,
-                                                          bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale) {
-  extern __shared__ float sc[];  // [group][lmax] scores / probabilities
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                           const bf16_t* __restrict__ vc, const int* __restrict__ pos,
+                                                           bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale,
+                                                           int KS) {
+  extern __shared__ float sc[];  // [group][lmax] scores | [group][KS][2] (max, sum) | [group][KS][64] partial outputs
   const int group = nq / nkv;
   const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (wv >= group) return;
-  const int head = kvh * group + wv;
+  const int hq = wv % group, ks = wv / group;  // query head of the group, key split
+  const int head = kvh * group + hq;
   const int n = min(pos[b] + 1, lmax);
   const int ld = (nq + 2 * nkv) * 64, w = nkv * 64;
   const bf16_t* kb = kc + (long)b * lmax * w + kvh * 64;
   const bf16_t* vb = vc + (long)b * lmax * w + kvh * 64;
-  float* s = sc + wv * lmax;
+  float* s = sc + hq * lmax;
+  float* st = sc + group * lmax + (hq * KS) * 2;
+  float* po = sc + group * lmax + group * KS * 2 + (hq * KS) * 64;
+  const int chunk = ((n + KS - 1) / KS + 63) / 64 * 64;  // keys per split, whole 64-key rounds
+  const int j0 = ks * chunk, j1 = min(j0 + chunk, n);
   float q[64];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(qkv + (long)b * ld + head * 64);
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restri
     }
   }
   float mx = -1e30f;
-  for (int j = lane; j < n; j += 64) {
+  for (int j = j0 + lane; j < j1; j += 64) {
     const u32x4* kp = reinterpret_cast<const u32x4*>(kb + (long)j * w);
     float d = 0.f;
 #pragma unroll
@@ -85,26 +91,30 @@ __global__ __launch_bounds__(512) void attn_decode_kernel(const bf16_t* __restri
   }
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int j = lane; j < n; j += 64) {
-    const float e = __expf(s[j] - mx);
-    s[j] = e;
-    sum += e;
-  }
+  for (int j = j0 + lane; j < j1; j += 64) sum += __expf(s[j] - mx);
   sum = wave_sum(sum);
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  const float inv = 1.f / sum;
+  if (lane == 0) { st[ks * 2] = mx; st[ks * 2 + 1] = sum; }
+  __syncthreads();
+  float gm = -1e30f, gl = 0.f;
+  for (int k = 0; k < KS; ++k) gm = fmaxf(gm, st[k * 2]);
+  for (int k = 0; k < KS; ++k) gl += st[k * 2 + 1] * __expf(st[k * 2] - gm);
+  const float inv = 1.f / gl;
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;  // four independent chains over the keys
-  int j = 0;
-  for (; j + 3 < n; j += 4) {
-    // probabilities are carried in fp16, as in the prefill kernel
-    o0 = fmaf(f16_to_f32(f32_to_f16(s[j] * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
-    o1 = fmaf(f16_to_f32(f32_to_f16(s[j + 1] * inv)), from16<F16>(vb[(long)(j + 1) * w + lane]), o1);
-    o2 = fmaf(f16_to_f32(f32_to_f16(s[j + 2] * inv)), from16<F16>(vb[(long)(j + 2) * w + lane]), o2);
-    o3 = fmaf(f16_to_f32(f32_to_f16(s[j + 3] * inv)), from16<F16>(vb[(long)(j + 3) * w + lane]), o3);
+  int j = j0;
+  for (; j + 3 < j1; j += 4) {
+    o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
+    o1 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 1] - gm) * inv)), from16<F16>(vb[(long)(j + 1) * w + lane]), o1);
+    o2 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 2] - gm) * inv)), from16<F16>(vb[(long)(j + 2) * w + lane]), o2);
+    o3 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 3] - gm) * inv)), from16<F16>(vb[(long)(j + 3) * w + lane]), o3);
   }
-  for (; j < n; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(s[j] * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
-  out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>((o0 + o1) + (o2 + o3));
+  for (; j < j1; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
+  po[ks * 64 + lane] = (o0 + o1) + (o2 + o3);
+  __syncthreads();
+  if (ks == 0) {
+    float o = po[lane];
+    for (int k = 1; k < KS; ++k) o += po[k * 64 + lane];
+    out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
+  }
 }
 
 // out[b] = src[b * L + kv_len[b] - 1]  (the last valid position's hidden state of each sample after the prefill)
@@ -432,7 +442,9 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->h /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
                              a->bad_id_flag, dt, a->h16, a->part, np_in, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
-  const size_t lds = (size_t)(nq / nkv) * a->kv_lmax * sizeof(float);
+  const int group = nq / nkv;
+  const int KS = 16 / group >= 1 ? 16 / group : 1;  // key splits per query head: up to 16 waves per workgroup
+  const size_t lds = ((size_t)group * a->kv_lmax + (size_t)group * KS * 66) * sizeof(float);
   TCAVT_CHECK_ARG(lds <= 64 * 1024, "llama_decode_step: kv_lmax = %d too long for the decode attention's score buffer", a->kv_lmax);
   for (int li = 0; li < a->n_layers; ++li) {
     const tcavt_llama_layer& w = a->layers[li];
@@ -459,11 +471,11 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     hipLaunchKernelGGL(kv_append_kernel, dim3(B), dim3(256), 0, st, static_cast<const bf16_t*>(a->qkv), kc, vc, a->pos,
                        a->kv_lmax, nq, nkv);
     if (dt == TCAVT_F16)
-      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nkv), dim3((nq / nkv) * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
-                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f);
+      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nkv), dim3(group * KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
     else
-      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nkv), dim3((nq / nkv) * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
-                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f);
+      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nkv), dim3(group * KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
     TCAVT_CHECK_LAUNCH("attn_decode");
     {
       tcavt_gemm_args g = {};

@@ -63,22 +63,26 @@ template <bool F16>
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ a_cat,
                                                         bf16_t* __restrict__ t, int M, int H, float scale, DropoutP dq,
                                                         DropoutP dv) {
+  // one workgroup per 16 tokens; its four waves split K (the mask generation is VALU work -- ~120 instructions per four
+  // elements and site -- so it is spread over as many waves as possible: M / 16 x 4), partial sums meet in LDS in wave order
+  __shared__ f32x4 red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = (blockIdx.x * 4 + wave) * 16;
-  if (m0 >= M) return;
+  const int m0 = blockIdx.x * 16;
   const int r16 = lane & 15, kq = lane >> 4;
   const long m = min(m0 + r16, M - 1);
-  const bf16_t* xp = x + m * H + kq * 8;
-  const bf16_t* aq = a_cat + (long)r16 * H + kq * 8;
-  const bf16_t* av = a_cat + (long)(16 + r16) * H + kq * 8;
+  const int kper = H / 4;  // H % 256 == 0: whole 64-deep steps per wave
+  const bf16_t* xp = x + m * H + wave * kper + kq * 8;
+  const bf16_t* aq = a_cat + (long)r16 * H + wave * kper + kq * 8;
+  const bf16_t* av = a_cat + (long)(16 + r16) * H + wave * kper + kq * 8;
   f32x4 cq = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
   const bool drop = dq.p > 0.f;
-  for (int k = 0; k < H; k += 64) {  // two MFMA steps per iteration: 2 x 3 loads in flight
+  for (int k = 0; k < kper; k += 64) {  // two MFMA steps per iteration: 2 x 3 loads in flight
     const u32x4 x0 = *reinterpret_cast<const u32x4*>(xp + k), x1 = *reinterpret_cast<const u32x4*>(xp + k + 32);
     const u32x4 q0 = *reinterpret_cast<const u32x4*>(aq + k), q1 = *reinterpret_cast<const u32x4*>(aq + k + 32);
     const u32x4 v0 = *reinterpret_cast<const u32x4*>(av + k), v1 = *reinterpret_cast<const u32x4*>(av + k + 32);
     if (drop) {
-      const unsigned long long e0 = ((unsigned long long)m * (unsigned long long)H + (unsigned long long)(k + kq * 8)) >> 2;
+      const unsigned long long e0 =
+          ((unsigned long long)m * (unsigned long long)H + (unsigned long long)(wave * kper + k + kq * 8)) >> 2;
       cq = mfma16s<F16>(q0, masked8<F16>(x0, dq, e0), cq);
       cv = mfma16s<F16>(v0, masked8<F16>(x0, dv, e0), cv);
       cq = mfma16s<F16>(q1, masked8<F16>(x1, dq, e0 + 8), cq);
@@ -90,6 +94,12 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
       cv = mfma16s<F16>(v1, x1, cv);
     }
   }
+  red[wave][0][lane] = cq;
+  red[wave][1][lane] = cv;
+  __syncthreads();
+  if (wave != 0) return;
+  cq = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+  cv = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
   // lane: features 4 kq .. + 3 of token m0 + r16 in each 16-column group
   if (m0 + r16 < M) {
     bf16_t* row = t + (long)(m0 + r16) * 64 + 4 * kq;
@@ -226,11 +236,11 @@ extern "C" int tcavt_norm_npart(int M, int N, int K) { return norm_out_npart(M, 
 
 extern "C" int tcavt_lora_down(const void* x16, const void* a_cat, void* t, int M, int H, float scale, float dropout_p,
                                uint64_t dropout_seed, uint32_t site_q, uint32_t site_v, int dtype16, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(x16 && a_cat && t && M > 0 && H > 0 && H % 64 == 0 && is16(dtype16) && dropout_p >= 0.f && dropout_p < 1.f,
-                  "lora_down: bad args (H %% 64 == 0, 0 <= dropout_p < 1)");
+  TCAVT_CHECK_ARG(x16 && a_cat && t && M > 0 && H > 0 && H % 256 == 0 && is16(dtype16) && dropout_p >= 0.f && dropout_p < 1.f,
+                  "lora_down: bad args (H %% 256 == 0, 0 <= dropout_p < 1)");
   TCAVT_CHECK_ARG(aligned16(x16) && aligned16(a_cat) && aligned16(t), "lora_down: 16-byte alignment required");
   const DropoutP dq = make_dropout(dropout_p, dropout_seed, site_q), dv = make_dropout(dropout_p, dropout_seed, site_v);
-  const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+  const dim3 grid((unsigned)((M + 15) / 16)), block(256);
   if (dtype16 == TCAVT_F16)
     hipLaunchKernelGGL(lora_down_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16),
                        static_cast<const bf16_t*>(a_cat), static_cast<bf16_t*>(t), M, H, scale, dq, dv);
