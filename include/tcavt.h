@@ -90,6 +90,9 @@ int tcavt_init(int device, int* num_cus);
  * NORM_OUT  (producer: o_proj / down_proj; fp32 output, optionally + RESIDUAL): besides C the epilogue writes the
  *           16-bit copy of C's rows to `norm_h16` (leading dimension ldc; it is the next projection's A operand) and,
  *           for every row and 64-column group, the sum of squares of the fp32 values to norm_part[M][N / 64].
+ *           C == NULL (and residual == NULL) selects the 16-bit residual stream: norm_h16 itself is the stream, with
+ *           RESIDUAL it is read, added to the accumulator and rewritten in place (leading dimension ldc), and the
+ *           partial sums are those of the ROUNDED values -- 4 bytes per element through HBM instead of 10.
  * ROWSCALE  (consumer: ROPE or SILU_MUL epilogue; gamma is folded into W by the caller): the accumulator row m is
  *           multiplied by rsqrt(sum_i rowscale_part[m][i] / rowscale_h + rowscale_eps) first; the partials are added in
  *           index order (no atomics: bit-reproducible).  rowscale_npart % 4 == 0. */
@@ -207,6 +210,8 @@ int tcavt_cast_f32_16(const float* x, void* out16, int64_t n, int dtype16, tcavt
  * h16 / part (optional, both or neither): what the first decoder layer's fused RMSNorm needs (TCAVT_EPI_ROWSCALE) --
  * the 16-bit copy of h (same type as the table) and part[row][npart] with the row's sum of squares in slot 0 and zeros
  * in the others (npart = H / 64, the layout TCAVT_EPI_NORM_OUT writes).
+ * h == NULL (h16 given): the 16-bit residual stream of tcavt_llama_stack_forward -- no fp32 copy is written and the sum
+ * of squares is that of the ROUNDED values (the stream's own content).
  * ---------------------------------------------------------------------- */
 int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                      const float* vis_mod, const float* txt_mod, float* h, int B,
@@ -491,7 +496,12 @@ typedef struct tcavt_llama_stack_args {
   const float* gamma_final;        /* fp32 [H]: model.norm.weight */
   const float* rope_cos;           /* fp32 [L][32] */
   const float* rope_sin;
-  float* h;                        /* fp32 [M][H]: the fused input embeddings; updated in place unless a tape is kept */
+  float* h;                        /* fp32 [M][H]: the fused input embeddings; updated in place unless a tape is kept.
+                                      NULL: 16-bit residual stream -- h16 IS the stream (its partial sums those of the rounded
+                                      values: tcavt_embed_fuse with h == NULL, tcavt_rownorm_prep with rounded_sums = 1); every
+                                      residual epilogue adds to it in place (TCAVT_EPI_NORM_OUT with C == NULL) and the final
+                                      norm is tcavt_rmsnorm16.  4 instead of 10 bytes per element and epilogue through HBM;
+                                      accumulation, norms, softmax stay fp32.  Not with a tape (the backward reads fp32 streams) */
   void* h16;                       /* 16-bit [M][H]: copy of h (tcavt_embed_fuse writes it); rewritten by every residual epilogue */
   float* part;                     /* fp32 [M][>= npart_in], at least [M][H / 16]: partial sums of squares of h's rows (same producers) */
   const int32_t* kv_len;           /* int32 [B] */
@@ -540,8 +550,14 @@ int tcavt_norm_npart(int M, int N, int K);
 
 /* x16 = 16-bit copy of x fp32 [M][H], part[M][npart] = (sum of squares of the row, 0, 0, ...): the h16 / part inputs of
  * tcavt_llama_stack_forward for embeddings that do not come from tcavt_embed_fuse (HF-style inputs_embeds call) */
-int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16,
+/* rounded_sums != 0: the sums are those of the rounded 16-bit values (the 16-bit residual stream, h == NULL) */
+int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16, int rounded_sums,
                        tcavt_stream_t stream);
+
+/* RMSNorm of 16-bit rows x16 [M][H] (fp32 arithmetic; H % 256 == 0): out16 and / or out_f32 -- the final norm of the
+ * 16-bit residual stream (HF modeling_llama.py:62-67 on the stream's stored values) */
+int tcavt_rmsnorm16(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H, int dtype16,
+                    tcavt_stream_t stream);
 
 /* ========================================================================
  * Autoregressive text generation (LlamaMultiModal.generate_batch, scripts/train.py:577-654;
@@ -582,7 +598,7 @@ typedef struct tcavt_decode_args {
   const float* txt_mod;            /* fp32 [H]: text_modality_embedding (generated tokens are text tokens, train.py:526-527) */
   const int64_t* cur_tok;          /* int64 [B]: the token fed in this step */
   const int32_t* pos;              /* int32 [B]: its position = number of keys already in the cache */
-  float* h;                        /* fp32 [B][H] workspace */
+  float* h;                        /* fp32 [B][H] workspace, or NULL: 16-bit residual stream (as tcavt_llama_stack_args.h) */
   void* h16;                       /* 16-bit [B][H] */
   float* part;                     /* fp32 [B][H / 16] */
   void* qkv;                       /* 16-bit [B][(nq + 2 nkv) * 64] */

@@ -57,7 +57,11 @@ class Rounder:
         # Named contracts of the HIP path (model.set_storage): "fp16" = its default storage type, "bf16" = the round-1
         # contract kept for the LoRA-trainable variant.  In both, attention probabilities are carried in fp16 (P in
         # [0, 1]: csrc/attention.hip) and the RMSNorm gains stay fp32 (they are applied in fp32 inside the norm kernel).
-        named = {"bf16": {"default": "bf16", "p": "fp16", "gamma": "fp32"}, "fp16": {"default": "fp16", "gamma": "fp32"},
+        # "res" = the decoder's residual stream (the fused embeddings and the stream after each residual add): the fp16
+        # contract carries it in fp16 (csrc/stack.hip, h == NULL: the residual epilogues add to the 16-bit stream in place),
+        # the bf16 contract -- the LoRA-trainable variant, whose backward reads the streams -- in fp32.
+        named = {"bf16": {"default": "bf16", "p": "fp16", "gamma": "fp32", "res": "fp32"},
+                 "fp16": {"default": "fp16", "gamma": "fp32"},
                  "fp32": {"default": "fp32"}}
         self.modes = dict(contract) if isinstance(contract, dict) else dict(named[contract])
         self.scope = scope
@@ -265,7 +269,7 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
     i = torch.arange(L)
     causal = i[None, :] <= i[:, None]
     allowed = causal[None] & (attn_mask[:, None, :] > 0)  # [B, Lq, Lk]
-    h = embeds
+    h = r(embeds, "res")
     # RMSNorm (modeling_llama.py:62-67) in the algebraic form the HIP path computes it in (csrc/stack.hip): the gain is
     # folded into the following projection's weights (product in fp32, rounded once), the 16-bit operand is the rounded
     # residual stream itself, and rs = rsqrt(mean(h^2) + eps) scales the fp32 accumulator rows:
@@ -303,12 +307,12 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
         s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
         s = s.masked_fill(~allowed[:, None], float("-inf"))
         a = r((r(torch.softmax(s, dim=-1), "p") @ vh).permute(0, 2, 1, 3).reshape(B, L, nq * hd), "att")
-        h = h + a @ r(W[P + "self_attn.o_proj.weight"], "w").T
+        h = r(h + a @ r(W[P + "self_attn.o_proj.weight"], "w").T, "res")
         hb2, rs2 = norm_parts(h)
         g = rs2 * (hb2 @ r(W[P + "mlp.gate_proj.weight"] * g2, "w").T)
         u = rs2 * (hb2 @ r(W[P + "mlp.up_proj.weight"] * g2, "w").T)
         act = r(F.silu(g) * u, "act")
-        h = h + act @ r(W[P + "mlp.down_proj.weight"], "w").T
+        h = r(h + act @ r(W[P + "mlp.down_proj.weight"], "w").T, "res")
         if collect is not None:
             collect.append(h)
     return rms_norm(h, W[LLAMA + "norm.weight"], ll.rms_eps)  # the final norm is a kernel of its own: fp32 in, fp32 out

@@ -483,3 +483,103 @@ def test_skinny_gemm_matches_tile_kernels(gpu, M, dt):
     w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
     a_ = run(0, N, 0, w, torch.empty(M, N, device=dev))
     assert _rel(a_, x.float() @ w.float().T) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,tile", [(300, 128), (300, 256), (512, 257), (512, 272), (512, 0), (20, 0)])
+def test_gemm_norm_out_fp32_and_16bit_stream(gpu, M, tile, dt):
+    """TCAVT_EPI_NORM_OUT on every kernel form that serves it, in both residual-stream modes:
+    fp32 stream: C = residual + A W^T, 16-bit copy, partial sums of squares of the fp32 values;
+    16-bit stream (C == NULL): norm_h16 <- round(norm_h16 + A W^T) in place, partial sums of the ROUNDED values."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(7 * M + tile)
+    K, N = 512, 512
+    x = torch.randn(M, K, generator=g).to(dt).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    npart = ops.norm_npart(M, N, K) if tile == 0 else N // 64
+    gw = N // npart
+
+    def run(C, residual, h16, pt, epi):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.ldc = x.data_ptr(), K, w.data_ptr(), K, N
+        a.C = None if C is None else C.data_ptr()
+        if residual is not None:
+            a.residual, a.ldr = residual.data_ptr(), N
+        a.M, a.N, a.K, a.tile, a.epilogue = M, N, K, tile, epi
+        a.in_dtype, a.out_dtype = ops._DT[dt], capi.F32
+        a.norm_h16, a.norm_part = h16.data_ptr(), pt.data_ptr()
+        return capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr())
+
+    prod = x.float() @ w.float().T
+    for with_res in (True, False):
+        epi = capi.EPI_NORM_OUT | (capi.EPI_RESIDUAL if with_res else 0)
+        # fp32 stream
+        C, h16, pt = torch.empty(M, N, device=dev), torch.zeros(M, N, dtype=dt, device=dev), torch.zeros(M, npart, device=dev)
+        capi.check(run(C, res if with_res else None, h16, pt, epi), "gemm")
+        want = prod + (res if with_res else 0)
+        assert _rel(C, want) < 1e-5
+        assert torch.equal(h16, C.to(dt))
+        assert _rel(pt, C.view(M, npart, gw).pow(2).sum(-1)) < 1e-5
+        # 16-bit stream, in place
+        s0 = res.to(dt)
+        s16, pt2 = s0.clone(), torch.zeros(M, npart, device=dev)
+        capi.check(run(None, None, s16, pt2, epi), "gemm")
+        want16 = prod + (s0.float() if with_res else 0)
+        # (the accumulation order differs from torch's: values at a rounding boundary may land one 16-bit ulp apart)
+        ulp = 2.0 ** (-10 if dt == torch.float16 else -7)
+        assert ((s16.float() - want16).abs() <= ulp * want16.abs().clamp_min(2.0 ** -14) * 1.01 + 2e-5).all()  # (+ fp32 accumulation-order noise)
+        assert _rel(s16.float(), want16) < (5e-4 if dt == torch.float16 else 4e-3)
+        assert _rel(pt2, s16.float().view(M, npart, gw).pow(2).sum(-1)) < 1e-5  # sums of what is stored
+    # C == NULL with a residual pointer is refused (the stream is norm_h16 itself)
+    assert run(None, res, s16, pt2, capi.EPI_NORM_OUT | capi.EPI_RESIDUAL) != 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(37, 256), (8, 2048), (5, 8192)])
+def test_rmsnorm16(gpu, M, H, dt):
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(M + H)
+    x = (torch.randn(M, H, generator=g) * 3).to(dt).to(dev)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    o32 = torch.empty(M, H, device=dev)
+    o16 = torch.empty(M, H, dtype=dt, device=dev)
+    ops.rmsnorm16(x, gamma, 1e-5, out16=o16, out_f32=o32)
+    xf = x.float()
+    want = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    assert _rel(o32, want) < 1e-6
+    assert torch.equal(o16, o32.to(dt))
+
+
+def test_embed_fuse_16bit_stream(gpu):
+    """tcavt_embed_fuse with h == NULL: the 16-bit stream equals the rounded fp32 embedding rows, the partial sum (slot 0)
+    is that of the ROUNDED values; tcavt_rownorm_prep(rounded_sums) likewise."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(3)
+    B, Nq, Lt, H, V = 2, 4, 9, 256, 50
+    table = torch.randn(V, H, generator=g).to(torch.float16).to(dev)
+    ids = torch.randint(0, V, (B, Lt), generator=g).to(dev)
+    img = torch.randn(B * Nq, H, generator=g).to(dev)
+    vis, txt = torch.randn(H, generator=g).to(dev), torch.randn(H, generator=g).to(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    rows = B * (Nq + Lt)
+    h = torch.empty(rows, H, device=dev)
+    h16a, pa = torch.empty(rows, H, dtype=torch.float16, device=dev), torch.empty(rows, 4, device=dev)
+    ops.embed_fuse(table, ids, img, vis, txt, h, flag, h16=h16a, part=pa, npart=4)
+    h16b, pb = torch.empty_like(h16a), torch.empty_like(pa)
+    ops.embed_fuse(table, ids, img, vis, txt, None, flag, h16=h16b, part=pb, npart=4)
+    assert torch.equal(h16a, h16b) and torch.equal(h16b, h.to(torch.float16))
+    assert _rel(pa[:, 0], h.pow(2).sum(-1)) < 1e-6 and _rel(pb[:, 0], h16b.float().pow(2).sum(-1)) < 1e-6
+    assert (pb[:, 1:] == 0).all()
+    h16c, pc = torch.empty_like(h16a), torch.empty_like(pa)
+    ops.rownorm_prep(h, h16c, pc, npart=4, rounded_sums=True)
+    assert torch.equal(h16c, h16b) and _rel(pc[:, 0], pb[:, 0]) < 1e-6
+    assert flag.item() == 0

@@ -182,7 +182,8 @@ _SIGNATURES = {
     "tcavt_norm_npart": [c_int, c_int, c_int],
     "tcavt_lora_down": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint32,
                         ctypes.c_uint32, c_int, c_void_p],
-    "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_event_elapsed_ms": [c_void_p, c_void_p, ctypes.POINTER(c_float)],

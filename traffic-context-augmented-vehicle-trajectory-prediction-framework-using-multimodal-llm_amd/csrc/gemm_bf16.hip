@@ -80,7 +80,9 @@ __device__ __forceinline__ float row_rscale(const GemmP& p, long m) {
 // silu(gate)*up needs them); its own instantiation so that the production SiLU kernel keeps its register allocation.
 // EPI_NORM = TCAVT_EPI_NORM_OUT (fp32 residual output + 16-bit copy + per-row partial sums of squares): its own
 // instantiation as well -- inside EPI_GENERIC it pushed the 4-wave kernel's generic form into 460 bytes of scratch.
-enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4, EPI_NORM = 5 };
+// EPI_NORM16 = the same with C == NULL (16-bit residual stream, updated in place): again its own instantiation (both bodies in
+// one kernel spilled 150-500 bytes per lane in the 4-wave kernel).
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4, EPI_NORM = 5, EPI_NORM16 = 6 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -157,22 +159,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   // Fast paths for the forms the decoder launches (whole wave tile inside the matrix): row pointers hoisted,
   // no per-quad flag tests -- the general path below costs ~55 instructions per quad, these ~8.
   const bool whole = WHOLE_ONLY || (m_base + TM * 16 <= p.M && n_base + TN * 16 <= p.N);  // wave-uniform
-  if constexpr (EPI == EPI_NORM && TN % 4 == 0) {
+  if constexpr ((EPI == EPI_NORM || EPI == EPI_NORM16) && TN % 4 == 0) {
     // o_proj / down_proj of the decoder with the NEXT RMSNorm's input side fused in: besides the fp32 residual stream
     // the epilogue leaves its 16-bit copy (the next projection's A operand; gamma is folded into that projection's
     // weights) and, per 64-column group, the row's partial sum of squares -- the consumer adds the N / 64 partials in
     // index order and applies rsqrt(mean + eps) as a row scale (TCAVT_EPI_ROWSCALE).  No float atomics anywhere.
-    {
-      const bool res = p.flags & TCAVT_EPI_RESIDUAL;
-      const int npart = p.N >> 6;
+    // The residual loads and the stores go to the same buffer (in place), so the compiler keeps them in program order:
+    // written load-add-store per group, every group cost one full memory latency (16 groups per wave, ~25 us per tile
+    // with every CU in its epilogue at once).  Hence the loads are issued up front, D rows (m-tiles) ahead of their use:
+    // all of them in the 4-wave kernel, whose accumulators sit in AGPRs and whose operand registers are dead by now.
+    const bool res = p.flags & TCAVT_EPI_RESIDUAL;
+    const int npart = p.N >> 6;
+    if constexpr (EPI == EPI_NORM16) {
+      // 16-bit residual stream (eval / frozen-decoder passes): norm_h16 IS the stream -- read, added to and rewritten in
+      // place by the lane that owns the element; the partial sums are of the rounded values, i.e. of what the consumer
+      // multiplies.  4 bytes per element instead of 10.
+      constexpr int D = WHOLE_ONLY ? (TM > 4 ? 4 : TM) : 1;
+      u32x2 old[TM][TN];
+      auto fetch = [&](int j) {
+        const long m = m_base + j * 16 + ml;
+        const long mm = (WHOLE_ONLY || m < p.M) ? m : 0;
+        const bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const bool colok = WHOLE_ONLY || n_base + (i >> 2) * 64 < p.N;
+          old[j][i] = (res && colok) ? *reinterpret_cast<const u32x2*>(hrow + i * 16) : u32x2{0u, 0u};
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < D; ++j) fetch(j);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
+        if (j + D < TM) fetch(j + D < TM ? j + D : 0);
         const long m = m_base + j * 16 + ml;
         const bool rowok = WHOLE_ONLY || m < p.M;
         const long mm = rowok ? m : 0;  // (rows beyond M read row 0 and store nothing: the shuffles below need every lane)
-        float* crow = reinterpret_cast<float*>(p.C) + mm * p.ldc + n_base + nq;
         bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
-        const float* rrow = res ? p.residual + mm * p.ldr + n_base + nq : nullptr;
 #pragma unroll
         for (int g = 0; g < TN / 4; ++g) {
           const bool colok = WHOLE_ONLY || n_base + g * 64 < p.N;  // (N % 64 == 0: a group is inside or outside)
@@ -180,7 +202,52 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
           for (int i = g * 4; i < g * 4 + 4; ++i) {
             f32x4 v = acc[i][j];
-            if (res && colok) v += *reinterpret_cast<const f32x4*>(rrow + i * 16);
+            const u32x2 o = old[j][i];
+            v += f32x4{from16_lo<F16>(o[0]), from16_hi<F16>(o[0]), from16_lo<F16>(o[1]), from16_hi<F16>(o[1])};
+            const u32x2 w = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+            if (rowok && colok) *reinterpret_cast<u32x2*>(hrow + i * 16) = w;
+            const float r0 = from16_lo<F16>(w[0]), r1 = from16_hi<F16>(w[0]), r2 = from16_lo<F16>(w[1]), r3 = from16_hi<F16>(w[1]);
+            ss += r0 * r0;
+            ss += r1 * r1;
+            ss += r2 * r2;
+            ss += r3 * r3;
+          }
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          if (lane < 16 && rowok && colok) p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+        }
+      }
+      return;
+    } else {
+      constexpr int D = WHOLE_ONLY ? 2 : 1;
+      f32x4 rv[TM][TN];
+      auto fetch = [&](int j) {
+        const long m = m_base + j * 16 + ml;
+        const long mm = (WHOLE_ONLY || m < p.M) ? m : 0;
+        const float* rrow = p.residual + mm * p.ldr + n_base + nq;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const bool colok = WHOLE_ONLY || n_base + (i >> 2) * 64 < p.N;
+          rv[j][i] = (res && colok) ? *reinterpret_cast<const f32x4*>(rrow + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < D && j < TM; ++j) fetch(j);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        if (j + D < TM) fetch(j + D < TM ? j + D : 0);
+        const long m = m_base + j * 16 + ml;
+        const bool rowok = WHOLE_ONLY || m < p.M;
+        const long mm = rowok ? m : 0;  // (rows beyond M read row 0 and store nothing: the shuffles below need every lane)
+        float* crow = reinterpret_cast<float*>(p.C) + mm * p.ldc + n_base + nq;
+        bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
+#pragma unroll
+        for (int g = 0; g < TN / 4; ++g) {
+          const bool colok = WHOLE_ONLY || n_base + g * 64 < p.N;  // (N % 64 == 0: a group is inside or outside)
+          float ss = 0.f;
+#pragma unroll
+          for (int i = g * 4; i < g * 4 + 4; ++i) {
+            const f32x4 v = acc[i][j] + rv[j][i];
             if (rowok && colok) {
               *reinterpret_cast<f32x4*>(crow + i * 16) = v;
               *reinterpret_cast<u32x2*>(hrow + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
@@ -200,14 +267,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   }
   if constexpr (EPI == EPI_GENERIC) {
     if (whole && p.acc_scale == 1.f && p.out_kind == TCAVT_F32 && p.flags == TCAVT_EPI_RESIDUAL) {
+      // (C and residual may be one buffer: load-add-store per quad would serialise on the memory latency -- a row's
+      // residual quads are loaded together, one row ahead of their use)
+      f32x4 rv[TM][TN];
+      auto fetch = [&](int j) {
+        const float* rrow = p.residual + (long)(m_base + j * 16 + ml) * p.ldr + n_base + nq;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) rv[j][i] = *reinterpret_cast<const f32x4*>(rrow + i * 16);
+      };
+      fetch(0);
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
+        if (j + 1 < TM) fetch(j + 1 < TM ? j + 1 : 0);
         const long m = m_base + j * 16 + ml;
         float* crow = reinterpret_cast<float*>(p.C) + m * p.ldc + n_base + nq;
-        const float* rrow = p.residual + m * p.ldr + n_base + nq;
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-          *reinterpret_cast<f32x4*>(crow + i * 16) = acc[i][j] + *reinterpret_cast<const f32x4*>(rrow + i * 16);
+        for (int i = 0; i < TN; ++i) *reinterpret_cast<f32x4*>(crow + i * 16) = acc[i][j] + rv[j][i];
       }
       return;
     }
@@ -250,12 +325,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   }
   if constexpr (EPI == EPI_ROPE) {
     if (whole && p.out_kind == OUT16) {
+      // cos / sin rows are loaded D rows ahead of their use (all of them in the 4-wave kernel): issued between the stores
+      // of the output, which the compiler must assume they alias, every load cost a full L2 latency (32 of them per tile)
+      constexpr int D = WHOLE_ONLY ? TM : 1;
+      f32x4 cs[TM][2], sn[TM][2];
+      int pos[TM];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int m = m_base + j * 16 + ml;
-        const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
-        const float* crp = p.cosT + pos * 32 + nq;
-        const float* srp = p.sinT + pos * 32 + nq;
+        pos[j] = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
+      }
+      auto fetch = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          cs[j][i] = *reinterpret_cast<const f32x4*>(p.cosT + pos[j] * 32 + nq + i * 16);
+          sn[j][i] = *reinterpret_cast<const f32x4*>(p.sinT + pos[j] * 32 + nq + i * 16);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < D; ++j) fetch(j);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        if (j + D < TM) fetch(j + D < TM ? j + D : 0);
+        const int m = m_base + j * 16 + ml;
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base + nq;
         const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
@@ -267,8 +359,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const f32x4 lo = acc[hh * 4 + i][j] * rs, hi = acc[hh * 4 + i + 2][j] * rs;
-              const f32x4 c = *reinterpret_cast<const f32x4*>(crp + i * 16);
-              const f32x4 s = *reinterpret_cast<const f32x4*>(srp + i * 16);
+              const f32x4 c = cs[j][i];
+              const f32x4 s = sn[j][i];
               const f32x4 l2 = lo * c - hi * s;
               const f32x4 h2 = hi * c + lo * s;
               *reinterpret_cast<u32x2*>(crow + hh * 64 + i * 16) = u32x2{pack16x2<F16>(l2[0], l2[1]), pack16x2<F16>(l2[2], l2[3])};
@@ -289,7 +381,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
   if constexpr (WHOLE_ONLY && EPI == EPI_ROPE) {
     return;  // the 4-wave kernel is dispatched for bf16 output only on this epilogue (launch_w4 checks)
   }
-  if constexpr (EPI == EPI_NORM) {
+  if constexpr (EPI == EPI_NORM || EPI == EPI_NORM16) {
     return;  // (TN % 4 != 0: the 64x64 form, never dispatched for this epilogue)
   }
   if constexpr (EPI == EPI_GENERIC || EPI == EPI_DROP) {
@@ -1221,7 +1313,7 @@ static int launch_small(const GemmP& p, int tile, int batch, hipStream_t stream)
   const long wgs = (long)((q.M + 127) / 128) * ((q.N + 127) / 128) * batch;
   static const bool no_deep = getenv("TCAVT_GEMM_NO_DEEP") != nullptr;  // A/B switches
   static const bool no_64 = getenv("TCAVT_GEMM_NO_64") != nullptr;
-  if constexpr (EPI != EPI_ROPE && EPI != EPI_NORM) {
+  if constexpr (EPI != EPI_ROPE && EPI != EPI_NORM && EPI != EPI_NORM16) {
     // very small grids (Q-Former projections, LoRA down-projection): 64x64 tiles, four times the workgroups,
     // each K-tile costing a quarter of the DMA issue and MFMA time
     // (not for EPI_NORM: the 64x64 form's waves cover 32 columns, no whole 64-column group)
@@ -1420,17 +1512,27 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     if (!rowok) return;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) store_quad(p, m, n0 + c * 16 + nq, v[c] * p.acc_scale);
-  } else if constexpr (EPI == EPI_NORM) {
+  } else if constexpr (EPI == EPI_NORM || EPI == EPI_NORM16) {
     const bool res = p.flags & TCAVT_EPI_RESIDUAL;
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
       f32x4 o = v[c];
       const long off = mm * p.ldc + n0 + c * 16 + nq;
-      if (res) o += *reinterpret_cast<const f32x4*>(p.residual + mm * p.ldr + n0 + c * 16 + nq);
-      if (rowok) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
-        *reinterpret_cast<u32x2*>(p.norm_h16 + off) = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+      if constexpr (EPI == EPI_NORM16) {  // 16-bit residual stream: in place, sums of the rounded values (see gemm_epilogue)
+        if (res) {
+          const u32x2 old = *reinterpret_cast<const u32x2*>(p.norm_h16 + off);
+          o += f32x4{from16_lo<F16>(old[0]), from16_hi<F16>(old[0]), from16_lo<F16>(old[1]), from16_hi<F16>(old[1])};
+        }
+        const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
+        o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
+      } else {
+        if (res) o += *reinterpret_cast<const f32x4*>(p.residual + mm * p.ldr + n0 + c * 16 + nq);
+        if (rowok) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
+          *reinterpret_cast<u32x2*>(p.norm_h16 + off) = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+        }
       }
       ss += o[0] * o[0];
       ss += o[1] * o[1];
@@ -1481,7 +1583,8 @@ using namespace tcavt;
 
 extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(a != nullptr, "gemm_bf16: null args");
-  TCAVT_CHECK_ARG(a->A && a->W && a->C, "gemm_bf16: null A/W/C");
+  const bool stream16 = (a->epilogue & TCAVT_EPI_NORM_OUT) && a->C == nullptr;  // 16-bit residual stream in norm_h16
+  TCAVT_CHECK_ARG(a->A && a->W && (a->C || stream16), "gemm_bf16: null A/W/C");
   TCAVT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "gemm_bf16: bad M/N/K %d/%d/%d", a->M, a->N, a->K);
   TCAVT_CHECK_ARG(a->K % 64 == 0, "gemm_bf16: K=%d must be a multiple of 64", a->K);
   TCAVT_CHECK_ARG(a->K < (1 << 26), "gemm_bf16: K too large");
@@ -1517,7 +1620,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   int epi = a->epilogue;
   if (epi & TCAVT_EPI_BIAS) TCAVT_CHECK_ARG(a->bias && aligned16(a->bias), "gemm_bf16: BIAS needs an aligned bias pointer");
   if (epi & TCAVT_EPI_BIAS_ROW) TCAVT_CHECK_ARG(a->bias && !(epi & TCAVT_EPI_BIAS), "gemm_bf16: BIAS_ROW needs bias and excludes BIAS");
-  if (epi & TCAVT_EPI_RESIDUAL)
+  if ((epi & TCAVT_EPI_RESIDUAL) && !stream16)  // (stream16: the residual is norm_h16 itself)
     TCAVT_CHECK_ARG(a->residual && aligned16(a->residual) && a->ldr >= a->N && a->ldr % 4 == 0,
                     "gemm_bf16: RESIDUAL needs residual pointer and ldr >= N");
   if (epi & TCAVT_EPI_SILU_MUL)
@@ -1572,6 +1675,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                         a->N % 64 == 0 && a->norm_h16 && a->norm_part && aligned16(a->norm_h16) && a->dropout_p == 0.f &&
                         (a->acc_scale == 0.f || a->acc_scale == 1.f) && a->tile != 64,
                     "gemm_bf16: NORM_OUT goes with an fp32 output (+ RESIDUAL) only, N %% 64 == 0, and needs norm_h16 / norm_part");
+    TCAVT_CHECK_ARG(!stream16 || a->residual == nullptr,
+                    "gemm_bf16: NORM_OUT with C == NULL keeps the residual stream in norm_h16 (updated in place): residual must be NULL");
     p.norm_h16 = static_cast<bf16_t*>(a->norm_h16);
     p.norm_part = a->norm_part;
   }
@@ -1602,8 +1707,10 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       return f16 ? launch_skinny<EPI_ROPE, 2, true>(p, s) : launch_skinny<EPI_ROPE, 2, false>(p, s);
     if (e0 == TCAVT_EPI_SILU_MUL && !a->silu_preact && a->N % 32 == 0)
       return f16 ? launch_skinny<EPI_SILU, 2, true>(p, s) : launch_skinny<EPI_SILU, 2, false>(p, s);
-    if ((e0 & TCAVT_EPI_NORM_OUT) && a->N % 16 == 0)
+    if ((e0 & TCAVT_EPI_NORM_OUT) && a->N % 16 == 0) {
+      if (stream16) return f16 ? launch_skinny<EPI_NORM16, 1, true>(p, s) : launch_skinny<EPI_NORM16, 1, false>(p, s);
       return f16 ? launch_skinny<EPI_NORM, 1, true>(p, s) : launch_skinny<EPI_NORM, 1, false>(p, s);
+    }
     if (e0 == 0 && K2 == 0 && a->N % 16 == 0)
       return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
   }
@@ -1641,6 +1748,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     return f16 ? dispatch_tile<EPI_SILU, true>(p, tile, 1, s) : dispatch_tile<EPI_SILU, false>(p, tile, 1, s);
   }
   if (epi & TCAVT_EPI_ROPE) return f16 ? dispatch_tile<EPI_ROPE, true>(p, tile, 1, s) : dispatch_tile<EPI_ROPE, false>(p, tile, 1, s);
+  if ((epi & TCAVT_EPI_NORM_OUT) && stream16)
+    return f16 ? dispatch_tile<EPI_NORM16, true>(p, tile, 1, s) : dispatch_tile<EPI_NORM16, false>(p, tile, 1, s);
   if (epi & TCAVT_EPI_NORM_OUT) return f16 ? dispatch_tile<EPI_NORM, true>(p, tile, 1, s) : dispatch_tile<EPI_NORM, false>(p, tile, 1, s);
   if (a->dropout_p > 0.f) {  // small layers only (Q-Former, polygon encoder, LTSF): one 128x128 variant
     const int t = a->tile == 64 || a->tile == 128 ? a->tile : 0;

@@ -427,7 +427,7 @@ extern "C" int tcavt_gather_last(const void* src16, const int32_t* kv_len, void*
 
 extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(a && a->layers && a->gamma_final && a->rope_cos && a->rope_sin && a->table && a->txt_mod && a->cur_tok && a->pos &&
-                      a->h && a->h16 && a->part && a->qkv && a->att && a->act && a->k_cache && a->v_cache && a->x16 && a->logits &&
+                      a->h16 && a->part && a->qkv && a->att && a->act && a->k_cache && a->v_cache && a->x16 && a->logits &&
                       a->bad_id_flag,
                   "llama_decode_step: null pointer");
   TCAVT_CHECK_ARG(a->n_layers > 0 && a->B > 0 && a->H % 256 == 0 && a->I > 0 && a->nq > 0 && a->nkv > 0 && a->nq % a->nkv == 0 &&
@@ -439,7 +439,8 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   hipStream_t st = static_cast<hipStream_t>(stream);
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
-  TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->h /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
+  // (a->h == NULL: the residual stream is the 16-bit h16 itself, as in tcavt_llama_stack_forward)
+  TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->txt_mod /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
                              a->bad_id_flag, dt, a->h16, a->part, np_in, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
   const int group = nq / nkv;
@@ -502,7 +503,8 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
   }
-  TCAVT_TRY(tcavt_rmsnorm(a->h, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, nullptr, 0.f, 0, 0, dt, stream));
+  if (a->h == nullptr) TCAVT_TRY(tcavt_rmsnorm16(a->h16, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, dt, stream));
+  else TCAVT_TRY(tcavt_rmsnorm(a->h, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, nullptr, 0.f, 0, 0, dt, stream));
   // lm_head: tied to the embedding table (Llama-3.2-1B: tie_word_embeddings)
   tcavt_gemm_args g = {};
   g.A = a->x16; g.lda = H; g.W = a->table; g.ldw = H; g.C = a->logits; g.ldc = a->V;

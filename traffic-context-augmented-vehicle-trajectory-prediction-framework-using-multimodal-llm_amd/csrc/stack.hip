@@ -130,8 +130,9 @@ struct Ev {
 }  // namespace
 
 extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(a && a->layers && a->gamma_final && a->rope_cos && a->rope_sin && a->h && a->h16 && a->part && a->kv_len,
+  TCAVT_CHECK_ARG(a && a->layers && a->gamma_final && a->rope_cos && a->rope_sin && a->h16 && a->part && a->kv_len,
                   "llama_stack_forward: null pointer");
+  const bool stream16 = a->h == nullptr;  // the residual stream is the 16-bit h16 itself (no fp32 copy anywhere)
   TCAVT_CHECK_ARG(a->n_layers > 0 && a->B > 0 && a->L > 0 && a->nq > 0 && a->nkv > 0 && a->I > 0, "llama_stack_forward: bad shape");
   TCAVT_CHECK_ARG(a->H % 256 == 0, "llama_stack_forward: H = %d must be a multiple of 256 (H / 64 partial sums, added four at a time)", a->H);
   TCAVT_CHECK_ARG(is16(a->dtype16), "llama_stack_forward: dtype16 must be TCAVT_BF16 or TCAVT_F16");
@@ -154,6 +155,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (w.a_cat == nullptr) == (w.b_ext == nullptr),
                     "llama_stack_forward: layer %d: null weight", li);
     const bool tape = w.tape_h_mid != nullptr;
+    TCAVT_CHECK_ARG(!(tape && stream16), "llama_stack_forward: a tape keeps fp32 residual streams: h must be given");
     if (tape) TCAVT_CHECK_ARG(w.tape_h_out && w.tape_qkv && w.tape_gu && (!w.a_cat || w.tape_t), "llama_stack_forward: layer %d: incomplete tape", li);
     void* qkv = tape ? w.tape_qkv : a->qkv;
     void* t = tape && w.a_cat ? w.tape_t : a->t;
@@ -197,7 +199,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       tcavt_gemm_args g = {};
       g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = h_mid; g.ldc = H;
       g.M = M; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
-      g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
+      g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;  // (stream16: C = residual = NULL)
       g.norm_h16 = a->h16; g.norm_part = a->part;
       ev.rec(4);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -229,7 +231,69 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     h = h_out;
   }
   // final RMSNorm: its fp32 result is hidden_states[-1] (scripts/train.py:553), the 16-bit copy feeds the head's K / V projections
+  if (stream16) return tcavt_rmsnorm16(a->h16, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, dt, stream);
   return tcavt_rmsnorm(h, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, nullptr, 0.f, 0, 0, dt, stream);
+}
+
+// RMSNorm of 16-bit rows (the 16-bit residual stream's final norm): one wave per row, the row stays in registers when
+// H <= 4096 (u32x2 = 4 elements per lane and step), fp32 arithmetic as tcavt_rmsnorm.
+namespace {
+template <bool F16>
+__global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, float eps,
+                                                        bf16_t* __restrict__ out16, float* __restrict__ out_f32, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16_t* xr = x + row * H;
+  constexpr int NV = 16;  // 16 x 256 = 4096 columns in registers
+  u32x2 w[NV];
+  float ss = 0.f;
+  const int nv = H >> 8;  // (H % 256 == 0)
+  auto sq = [&](const u32x2& v) {
+    const float a = from16_lo<F16>(v[0]), b = from16_hi<F16>(v[0]), c = from16_lo<F16>(v[1]), d = from16_hi<F16>(v[1]);
+    ss += a * a + b * b + c * c + d * d;
+  };
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) {
+      w[i] = *reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4);
+      sq(w[i]);
+    }
+  for (int i = NV; i < nv; ++i) sq(*reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4));
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  auto emit = [&](int i, const u32x2& v) {
+    const int c = i * 256 + lane * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 y;
+    y[0] = from16_lo<F16>(v[0]) * rs * g[0];
+    y[1] = from16_hi<F16>(v[0]) * rs * g[1];
+    y[2] = from16_lo<F16>(v[1]) * rs * g[2];
+    y[3] = from16_hi<F16>(v[1]) * rs * g[3];
+    if (out16) *reinterpret_cast<u32x2*>(out16 + row * H + c) = u32x2{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
+    if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = y;
+  };
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) emit(i, w[i]);
+  for (int i = NV; i < nv; ++i) emit(i, *reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4));
+}
+}  // namespace
+
+extern "C" int tcavt_rmsnorm16(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H,
+                               int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x16 && gamma && (out16 || out_f32) && M > 0 && H > 0 && H % 256 == 0 && is16(dtype16),
+                  "rmsnorm16: bad args (H %% 256 == 0)");
+  TCAVT_CHECK_ARG(aligned16(x16) && aligned16(gamma), "rmsnorm16: unaligned input");
+  const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  if (dtype16 == TCAVT_F16)
+    hipLaunchKernelGGL(rmsnorm16_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16), gamma,
+                       eps, static_cast<bf16_t*>(out16), out_f32, M, H);
+  else
+    hipLaunchKernelGGL(rmsnorm16_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16), gamma,
+                       eps, static_cast<bf16_t*>(out16), out_f32, M, H);
+  TCAVT_CHECK_LAUNCH("rmsnorm16");
+  return TCAVT_OK;
 }
 
 extern "C" int tcavt_norm_npart(int M, int N, int K) { return norm_out_npart(M, N, K); }

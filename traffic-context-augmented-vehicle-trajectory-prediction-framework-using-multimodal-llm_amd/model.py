@@ -616,18 +616,27 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         H = self.shape.hidden
         return (self._ws.get("ll.h16", (M, H), self.storage, dev), self._ws.get("ll.part", (M, H // 16), torch.float32, dev))
 
+    @property
+    def stream16(self):
+        """16-bit residual stream (fp16 storage, no tape): the stream lives in norm_inputs()[0] only -- the residual
+        epilogues add to it in place, no fp32 copy exists (tcavt_llama_stack_args.h == NULL).  The LoRA-trainable variant
+        (bf16 storage, a tape for the backward) keeps fp32 streams."""
+        return self.storage == torch.float16 and not self.save_for_backward
+
     def norm_npart(self, M):
         """Partials per row the first fused norm of a pass over M rows reads (what embed_fuse / rownorm_prep must write)."""
         return ops.norm_npart(M, self.shape.hidden, self.shape.inter)
 
     def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None, kv_cache=None):
-        """h: fp32 [B*L, H] residual stream (updated in place unless a tape is kept); its norm_inputs() must have been
-        filled; kv_len int32 [B].  One C call: tcavt_llama_stack_forward (csrc/stack.hip).  kv_cache = (k, v, lmax):
+        """h: fp32 [B*L, H] residual stream (updated in place unless a tape is kept), or None with ``stream16`` (the stream
+        is norm_inputs()[0]); norm_inputs() must have been filled; kv_len int32 [B].  One C call: tcavt_llama_stack_forward (csrc/stack.hip).  kv_cache = (k, v, lmax):
         16-bit [layers, B, lmax, nkv*64] tensors that receive the rotated keys / values (generation prefill)."""
         from . import capi
 
         ll, P, ws = self.shape, self._prepared(), self._ws
-        dev, M, H = h.device, B * L, ll.hidden
+        dev, M, H = kv_len.device, B * L, ll.hidden
+        if (h is None) != self.stream16:
+            raise capi.TcavtError("decoder_stack: h must be None exactly when the 16-bit residual stream is in use (stream16)")
         nq, nkv, hd = ll.n_q_heads, ll.n_kv_heads, ll.head_dim
         nqkv = (nq + 2 * nkv) * hd
         if hd != 64:
@@ -682,7 +691,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 args.lora_dropout_p, args.dropout_seed, args.lora_first_site = dq[0], dq[1] & 0xFFFFFFFFFFFFFFFF, dq[2]
         args.layers = carr
         args.gamma_final, args.rope_cos, args.rope_sin = P.g_final.data_ptr(), cos.data_ptr(), sin.data_ptr()
-        args.h, args.h16, args.part, args.kv_len = h.data_ptr(), h16.data_ptr(), part.data_ptr(), kv_len.data_ptr()
+        args.h = None if h is None else h.data_ptr()
+        args.h16, args.part, args.kv_len = h16.data_ptr(), part.data_ptr(), kv_len.data_ptr()
         args.att, args.act = att.data_ptr(), act.data_ptr()
         for t_, nm, n_ in ((out_f32, "out_f32", M * H), (out_bf16, "out_bf16", M * H), (kv_len, "kv_len", B), (h, "h", M * H)):
             if t_ is not None and t_.numel() < n_:
@@ -695,7 +705,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             if out_bf16.dtype != self.storage:
                 raise capi.TcavtError(f"decoder_stack.out_bf16: {self.storage} required")
             args.out16 = out_bf16.data_ptr()
-        if h.dtype != torch.float32 or kv_len.dtype != torch.int32:
+        if (h is not None and h.dtype != torch.float32) or kv_len.dtype != torch.int32:
             raise capi.TcavtError("decoder_stack: h fp32 and kv_len int32 required")
         if kv_cache is not None:
             kc, vc, lmax = kv_cache
@@ -718,9 +728,14 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         """HF-call-shaped entry (train.py:445-453).  Only ``hidden_states[-1]`` is produced."""
         B, L, H = inputs_embeds.shape
         dev = inputs_embeds.device
-        h = self._ws.get("ll.h", (B * L, H), torch.float32, dev)
-        h.copy_(inputs_embeds.reshape(B * L, H))
-        ops.rownorm_prep(h, *self.norm_inputs(B * L, dev), npart=self.norm_npart(B * L))
+        if self.stream16:
+            h = None
+            ops.rownorm_prep(inputs_embeds.reshape(B * L, H).float().contiguous(), *self.norm_inputs(B * L, dev),
+                             npart=self.norm_npart(B * L), rounded_sums=True)
+        else:
+            h = self._ws.get("ll.h", (B * L, H), torch.float32, dev)
+            h.copy_(inputs_embeds.reshape(B * L, H))
+            ops.rownorm_prep(h, *self.norm_inputs(B * L, dev), npart=self.norm_npart(B * L))
         kv_len = torch.empty(B, dtype=torch.int32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), 0, kv_len, flag)
@@ -823,7 +838,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
             if pf is not None:  # a prefetch for some other tensor is in flight in the same workspaces
                 torch.cuda.current_stream().wait_stream(self._pf_stream)
             img = self._image_tokens(vision_embs)
-        h = ws.get("mm.h", (B * L, H), torch.float32, dev)
+        h = None if LW.stream16 else ws.get("mm.h", (B * L, H), torch.float32, dev)
         # error flags: the kernels only ever SET them, so they accumulate over forwards until check_flags() reads and
         # clears them (evaluate_model and Trainer.check_flags do; one host sync, off the hot path)
         flags = ws.get("mm.flags", (2,), torch.int32, dev, zero=True)
@@ -901,7 +916,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
             try:
                 # ---- prefill: image tokens + prompt through the decoder, keys / values of every layer into the cache
                 img = self._image_tokens(vision_embs_batch)
-                h = ws.get("gen.h", (B * L, H), torch.float32, dev)
+                h = None if LW.stream16 else ws.get("gen.h", (B * L, H), torch.float32, dev)
                 flags = ws.get("mm.flags", (2,), i32, dev, zero=True)
                 h16, part = LW.norm_inputs(B * L, dev)
                 ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part, npart=LW.norm_npart(B * L))
@@ -933,10 +948,12 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 if N > 1:
                     cos, sin = LW._rope_tables(Lmax, dev)
                     a = capi.DecodeArgs()
-                    bufs = dict(h=ws.get("gen.dh", (B, H), torch.float32, dev), h16=ws.get("gen.dh16", (B, H), st, dev),
+                    bufs = dict(h16=ws.get("gen.dh16", (B, H), st, dev),
                                 part=ws.get("gen.dpart", (B, H // 16), torch.float32, dev),
                                 qkv=ws.get("gen.dqkv", (B, nqkv), st, dev), att=ws.get("gen.datt", (B, ll.n_q_heads * ll.head_dim), st, dev),
                                 act=ws.get("gen.dact", (B, ll.inter), st, dev), t=ws.get("gen.dt", (B, 64), st, dev, zero=True))
+                    if not LW.stream16:
+                        bufs["h"] = ws.get("gen.dh", (B, H), torch.float32, dev)
                     for k_, v_ in bufs.items():
                         setattr(a, k_, v_.data_ptr())
                     a.layers, a.gamma_final = PL.carr, PL.g_final.data_ptr()

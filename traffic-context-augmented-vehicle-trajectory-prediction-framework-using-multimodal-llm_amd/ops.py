@@ -289,21 +289,24 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=No
     V, H = table.shape
     Nq = img.numel() // (B * H)
     _need(img, B * Nq * H, "embed.img")
-    _need(h, B * (Nq + Lt) * H, "embed.h")
+    if h is None and h16 is None:
+        raise capi.TcavtError("embed: h (fp32 stream) or h16 (16-bit residual stream) required")
+    if h is not None:
+        _req(h, torch.float32, "embed.h")
+        _need(h, B * (Nq + Lt) * H, "embed.h")
     _need(vis_mod, H, "embed.vis_mod")
     _need(txt_mod, H, "embed.txt_mod")
     _need(bad_flag, 1, "embed.bad_flag")
-    npart = 0
     if (h16 is None) != (part is None):
         raise capi.TcavtError("embed.h16 and embed.part go together")
     if h16 is not None:
         _req16(h16, "embed.h16", like=table)
         _req(part, torch.float32, "embed.part")
-        npart = npart or H // 64
+        npart = int(npart or H // 64)
         _need(h16, B * (Nq + Lt) * H, "embed.h16")
         _need(part, B * (Nq + Lt) * npart, "embed.part")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
-                                 V, ptr(bad_flag), _DT[table.dtype], ptr(h16), ptr(part), npart, stream_ptr()),
+                                 V, ptr(bad_flag), _DT[table.dtype], ptr(h16), ptr(part), npart if h16 is not None else 0, stream_ptr()),
           "tcavt_embed_fuse")
 
 
@@ -796,8 +799,28 @@ def llama_decode_step(args):
     check(lib().tcavt_llama_decode_step(ctypes.byref(args), stream_ptr()), "tcavt_llama_decode_step")
 
 
-def rownorm_prep(x, x16, part, npart=None):
-    """x16 = 16-bit copy of x [M, H]; part [M, npart] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm."""
+def rmsnorm16(x16, gamma, eps, out16=None, out_f32=None):
+    """RMSNorm of 16-bit rows (the final norm of the 16-bit residual stream): out16 and / or out_f32."""
+    _req16(x16, "rmsnorm16.x16")
+    _req(gamma, torch.float32, "rmsnorm16.gamma")
+    M, H = x16.shape
+    _need(gamma, H, "rmsnorm16.gamma")
+    if out16 is None and out_f32 is None:
+        out_f32 = torch.empty((M, H), dtype=torch.float32, device=x16.device)
+    if out16 is not None:
+        _req16(out16, "rmsnorm16.out16", like=x16)
+        _need(out16, M * H, "rmsnorm16.out16")
+    if out_f32 is not None:
+        _req(out_f32, torch.float32, "rmsnorm16.out_f32")
+        _need(out_f32, M * H, "rmsnorm16.out_f32")
+    check(lib().tcavt_rmsnorm16(ptr(x16), ptr(gamma), eps, ptr(out16), ptr(out_f32), M, H, _DT[x16.dtype], stream_ptr()),
+          "tcavt_rmsnorm16")
+    return out16 if out_f32 is None else out_f32
+
+
+def rownorm_prep(x, x16, part, npart=None, rounded_sums=False):
+    """x16 = 16-bit copy of x [M, H]; part [M, npart] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm.
+    rounded_sums: sums of the rounded values (16-bit residual stream)."""
     _req(x, torch.float32, "rownorm_prep.x")
     _req16(x16, "rownorm_prep.x16")
     _req(part, torch.float32, "rownorm_prep.part")
@@ -805,7 +828,8 @@ def rownorm_prep(x, x16, part, npart=None):
     npart = npart or H // 64
     _need(x16, M * H, "rownorm_prep.x16")
     _need(part, M * npart, "rownorm_prep.part")
-    check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], stream_ptr()), "tcavt_rownorm_prep")
+    check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], int(bool(rounded_sums)), stream_ptr()),
+          "tcavt_rownorm_prep")
 
 
 class StackEvents:
