@@ -88,6 +88,9 @@ def parse():
                          "ddp_model.train() (train.py:1152; dropout 0.1 in the lane-polygon encoder, Q-Former, LoRA branch, LTSF)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not start the (frozen) Q-Former of the next batch underneath the step in flight")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="train.py variant: do not run the frozen MLLM pass on a stream of its own (the decoder of step i+1 "
+                         "then waits for step i's backward and optimizer instead of running over them)")
     ap.add_argument("--no-graph", action="store_true", help="(kept for old command lines; same as --launch eager)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -322,12 +325,15 @@ def main():
     if args.mode == "train":
         trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4, lora_trainable=args.lora_trainable,
                                    max_grad_norm=1.0 if args.lora_trainable else None)
+        if args.no_pipeline:
+            m.pipeline_decoder = False
 
     def step(next_vision=None):
         if trainer is not None:
             return trainer.step(g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"],
                                 g["target_traj"], g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"],
-                                next_vision_embs=next_vision)
+                                next_vision_embs=next_vision, inputs_ready=True if m.pipeline_decoder else None)  # (the
+            # synthetic batch is resident: nothing writes the MLLM inputs between steps)
         return m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], y=g["target_traj"],
                  norm_stat=g["norm_stat"], input_ids=g["input_ids"], attention_mask=g["attention_mask"],
                  labels=g["labels"])
@@ -469,8 +475,12 @@ def main():
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
                 "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",
                 "launch": "eager" if graph is None else "hipGraph replay",
-                "pipelining": ("Q-Former of batch i+1 prefetched on a side stream during step i (every timed step runs "
-                               "one Q-Former pass; results identical)") if prefetch else "none",
+                "pipelining": "; ".join(
+                    ([("Q-Former of batch i+1 prefetched on a side stream during step i (every timed step runs one Q-Former "
+                       "pass; results identical)")] if prefetch else []) +
+                    ([("frozen MLLM pass on a stream of its own: the decoder of step i+1 runs over step i's head, backward "
+                       "and AdamW, which it does not depend on (every timed step runs one pass of each; results identical)")]
+                     if (graph is None and m.pipeline_decoder) else [])) or "none",
             },
             "achieved_model_tflops": round(value * gflop_per_sample(cfg, L) / 1e3, 1),
             "gflop_per_sample_forward": round(gflop_per_sample(cfg, L), 1),

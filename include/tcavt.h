@@ -535,6 +535,12 @@ typedef struct tcavt_llama_stack_args {
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
 
+/* SUM all-reduce, in place, of a flat fp32 buffer on the caller's RCCL communicator (`nccl_comm` is an ncclComm_t) and
+ * stream: one gradient bucket of the data-parallel step (the DistributedDataParallel wrap of scripts/train.py:1127 does
+ * this during backward; tcavt_amd.training.Trainer issues the same exchange through torch.distributed).  The mean is taken
+ * afterwards (tcavt_clip_grad_norm / tcavt_adamw grad_scale = 1 / world).  librccl is opened on first use. */
+int tcavt_allreduce_flat(float* buf, int64_t n, void* nccl_comm, tcavt_stream_t stream);
+
 /* LoRA down-projection of both adapters in one pass over x16 [M][H] (the 16-bit residual-stream copy):
  *   t[m][0:16] = scale * (mask_q o x16[m]) . a_cat[0:16]^T,   t[m][16:32] = scale * (mask_v o x16[m]) . a_cat[16:32]^T
  * t is 16-bit [M][64] (columns >= 32 untouched).  dropout_p > 0: PEFT's per-adapter lora_dropout (scripts/train.py:433-439)

@@ -409,3 +409,37 @@ def test_wgrad_tn_matches_transposed_product(gpu, xdt):
         outT = torch.zeros(H, 64, device=dev)
         ops.wgrad_tn(G, g0, n, X, outT, trans_out=True)
         assert rel_err(outT[:, :n].cpu(), ref.T.cpu()) < 2e-6 and (outT[:, n:] == 0).all()
+
+
+def test_allreduce_flat_on_a_raw_rccl_communicator(gpu):
+    """tcavt_allreduce_flat on an ncclComm_t the caller made itself (here: a one-rank communicator created through ctypes on
+    librccl): the sum over one rank is the buffer itself; a null communicator is an argument error, not a crash."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    buf = torch.randn(1 << 20, device=dev)
+    want = buf.clone()
+    with pytest.raises(capi.TcavtError):
+        ops.allreduce_flat(buf, None)
+    try:
+        rccl = ctypes.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 not loadable on this box")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        ops.allreduce_flat(buf, comm)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

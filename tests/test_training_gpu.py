@@ -436,3 +436,47 @@ def test_captured_step_replays_like_eager_steps(gpu):
         seen.append(gl3.item())
     tr3.release_graph()
     assert len(set(seen)) == 3 and all(np.isfinite(seen))  # lr = 0: only the masks change from replay to replay
+
+
+def test_pipelined_decoder_is_equivalent(gpu):
+    """model.pipeline_decoder (the frozen MLLM pass on a stream of its own, next step's decoder over this step's head /
+    backward / AdamW): same results as the one-stream order.  Two different batches alternate and no host sync happens
+    between the steps, so the two output slots and the cross-stream events are all exercised; the frozen MLLM's output
+    must be BIT-equal step by step, the trained parameters equal up to the float-atomic noise of the weight gradients."""
+    from tcavt_amd import model, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    ga = {k: v.to(dev) for k, v in t.items()}
+    gen = torch.Generator().manual_seed(11)
+    perm = torch.randperm(t["traj_emb"].shape[0], generator=gen)
+    gb = {k: v[perm].clone().to(dev) for k, v in t.items()}
+    gb["vision_emb"] = gb["vision_emb"] * 0.5 + 0.1
+    gb["input_ids"] = (gb["input_ids"] * 5 + 1) % cfg.llama.vocab
+
+    def run(pipeline):
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).train()
+        tr = training.Trainer(m, lr=1e-4)
+        assert m.pipeline_decoder  # the frozen-MLLM variant turns it on
+        m.pipeline_decoder = pipeline
+        hid, dec, losses = [], [], []
+        for i in range(6):
+            g = ga if i % 2 == 0 else gb
+            loss, d = tr.step(g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"],
+                              g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"],
+                              inputs_ready=True if pipeline else None)
+            hid.append(m.last.final_hidden_bf16.clone())
+            dec.append(d.clone())
+            losses.append(loss)
+        torch.cuda.synchronize()
+        m.mllm.check_flags()
+        return hid, dec, [l.item() for l in losses], tr.book.params.clone()
+
+    ha, da, la, pa = run(False)
+    hb, db, lb, pb = run(True)
+    for i in range(6):
+        assert torch.equal(ha[i], hb[i]), f"step {i}: the frozen MLLM's output differs"
+    assert torch.equal(da[0], db[0])
+    assert np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
+    assert not torch.equal(ha[0], ha[1])  # (the two batches do differ)

@@ -20,10 +20,10 @@ from oracle import forward as O  # noqa: E402
 from tcavt_amd import config, synth  # noqa: E402
 from tcavt_amd.weights import make_weights  # noqa: E402
 
-POINTS = ["w", "gamma", "xn", "t", "qkv", "p", "att", "act", "emb", "qf", "fh", "xa"]
+POINTS = ["w", "gamma", "xn", "t", "qkv", "p", "att", "act", "res", "emb", "qf", "fh", "xa"]
 NOTE = {"w": "decoder weights", "gamma": "RMSNorm gains", "xn": "normalised rows (A operand of q|k|v, gate|up)",
         "t": "LoRA down-projection", "qkv": "rotated q, k, v", "p": "attention probabilities", "att": "attention output",
-        "act": "silu(gate)*up", "emb": "embedding table", "qf": "Q-Former + q_proj (all points)",
+        "act": "silu(gate)*up", "res": "decoder residual stream (after every residual add)", "emb": "embedding table", "qf": "Q-Former + q_proj (all points)",
         "fh": "final hidden states handed to the head", "xa": "LTSF cross-attention head (all other points)"}
 
 
@@ -65,7 +65,8 @@ def main():
         return r
 
     rows = [row("all bf16 (round-1 contract, P fp16)", "bf16"),
-            row("all fp16", "fp16"),
+            row("all fp16 (the HIP path's contract: residual stream fp16)", "fp16"),
+            row("fp16, residual stream fp32 (the contract before the 16-bit stream)", {"default": "fp16", "gamma": "fp32", "res": "fp32"}),
             row("fp16, weights bf16", {"default": "fp16", "w": "bf16"}),
             row("bf16, weights fp16", {"default": "bf16", "p": "fp16", "w": "fp16"}),
             row("bf16, activations xn/att/act fp16", {"default": "bf16", "p": "fp16", "xn": "fp16", "att": "fp16", "act": "fp16"}),

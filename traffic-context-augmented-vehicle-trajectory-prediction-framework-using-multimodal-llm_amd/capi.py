@@ -183,6 +183,7 @@ _SIGNATURES = {
     "tcavt_lora_down": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint32,
                         ctypes.c_uint32, c_int, c_void_p],
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_allreduce_flat": [c_void_p, c_int64, c_void_p, c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

@@ -385,8 +385,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
     return;  // (TN % 4 != 0: the 64x64 form, never dispatched for this epilogue)
   }
   if constexpr (EPI == EPI_GENERIC || EPI == EPI_DROP) {
+    // Loads first, stores after: bias / residual loads written between the stores of C (which they may alias as far as
+    // the compiler knows) each waited for a full memory latency, TM x TN times per wave.  The column biases are loaded
+    // once, the row biases for all rows, the residual quads one row ahead of their use.
+    const bool has_bias = p.flags & TCAVT_EPI_BIAS, has_brow = p.flags & TCAVT_EPI_BIAS_ROW, has_res = p.flags & TCAVT_EPI_RESIDUAL;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[TN];
+    float bm[TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n_base + i * 16 + nq;
+      bq[i] = (has_bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
+      const int m = m_base + j * 16 + ml;
+      bm[j] = (has_brow && m < p.M) ? p.bias[m] : 0.f;
+    }
+    f32x4 rv[TM][TN];
+    auto fetch = [&](int j) {
+      const int m = m_base + j * 16 + ml;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int n = n_base + i * 16 + nq;
+        rv[j][i] = (has_res && m < p.M && n < p.N) ? *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n) : zero4;
+      }
+    };
+    fetch(0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      if (j + 1 < TM) fetch(j + 1 < TM ? j + 1 : 0);
       const int m = m_base + j * 16 + ml;
       if (m >= p.M) continue;
 #pragma unroll
@@ -394,10 +422,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         const int n = n_base + i * 16 + nq;
         if (n >= p.N) continue;
         f32x4 v = acc[i][j] * p.acc_scale;
-        if (p.flags & TCAVT_EPI_BIAS) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.flags & TCAVT_EPI_BIAS_ROW) {
-          const float bm = p.bias[m];
-          v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+        if (has_bias) v += bq[i];
+        if (has_brow) {
+          v[0] += bm[j]; v[1] += bm[j]; v[2] += bm[j]; v[3] += bm[j];
         }
         if (p.flags & TCAVT_EPI_RELU) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
@@ -408,8 +435,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           dropout_quad(p.drop, ((unsigned long long)m * (unsigned long long)p.N + (unsigned long long)n) >> 2, sc);
           v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
         }
-        if (p.flags & TCAVT_EPI_RESIDUAL)
-          v += *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.ldr + n);
+        if (has_res) v += rv[j][i];
         store_quad(p, m, n, v);
       }
     }

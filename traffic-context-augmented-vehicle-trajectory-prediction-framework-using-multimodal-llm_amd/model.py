@@ -817,7 +817,11 @@ class LlamaMultiModal(nn.Module, _Prepared):
                                vis=self.vision_modality_embedding.detach().reshape(-1).contiguous(),
                                txt=self.text_modality_embedding.detach().reshape(-1).contiguous())
 
-    def forward(self, vision_embs, context_str, input_ids=None, attention_mask=None, labels=None, return_bf16=False):
+    def forward(self, vision_embs, context_str, input_ids=None, attention_mask=None, labels=None, return_bf16=False,
+                out_slot=0):
+        """out_slot (0 / 1): which of two 16-bit output buffers receives the final hidden states -- the pipelined decoder
+        (MultiModalTrajectoryModel.pipeline_decoder) alternates them, the head of pass i still reads one while pass i + 1
+        writes the other."""
         if input_ids is None or attention_mask is None:
             raise NotImplementedError(
                 "the tokenizer branch (train.py:556-575) needs a tokenizer that cannot be fetched offline; "
@@ -853,7 +857,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
         # bf16 copy for the cross-attention K/V projections; XATTN_PAD zeroed tail rows let those
         # GEMMs run on key counts padded to a multiple of 64 (TransformerLTSF.forward)
-        final_b = ws.get("mm.finalb", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
+        final_b = ws.get("mm.finalb" if not out_slot else "mm.finalb1", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
         LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
         self._last_flags = flags
         if return_bf16:
@@ -1235,6 +1239,14 @@ class MultiModalTrajectoryModel(nn.Module):
         self._llm_cache = None  # (final_hidden, final_hidden_bf16) of an earlier pass on the same batch (evaluate_model)
         self.overlap_streams = True  # side stream for the LLM-independent small-kernel chains (see forward)
         self._side = None
+        # Pipelined decoder (train.py's frozen MLLM: nothing the decoder reads is written by the step's backward or
+        # optimizer): the MLLM pass runs on a stream of its own, so the decoder of step i + 1 starts as soon as the decoder
+        # of step i has finished and runs over step i's head / loss / backward / AdamW -- ~200 small dependent launches
+        # that leave the chip idle (2.2 of 17 ms).  Results are identical; every step still runs one pass of everything.
+        # Off by default; training.Trainer turns it on for the frozen-decoder variant.  See forward / inputs_ready.
+        self.pipeline_decoder = False
+        self.inputs_ready = None  # see forward
+        self._dec_stream, self._dec_slot, self._fwd_start_ev = None, 0, None
         # Train-mode dropout (the MC-dropout K-candidate protocol, test.py:1301-1342): active when the module
         # is in .train() mode; every forward uses seed dropout_seed + number of forwards so far.
         self.dropout_seed, self._fwd_count = 0x5EED, 0
@@ -1297,6 +1309,12 @@ class MultiModalTrajectoryModel(nn.Module):
 
     def forward(self, x, vision_embs, context_str, lane_polygon_batch, lane_polygon_len, y=None, norm_stat=None,
                 input_ids=None, attention_mask=None, labels=None):
+        """(Signature of the reference's forward, scripts/train.py:914.)  With pipeline_decoder, `self.inputs_ready` says
+        when the MLLM inputs of THIS call (vision_embs, input_ids, attention_mask) are ready on the device: a
+        torch.cuda.Event (e.g. of the copy stream that uploaded the batch), True (already resident, nobody is writing them),
+        or None: ready once the work queued on the current stream so far is done (always correct; the decoder then cannot
+        start before the previous step's optimizer has finished).  It is consumed by the call (reset to None)."""
+        inputs_ready, self.inputs_ready = self.inputs_ready, None
         B = x.size(0)
         dev = x.device
         x = x.contiguous()
@@ -1324,6 +1342,28 @@ class MultiModalTrajectoryModel(nn.Module):
             front = self.ltsf.front(x)
         if self._llm_cache is not None:  # evaluate_model(reuse_prefix=True): the MLLM pass of an earlier candidate
             final_hidden, final_b = self._llm_cache
+        elif main is not None and self.pipeline_decoder and not self.mllm.llama_wrapper.save_for_backward:
+            if self._dec_stream is None:
+                self._dec_stream = torch.cuda.Stream(device=dev)
+            D = self._dec_stream
+            if inputs_ready is None:
+                D.wait_stream(main)
+            elif inputs_ready is not True:
+                D.wait_event(inputs_ready)
+            # output slot s was last read by the head / backward of the pass before the previous one: all of that was on the
+            # caller's queue when the previous forward began
+            if self._fwd_start_ev is not None:
+                D.wait_event(self._fwd_start_ev)
+            self._fwd_start_ev = torch.cuda.Event()
+            self._fwd_start_ev.record(main)
+            with torch.cuda.stream(D):
+                final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids, attention_mask=attention_mask,
+                                                     labels=labels, return_bf16=True, out_slot=self._dec_slot)
+                done = torch.cuda.Event()
+                done.record(D)
+            self._dec_slot ^= 1
+            final_hidden.record_stream(main)
+            main.wait_event(done)
         else:
             final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids,
                                                  attention_mask=attention_mask, labels=labels, return_bf16=True)

@@ -799,6 +799,16 @@ def llama_decode_step(args):
     check(lib().tcavt_llama_decode_step(ctypes.byref(args), stream_ptr()), "tcavt_llama_decode_step")
 
 
+def allreduce_flat(buf, nccl_comm):
+    """In-place SUM all-reduce of a flat fp32 buffer on a raw RCCL communicator (an ncclComm_t as int / c_void_p) and the
+    current stream: tcavt_allreduce_flat, the C host's form of the gradient-bucket exchange (Trainer itself goes through
+    torch.distributed, whose process group owns its communicator)."""
+    _req(buf, torch.float32, "allreduce_flat.buf")
+    comm = nccl_comm if isinstance(nccl_comm, ctypes.c_void_p) else ctypes.c_void_p(int(nccl_comm) if nccl_comm else None)
+    check(lib().tcavt_allreduce_flat(ptr(buf), buf.numel(), comm, stream_ptr()), "tcavt_allreduce_flat")
+    return buf
+
+
 def rmsnorm16(x16, gamma, eps, out16=None, out_f32=None):
     """RMSNorm of 16-bit rows (the final norm of the 16-bit residual stream): out16 and / or out_f32."""
     _req16(x16, "rmsnorm16.x16")

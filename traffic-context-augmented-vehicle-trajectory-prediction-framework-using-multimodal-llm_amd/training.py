@@ -80,6 +80,9 @@ class Trainer:
             self._lora_stacked = self._stacked_lora_views(lora)
         model.lane_polygon_encoder.save_for_backward = True
         model.ltsf.save_for_backward = True
+        # train.py's frozen MLLM: its pass reads nothing this step's backward / optimizer writes, so it runs on a stream
+        # of its own and the next step's decoder overlaps this step's head, backward and AdamW (model.pipeline_decoder)
+        model.pipeline_decoder = not self.lora_trainable and dev.type == "cuda"
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
@@ -127,14 +130,17 @@ class Trainer:
 
     # ---- one optimisation step -----------------------------------------------------------------
     def forward_backward(self, x, vision_embs, lane_polygon_batch, lane_polygon_len, y, norm_stat, input_ids,
-                         attention_mask, labels=None, next_vision_embs=None):
+                         attention_mask, labels=None, next_vision_embs=None, inputs_ready=None):
         """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``.
         next_vision_embs (optional): the next batch's vision embeddings, already resident -- its frozen Q-Former is
         enqueued on a side stream between this step's forward and backward (model.prefetch) and runs under this step's
-        decoder; results are identical with or without it."""
+        decoder; results are identical with or without it.
+        inputs_ready: see MultiModalTrajectoryModel.forward (pipelined decoder of the frozen-MLLM variant: an event /
+        True lets this step's decoder start under the previous step's head, backward and optimizer)."""
         m = self.model
         with torch.no_grad():
             self.book.grads.zero_()  # optimizer.zero_grad()
+            m.inputs_ready = inputs_ready
             loss, decoded = m(x, vision_embs, None, lane_polygon_batch, lane_polygon_len, y=y, norm_stat=norm_stat,
                               input_ids=input_ids, attention_mask=attention_mask, labels=labels)
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat])
@@ -142,7 +148,7 @@ class Trainer:
             if next_vision_embs is not None:
                 m.prefetch(next_vision_embs)  # before the backward: its leaf work shares the prefetch stream's queue
             B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
-            fh_b = m.mllm._ws.get("mm.finalb", (B * L + 64, m.llama_hidden_size), m.mllm.storage, x.device)
+            fh_b = m.last.final_hidden_bf16  # [B * L + 64 zeroed pad rows, H]
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
                         after_ltsf=lambda: self._allreduce_bucket(0, self.n_ltsf))
             self._allreduce_bucket(self.n_ltsf, self.n_base)
@@ -239,6 +245,7 @@ class Trainer:
         if self.device_step is False and self.step_count > 0 and not self.skip_nonfinite:
             self._ctl[0] = self.step_count  # continue the bias-correction count of the eager steps taken so far
         self.device_step = True
+        self.model.pipeline_decoder = False  # (one graph = one step: nothing to overlap across replays)
         if self.model.training:
             self._epoch = torch.zeros(1, dtype=torch.int64, device=self.book.grads.device)
             ops.set_dropout_epoch(self._epoch)
