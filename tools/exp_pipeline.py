@@ -87,3 +87,35 @@ with torch.no_grad():
         step()
 
     print(f"pipelined (MLLM of the next batch on its own stream, D prio {prio}, head prio {hp}): {timed(piped):.3f} ms", flush=True)
+
+    # ---- the head (forward from cached MLLM result + loss + backward + AdamW) as a hipGraph: how much of its 3.9 ms is
+    # launch / cross-stream dependency latency that a replay removes?
+    if os.environ.get("EXP_HEAD_GRAPH", "1") == "1":
+        m.pipeline_decoder = False
+        graph, _ = tr.capture(g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"],
+                              g["norm_stat"], g["input_ids"], g["attention_mask"], g["labels"])
+        print(f"head alone as a hipGraph replay: {timed(graph.replay):.3f} ms", flush=True)
+
+        def piped_graph():
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            D.wait_event(ev)
+            prev = state["done"]
+            with torch.cuda.stream(D):
+                mllm_only()
+                d = torch.cuda.Event()
+                d.record(D)
+            state["done"] = d
+            if prev is not None:
+                main.wait_event(prev)
+            graph.replay()
+
+        print(f"pipelined, head as a graph: {timed(piped_graph):.3f} ms", flush=True)
+
+        def serial_graph():
+            mllm_only()
+            graph.replay()
+
+        print(f"serial (MLLM pass incl. Q-Former, then head graph): {timed(serial_graph):.3f} ms", flush=True)
+        tr.release_graph()

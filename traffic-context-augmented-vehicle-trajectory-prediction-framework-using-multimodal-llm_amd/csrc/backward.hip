@@ -456,15 +456,23 @@ __global__ __launch_bounds__(256) void nlinear_bwd_kernel(const float* __restric
     gbias[c * S + s] = a;
   }
   if (gin) {
+    // gin[b][t] for t < T-1: one (b, t) pair per thread over the channel's weights in LDS (the first version gave a sample to
+    // one thread: B of 256 threads busy, S*(T-1) dependent global loads each); then the last column from the row sums
+    float* Ws = gg + B * S;  // [S][T]
+    for (int i = tid; i < S * T; i += 256) Ws[i] = W[(long)c * S * T + i];
+    __syncthreads();
+    for (int bt = tid; bt < B * (T - 1); bt += 256) {
+      const int b = bt / (T - 1), t = bt % (T - 1);
+      float a = 0.f;
+      for (int s = 0; s < S; ++s) a = fmaf(gg[b * S + s], Ws[s * T + t], a);
+      gin[((long)b * T + t) * C + c] = a;
+      u[b * T + t] = a;  // (u is dead by now: reuse it for the row sums below)
+    }
+    __syncthreads();
     for (int b = tid; b < B; b += 256) {
       float tot = 0.f, acc_last = 0.f;
       for (int s = 0; s < S; ++s) tot += gg[b * S + s];
-      for (int t = 0; t < T - 1; ++t) {
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a = fmaf(gg[b * S + s], W[((long)c * S + s) * T + t], a);
-        gin[((long)b * T + t) * C + c] = a;
-        acc_last += a;
-      }
+      for (int t = 0; t < T - 1; ++t) acc_last += u[b * T + t];
       gin[((long)b * T + T - 1) * C + c] = tot - acc_last;
     }
   }
@@ -734,8 +742,8 @@ extern "C" int tcavt_nlinear_bwd(const float* in_tok, const float* W, const floa
                                  int64_t g_ss, float* gW, float* gbias, float* gin_tok, int B, int C, int T, int S,
                                  tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(in_tok && W && g && gW && gbias && B > 0 && C > 0 && T > 0 && S > 0, "nlinear_bwd: bad args");
-  const long lds = ((long)B * T + (long)B * S) * 4;
-  TCAVT_CHECK_ARG(lds <= 64 * 1024, "nlinear_bwd: B*(T+S)*4 = %ld bytes exceeds 64 KiB", lds);
+  const long lds = ((long)B * T + (long)B * S + (long)S * T) * 4;
+  TCAVT_CHECK_ARG(lds <= 64 * 1024, "nlinear_bwd: (B*(T+S) + S*T)*4 = %ld bytes exceeds 64 KiB", lds);
   hipLaunchKernelGGL(nlinear_bwd_kernel, dim3(C), dim3(256), lds, S_(stream), in_tok, W, g, (long)g_sb, (long)g_sc,
                      (long)g_ss, gW, gbias, gin_tok, B, C, T, S);
   TCAVT_CHECK_LAUNCH("nlinear_bwd");

@@ -14,7 +14,9 @@ namespace tcavt {
 // General element strides: A[m][k] = A[m*rsA + k*csA], W[n][k] = W[n*rsW + k*csW], so the same
 // kernel serves y = x W^T (forward), gx = gy W and gW = gy^T x (backward) without transposes.
 // 64x64 tile, 4 waves (2x2) of 32x32, K-step 16 staged through LDS ([row][k], 17-float rows);
-// global->register prefetch of step s+1 overlaps the MFMAs of step s.  The global read pattern
+// global->register prefetch of step s+1 overlaps the MFMAs of step s.  (Measured and rejected in round 2: K-step 64 with 32
+// unconditional loads in flight per thread -- 10-40 % slower on the head's shapes, whose cost is the K-serial chain of one or
+// a few workgroups, not the loads.)  The global read pattern
 // follows the operand's contiguous direction (lanes walk k when csX == 1, rows otherwise).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void gemm_f32_fetch(const float* __restrict__ X, long rs, long cs, int r0, int R, int k0,
@@ -168,18 +170,28 @@ __global__ void ltsf_front_kernel(const float* __restrict__ x, const float* __re
 __global__ void ltsf_decode_kernel(const float* __restrict__ e, const float* __restrict__ dw,
                                    const float* __restrict__ db, const float* __restrict__ lane,
                                    float* __restrict__ dec, int B, int C, int T, int To) {
+  // grid (chunks of 256 outputs, B): one output per thread, its T weights loaded in one burst (the first version gave a
+  // sample to one workgroup, 8 outputs x T dependent weight loads per thread: 95 us on the critical path of the head)
   extern __shared__ float es[];  // [T][C]
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   for (int i = threadIdx.x; i < T * C; i += blockDim.x) es[i] = e[(long)b * T * C + i];
   __syncthreads();
-  for (int cs = threadIdx.x; cs < C * To; cs += blockDim.x) {
-    const int c = cs / To, s = cs % To;
-    const float last = es[(T - 1) * C + c];
-    const float* wr = dw + ((long)c * To + s) * T;
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc = fmaf(wr[t], es[t * C + c] - last, acc);
-    dec[(long)b * C * To + cs] = acc + db[c * To + s] + last + lane[(long)b * C * To + cs];
+  const int cs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cs >= C * To) return;
+  const int c = cs / To, s = cs % To;
+  const float last = es[(T - 1) * C + c];
+  const float* wr = dw + ((long)c * To + s) * T;
+  float acc = 0.f;
+  int t = 0;
+  for (; t + 6 <= T; t += 6) {
+    float w[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) w[u] = wr[t + u];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc = fmaf(w[u], es[(t + u) * C + c] - last, acc);
   }
+  for (; t < T; ++t) acc = fmaf(wr[t], es[t * C + c] - last, acc);
+  dec[(long)b * C * To + cs] = acc + db[c * To + s] + last + lane[(long)b * C * To + cs];
 }
 
 __global__ void transpose_ct_kernel(const float* __restrict__ in, float* __restrict__ of,
@@ -374,7 +386,7 @@ extern "C" int tcavt_ltsf_decode(const float* e_tok, const float* dec_w, const f
   TCAVT_CHECK_ARG(e_tok && dec_w && dec_b && lane_adj && dec && B > 0 && C > 0 && T > 0 && To > 0,
                   "ltsf_decode: bad args");
   TCAVT_CHECK_ARG((long)T * C * 4 <= 48 * 1024, "ltsf_decode: T*C too large for LDS");
-  hipLaunchKernelGGL(ltsf_decode_kernel, dim3(B), dim3(256), T * C * sizeof(float),
+  hipLaunchKernelGGL(ltsf_decode_kernel, dim3((C * To + 255) / 256, B), dim3(256), T * C * sizeof(float),
                      static_cast<hipStream_t>(stream), e_tok, dec_w, dec_b, lane_adj, dec, B, C, T, To);
   TCAVT_CHECK_LAUNCH("ltsf_decode");
   return TCAVT_OK;
