@@ -257,16 +257,23 @@ class Trainer:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        try:
+            with torch.cuda.graph(graph):
+                if self._epoch is not None:
+                    ops.dropout_epoch_advance(self._epoch)
+                out = self.step(*args, **kw)
+        finally:
+            # The captured kernels carry the epoch's address in their (by-value) arguments; the library-wide pointer is only
+            # needed while launches are being recorded.  Clearing it here means no later eager launch reads the epoch, and a
+            # Trainer that is dropped without release_graph() leaves no dangling pointer behind in the library.
             if self._epoch is not None:
-                ops.dropout_epoch_advance(self._epoch)
-            out = self.step(*args, **kw)
+                ops.set_dropout_epoch(None)
+        graph._tcavt_epoch = self._epoch  # the graph's kernels read it on every replay: it lives as long as the graph
         return graph, out
 
     def release_graph(self):
-        if self._epoch is not None:
-            ops.set_dropout_epoch(None)
-            self._epoch = None
+        """Forget the captured step's device-side dropout epoch (the graph object keeps its own reference)."""
+        self._epoch = None
 
     def optimizer_counters(self):
         """(applied, skipped) updates of the gated optimizer (one host sync)."""
