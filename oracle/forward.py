@@ -397,7 +397,22 @@ def ltsf_forward(W, cfg, x, poly_emb, final_hidden, r, drop=_ident, xattn_pad=64
     v = r(fh @ r(Win[2 * H:]).T + bin_[2 * H:])
     # (the HIP kernel draws this site's mask over score rows padded to a multiple of `xattn_pad` keys)
     Lk = fh.shape[1]
-    a = r(mha_core(q, k, v, cfg.cross_nhead, drop=drop, drop_cols=(Lk + xattn_pad - 1) // xattn_pad * xattn_pad))
+    drop_cols = (Lk + xattn_pad - 1) // xattn_pad * xattn_pad
+    if r.mode() == "fp32":
+        a = r(mha_core(q, k, v, cfg.cross_nhead, drop=drop, drop_cols=drop_cols))
+    else:
+        # The 16-bit contracts follow the HIP path's absorbed form (model.TransformerLTSF.forward): with To queries against
+        # Lk keys per sample the K / V projections move to the query / output side,
+        #     q_h (fh W_k[h]^T + b_k)^T = (q_h W_k[h]) fh^T + const per query (softmax-invariant),
+        #     P_h (fh W_v[h]^T + b_v)   = (P_h fh) W_v[h]^T + b_v,
+        # identical to the lines above in exact arithmetic; the rounding points are q' and ctx instead of k and v.
+        nh = cfg.cross_nhead
+        dh = H // nh
+        Wk, Wv = r(Win[H:2 * H]).view(nh, dh, H), r(Win[2 * H:]).view(nh, dh, H)
+        qh = q.view(B, To, nh, dh)
+        s = torch.stack([r(qh[:, :, h] @ Wk[h]) @ fh.transpose(1, 2) for h in range(nh)], dim=1) / math.sqrt(dh)
+        p = drop(torch.softmax(s, dim=-1), cols=drop_cols) if drop is not _ident else torch.softmax(s, dim=-1)
+        a = r(torch.cat([r(p[:, h] @ fh) @ Wv[h].T + bin_[2 * H + h * dh: 2 * H + (h + 1) * dh] for h in range(nh)], dim=-1))
     cross = r(a @ r(W["ltsf.decoder.cross_attn.out_proj.weight"]).T + W["ltsf.decoder.cross_attn.out_proj.bias"])
     fused = dec_t + linear(cross, W, "ltsf.decoder.dec_unproj", r)
     f = layer_norm(fused, W, "ltsf.decoder.fusion_layer.0")

@@ -212,17 +212,20 @@ class Backward:
         ca = dec.cross_attn
         self.lin_bwd_bf16("co", att, ca.out_proj.weight, g_cross, G[pl + "decoder.cross_attn.out_proj.weight"],
                           G[pl + "decoder.cross_attn.out_proj.bias"], gx=g_att)
-        # attention core
-        g_q, g_k, g_v, L = self._xattn_core(g_att, B, To, H, nh, dh)
-        # in-projection (packed [3H, H] weight / [3H] bias)
+        # attention core + in-projection (packed [3H, H] weight / [3H] bias)
         gWin, gbin = G[pl + "decoder.cross_attn.in_proj_weight"], G[pl + "decoder.cross_attn.in_proj_bias"]
         g_proj = self._buf("g_proj", (M, H), torch.bfloat16)
-        self.lin_bwd_bf16("q", proj, ca.in_proj_weight[:H], g_q, gWin[:H], gbin[:H], gx=g_proj)
-        fh_b = self._fh_b
-        fhT = self.lin_bwd_bf16("k", fh_b[: B * L], ca.in_proj_weight[H:2 * H], g_k[: B * L], gWin[H:2 * H],
-                                gbin[H:2 * H], pin=0)
-        self.lin_bwd_bf16("v", fh_b[: B * L], ca.in_proj_weight[2 * H:], g_v[: B * L], gWin[2 * H:], gbin[2 * H:],
-                          xT=fhT, pin=0)
+        if m._absorbed:  # the forward ran the absorbed form: k / v never existed, their weight gradients come from q', ctx
+            g_q = self._xattn_absorbed(g_att, q, B, To, H, nh, dh, gWin, gbin)
+            self.lin_bwd_bf16("q", proj, ca.in_proj_weight[:H], g_q, gWin[:H], gbin[:H], gx=g_proj)
+        else:
+            g_q, g_k, g_v, L = self._xattn_core(g_att, B, To, H, nh, dh)
+            self.lin_bwd_bf16("q", proj, ca.in_proj_weight[:H], g_q, gWin[:H], gbin[:H], gx=g_proj)
+            fh_b = self._fh_b
+            fhT = self.lin_bwd_bf16("k", fh_b[: B * L], ca.in_proj_weight[H:2 * H], g_k[: B * L], gWin[H:2 * H],
+                                    gbin[H:2 * H], pin=0)
+            self.lin_bwd_bf16("v", fh_b[: B * L], ca.in_proj_weight[2 * H:], g_v[: B * L], gWin[2 * H:], gbin[2 * H:],
+                              xT=fhT, pin=0)
         # proj = dec_t W_dp^T + b_dp
         g_dt2 = self._buf("g_dt2", (M, C))
         self.lin_bwd_bf16("dp", dec_tb, dec.dec_proj.weight, g_proj, G[pl + "decoder.dec_proj.weight"],
@@ -379,6 +382,79 @@ class Backward:
             g_k, g_v = self._xattn_kv_grads(g_att, dS, q, B, To, H, nh, dh, L, Lp, Tp)
         return g_q, g_k, g_v, L
 
+    def _xattn_absorbed(self, g_att, q, B, To, H, nh, dh, gWin, gbin):
+        """Backward of the absorbed cross-attention (model.TransformerLTSF.forward), per head h with F = the sample's final
+        hidden states (a constant: the MLLM is frozen), q' = q_h W_k[h], S = q' F^T / sqrt(dh), P = dropout(softmax(S)),
+        ctx = P F, att_h = ctx W_v[h]^T + b_v:
+            gW_v[h] = g_att_h^T ctx      gb_v = colsum(g_att)      g_ctx = g_att_h W_v[h]
+            g_P = g_ctx F^T              g_S = softmax'(P, g_P)    g_q' = g_S F
+            gW_k[h] = q_h^T g_q'         gb_k = 0 (softmax-invariant)                 g_q_h = g_q' W_k[h]^T
+        Every contraction over the B*L hidden-state rows of the un-absorbed form (dW_k, dW_v, the V recompute: three
+        chip-filling GEMMs + two transposes of the hidden states) becomes a contraction over the B*To query rows."""
+        m = self.m.ltsf
+        ws, dev = m._ws, g_att.device
+        L = self._L
+        Lp = _rup(L, XATTN_PAD)
+        M = B * To
+        Mp = _rup(M, 64)
+        ca = m.decoder.cross_attn
+        st = m.storage
+        bf = torch.bfloat16
+        scale = 1.0 / math.sqrt(dh)
+        ctx = ws.get("lt.ctx", (nh, M, H), st, dev)
+        Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
+        # bf16 copies of the hidden states for the gradient-side contractions: per-sample transposed [H][B*Lp] (converted
+        # while transposing, keys padded to Lp with zeros) and, transposed back, row-major [B*Lp][H]
+        fhTb = self._buf("xa.fhTb", (H, B * Lp), bf)
+        ops.transpose16(self._fh_b, fhTb, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
+        fhb = self._buf("xa.fhb", (B * Lp, H), bf)
+        ops.transpose16(fhTb, fhb, H, B * Lp, H)
+        # ---- value side
+        with self._leaf():
+            ops.colsum(g_att, gbin[2 * H:], M, H, accumulate=True)
+        gaT = self._buf("xa.gaT2", (H, Mp), bf)  # g_att^T: rows h*dh.. are head h's
+        ops.transpose16(g_att, gaT, M, H, Mp)
+        g_ctx = self._buf("xa.g_ctx", (nh, M, H), bf)
+        for h in range(nh):
+            Wv_h = ca.in_proj_weight[2 * H + h * dh: 2 * H + (h + 1) * dh]  # [dh, H] fp32 parameter rows
+            WvT = self._buf(f"xa.WvT{h}", (H, dh), bf)
+            ops.transpose_f32_bf16(Wv_h.detach(), WvT, dh, H, dh)
+            ops.gemm_bf16(g_att[:, h * dh:(h + 1) * dh], WvT, out=g_ctx[h])
+            with self._leaf():
+                ctxT = self._buf(f"xa.ctxT{h}", (H, Mp), bf)
+                ops.transpose16(ctx[h], ctxT, M, H, Mp)
+                ops.gemm_bf16(gaT[h * dh:(h + 1) * dh], ctxT, out=gWin[2 * H + h * dh: 2 * H + (h + 1) * dh])
+        # ---- scores
+        dP = self._buf("xa.dP", (B * nh * To, Lp))
+        ops.gemm_batched(g_ctx, fhb, dP, M=To, N=Lp, K=H, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                         sA=(To * H, M * H), sW=(Lp * H, 0), sC=(nh * To * Lp, To * Lp), tile=64)
+        xsp = getattr(m, "drop_xattn", None)
+        if xsp is not None:  # the softmax backward needs the un-dropped probabilities and the masked dP
+            ops.dropout_(dP, xsp)
+            Pu = self._buf("xa.Pu", (B * nh * To, Lp), torch.float16)
+            ops.softmax_rows(ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), Pu, B * nh * To, L, Lp, Lp, Lp)
+        else:
+            Pu = Pm
+        dS = self._buf("xa.dS", (B * nh * To, Lp), bf)
+        ops.softmax_bwd_rows(Pu, dP, dS, scale, B * nh * To, L, Lp, Lp, Lp, Lp)
+        # ---- query side
+        g_qp = self._buf("xa.g_qp", (nh, M, H), bf)
+        ops.gemm_batched(dS, fhTb, g_qp, M=To, N=H, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                         sA=(nh * To * Lp, To * Lp), sW=(Lp, 0), sC=(To * H, M * H), tile=64)
+        g_q = self._buf("xa.g_q", (M, H), bf)
+        for h in range(nh):
+            Wk_h = ca.in_proj_weight[H + h * dh: H + (h + 1) * dh]
+            Wkb = self._buf(f"xa.Wkb{h}", (dh, H), bf)
+            ops.cast_bf16(Wk_h.detach(), out=Wkb)
+            ops.gemm_bf16(g_qp[h], Wkb, out=g_q[:, h * dh:(h + 1) * dh])
+            with self._leaf():
+                qT = self._buf(f"xa.qT{h}", (dh, Mp), bf)
+                ops.transpose16(q[:, h * dh:(h + 1) * dh], qT, M, dh, Mp, ld_in=H)
+                gqpT = self._buf(f"xa.gqpT{h}", (H, Mp), bf)
+                ops.transpose16(g_qp[h], gqpT, M, H, Mp)
+                ops.gemm_bf16(qT, gqpT, out=gWin[H + h * dh: H + (h + 1) * dh])
+        return g_q
+
     def _recompute_v(self, B, L, H):
         P = self.m.ltsf._prepared()
         v = self._buf("xa.v", (B * L + XATTN_PAD, H), torch.bfloat16, zero=True)
@@ -469,10 +545,11 @@ class Backward:
         main = torch.cuda.current_stream()
         # the cross-attention backward needs V row-major (the forward kept only V^T): a chip-filling GEMM that depends on
         # no gradient -> started now on a side stream, off the gradient chain
-        with _Fork(self._leaf_streams[0]):
-            self._recompute_v(B, L, fh_b.shape[1])
-            self._v_ready = torch.cuda.Event()
-            self._v_ready.record()
+        if not self.m.ltsf._absorbed:
+            with _Fork(self._leaf_streams[0]):
+                self._recompute_v(B, L, fh_b.shape[1])
+                self._v_ready = torch.cuda.Event()
+                self._v_ready.record()
 
         def start_polygon(g_poly):
             with _Fork(self._poly_stream):

@@ -1094,6 +1094,10 @@ class TransformerLTSF(nn.Module, _Prepared):
         self.save_for_backward = False  # set by training.Trainer
         self.dropout_p, self.dctx = dropout_rate, None
         self._kv_stream = None
+        # absorbed cross-attention (see forward): on for fp16 storage; training.Trainer(lora_trainable=True) turns it off
+        # (that variant's backward wants dL/dk, dL/dv of the un-absorbed form)
+        self.absorb_kv = True
+        self._absorbed = False
 
     def _prepare(self):
         dec, C = self.decoder, self.d_model
@@ -1109,7 +1113,9 @@ class TransformerLTSF(nn.Module, _Prepared):
             w_dp=_bf16(dec.dec_proj.weight), w_q=_bf16(ca.in_proj_weight[:H]), w_k=_bf16(ca.in_proj_weight[H:2 * H]),
             w_v=_bf16(ca.in_proj_weight[2 * H:]), b_q=ca.in_proj_bias.detach()[:H].contiguous(),
             b_k=ca.in_proj_bias.detach()[H:2 * H].contiguous(), b_v=ca.in_proj_bias.detach()[2 * H:].contiguous(),
-            w_co=_bf16(ca.out_proj.weight), w_un=_bf16(dec.dec_unproj.weight))
+            w_co=_bf16(ca.out_proj.weight), w_un=_bf16(dec.dec_unproj.weight),
+            # absorbed cross-attention (forward): W_k per head, transposed -- [nh][H][dh], the W operand of q' = q_h W_k[h]
+            wk_T=_bf16(ca.in_proj_weight[H:2 * H].detach().view(dec.cross_nhead, H // dec.cross_nhead, H).transpose(1, 2)))
 
     def front(self, x):
         """The part of forward() that does not depend on the LLM: token projection, per-channel N-Linear
@@ -1145,23 +1151,33 @@ class TransformerLTSF(nn.Module, _Prepared):
         # on the decoder chain below (lane_fc -> N-Linear decoder -> post-MLP -> dec_proj -> q projection: one-workgroup
         # launches): they go to a side stream and join before the scores.
         main = torch.cuda.current_stream() if dev.type == "cuda" else None
-        if main is not None:
+        absorb = self.absorb_kv and self.storage == torch.float16
+        self._absorbed = absorb  # (the backward follows the form the forward ran)
+        if absorb:
+            kv_ctx = None
+        elif main is not None:
             if self._kv_stream is None:
                 self._kv_stream = streams.side_stream(dev, 1)
             self._kv_stream.wait_stream(main)
             kv_ctx = torch.cuda.stream(self._kv_stream)
         else:
             kv_ctx = contextlib.nullcontext()
-        with kv_ctx:
-            # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
-            kx = ws.get("lt.k", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
-            ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
-            # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
-            # (roles of weights and activations swapped, batched over samples), so that P.V is again
-            # a K-contiguous A.W^T product
-            vT = ws.get("lt.vT", (H, B * Lp), torch.float16, dev)
-            ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
-                             sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
+        if absorb:
+            # fh^T per sample [H][B*Lp] (keys padded to Lp with zeros): the W operand of ctx = P . fh.  No K / V projection:
+            # see the absorbed form below.
+            fhT = ws.get("lt.fhT", (H, B * Lp), self.storage, dev)
+            ops.transpose16(final_hidden_bf16, fhT, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
+        else:
+            with kv_ctx:
+                # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
+                kx = ws.get("lt.k", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
+                ops.gemm_bf16(final_hidden_bf16[: B * L], P.w_k, out=kx, bias=P.b_k)
+                # V projection emitted TRANSPOSED and in fp16: vT[d][b*Lp + l] = W_v[d] . x[b*L + l] + b_v[d]
+                # (roles of weights and activations swapped, batched over samples), so that P.V is again
+                # a K-contiguous A.W^T product
+                vT = ws.get("lt.vT", (H, B * Lp), torch.float16, dev)
+                ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
+                                 sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
         e = _front if _front is not None else self.front(x)
         lane = ws.get("lt.lane", (B, C * To), torch.float32, dev)
         ops.gemm_f32(lane_polygon_emb.contiguous(), dec.lane_fc.weight, out=lane, bias=dec.lane_fc.bias)
@@ -1184,18 +1200,42 @@ class TransformerLTSF(nn.Module, _Prepared):
         ops.gemm_bf16(dec_tb, P.w_dp, out=proj, bias=dec.dec_proj.bias)
         q = ws.get("lt.q", (B * To, H), self.storage, dev)
         ops.gemm_bf16(proj, P.w_q, out=q, bias=P.b_q)
-        if main is not None:
-            main.wait_stream(self._kv_stream)
-        # scores[b,h] = q_bh . k_bh^T / sqrt(dh)  (fp32), softmax -> fp16 probabilities (zero beyond L)
         S = ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev)
-        ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
-                         sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh))
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
-        self.drop_xattn = _spec(self.dctx, self.dropout_p)
-        ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
         att = ws.get("lt.att", (B * To, H), self.storage, dev)
-        ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
-                         sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
+        M = B * To
+        if absorb:
+            # Absorbed form.  With To (30) queries per sample against L (256) keys the K / V projections of the final hidden
+            # states (2 x 2 M H^2 = 137 GFLOP, the head's two chip-filling GEMMs -- and three more in the backward) move to
+            # the query / output side, where they cost 2 x 2 (B To) H^2 = 16 GFLOP:
+            #     scores_h = q_h (fh W_k[h]^T + b_k)^T  =  (q_h W_k[h]) fh^T  + const per query   (softmax-invariant: b_k drops out)
+            #     att_h    = P_h (fh W_v[h]^T + b_v)    =  (P_h fh) W_v[h]^T + b_v               (rows of P sum to 1)
+            # Same arithmetic as nn.MultiheadAttention (train.py:795-798) in exact arithmetic; the rounding points move from
+            # k, v to q' = q_h W_k[h] and ctx_h = P_h fh (oracle/forward.py restates both forms).
+            qp = ws.get("lt.qp", (nh, M, H), self.storage, dev)
+            for h in range(nh):
+                ops.gemm_bf16(q[:, h * dh:(h + 1) * dh], P.wk_T[h], out=qp[h])
+            ops.gemm_batched(qp, final_hidden_bf16, S, M=To, N=Lp, K=H, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                             sA=(To * H, M * H), sW=(L * H, 0), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh),
+                             tile=64)
+            self.drop_xattn = _spec(self.dctx, self.dropout_p)
+            ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
+            ctx = ws.get("lt.ctx", (nh, M, H), self.storage, dev)
+            ops.gemm_batched(Pm, fhT, ctx, M=To, N=H, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                             sA=(nh * To * Lp, To * Lp), sW=(Lp, 0), sC=(To * H, M * H), tile=64)
+            for h in range(nh):
+                ops.gemm_bf16(ctx[h], P.w_v[h * dh:(h + 1) * dh], out=att[:, h * dh:(h + 1) * dh],
+                              bias=P.b_v[h * dh:(h + 1) * dh])
+        else:
+            if main is not None:
+                main.wait_stream(self._kv_stream)
+            # scores[b,h] = q_bh . k_bh^T / sqrt(dh)  (fp32), softmax -> fp16 probabilities (zero beyond L)
+            ops.gemm_batched(q, kx, S, M=To, N=Lp, K=dh, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                             sA=(To * H, dh), sW=(L * H, dh), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh))
+            self.drop_xattn = _spec(self.dctx, self.dropout_p)
+            ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
+            ops.gemm_batched(Pm, vT, att, M=To, N=dh, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                             sA=(nh * To * Lp, To * Lp), sW=(Lp, dh * B * Lp), sC=(To * H, dh))
         cross = ws.get("lt.cross", (B * To, H), self.storage, dev)
         ops.gemm_bf16(att, P.w_co, out=cross, bias=dec.cross_attn.out_proj.bias)
         fused = ws.get("lt.fused", (B * To, C), torch.float32, dev)

@@ -34,15 +34,16 @@ def _req(t, dtype, name):
 _H16 = (torch.float16, torch.bfloat16)
 
 
-def _req16(t, name, like=None):
-    """16-bit storage tensor (fp16 = the forward path's default, or bf16); `like`: must share that tensor's dtype."""
+def _req16(t, name, like=None, rows_ok=False):
+    """16-bit storage tensor (fp16 = the forward path's default, or bf16); `like`: must share that tensor's dtype.
+    rows_ok: a 2-D view with unit column stride (a column slice of a wider matrix) is accepted as well."""
     if t is None:
         return
     if not t.is_cuda and not _ALLOW_CPU:
         raise capi.TcavtError(f"{name}: tensor must live on the GPU (no CPU fallback)")
     if t.dtype not in _H16 or (like is not None and t.dtype != like.dtype):
         raise capi.TcavtError(f"{name}: expected {'fp16 or bf16' if like is None else like.dtype}, got {t.dtype}")
-    if not t.is_contiguous():
+    if not t.is_contiguous() and not (rows_ok and t.dim() == 2 and t.stride(1) == 1):
         raise capi.TcavtError(f"{name}: tensor must be contiguous")
 
 
@@ -69,8 +70,8 @@ def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
     """
-    _req16(a, "gemm_bf16.a")
-    _req16(w, "gemm_bf16.w", like=a)
+    _req16(a, "gemm_bf16.a", rows_ok=True)  # (A may be a column slice: lda = its row stride)
+    _req16(w, "gemm_bf16.w", like=a, rows_ok=True)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K

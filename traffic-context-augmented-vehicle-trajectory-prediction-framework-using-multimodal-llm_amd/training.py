@@ -77,6 +77,7 @@ class Trainer:
         if self.lora_trainable:
             self.lbw = LoraBackward(model, self.book)
             model.mllm.llama_wrapper.save_for_backward = True
+            model.ltsf.absorb_kv = False  # _lora_backward starts from dL/dk, dL/dv of the un-absorbed cross-attention
             self._lora_stacked = self._stacked_lora_views(lora)
         model.lane_polygon_encoder.save_for_backward = True
         model.ltsf.save_for_backward = True
