@@ -763,6 +763,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                                                     llama_shape)
         self.llama_hidden_size = self.llama_wrapper.hidden_size
         # the reference uses nn.Identity when the sizes agree (train.py:492-495); they never do here
+        self.skip_f32_hidden = False  # training.Trainer (frozen-MLLM variant): see forward
         self.q_proj = _Linear(q_hidden_size, self.llama_hidden_size)
         self.vision_modality_embedding = _p(1, 1, self.llama_hidden_size)
         self.text_modality_embedding = _p(1, 1, self.llama_hidden_size)
@@ -854,11 +855,17 @@ class LlamaMultiModal(nn.Module, _Prepared):
             self._img_consumed.record()
         kv_len = ws.get("mm.kvlen", (B,), torch.int32, dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), Nq, kv_len, flags[1:2])
-        final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
-        # bf16 copy for the cross-attention K/V projections; XATTN_PAD zeroed tail rows let those
-        # GEMMs run on key counts padded to a multiple of 64 (TransformerLTSF.forward)
+        # 16-bit copy for the head's cross-attention; XATTN_PAD zeroed tail rows let its GEMMs run on key counts padded to a
+        # multiple of 64 (TransformerLTSF.forward)
         final_b = ws.get("mm.finalb" if not out_slot else "mm.finalb1", (B * L + XATTN_PAD, H), self.storage, dev, zero=True)
-        LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
+        if self.skip_f32_hidden and return_bf16 and LW.stream16:
+            # the head reads the 16-bit copy only: skip the fp32 hidden_states[-1] (67 MB written by the final norm on the
+            # decoder's critical path); the 16-bit tensor stands in for it (shape carrier)
+            final = final_b[: B * L].view(B, L, H)
+            LW.decoder_stack(h, kv_len, B, L, out_bf16=final_b)
+        else:
+            final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
+            LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
         self._last_flags = flags
         if return_bf16:
             return final, Nq, final_b

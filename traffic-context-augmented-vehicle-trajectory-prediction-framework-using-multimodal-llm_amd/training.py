@@ -84,6 +84,7 @@ class Trainer:
         # train.py's frozen MLLM: its pass reads nothing this step's backward / optimizer writes, so it runs on a stream
         # of its own and the next step's decoder overlaps this step's head, backward and AdamW (model.pipeline_decoder)
         model.pipeline_decoder = not self.lora_trainable and dev.type == "cuda"
+        model.mllm.skip_f32_hidden = not self.lora_trainable  # the head consumes the 16-bit final hidden states only
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
