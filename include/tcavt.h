@@ -130,7 +130,8 @@ typedef struct tcavt_gemm_args {
   int64_t sAo, sAi, sWo, sWi, sCo, sCi;
   /* Train-mode dropout fused into the generic epilogue, applied after bias / ReLU and before the residual
    * (nn.Dropout placement of nn.Transformer*Layer and the LTSF blocks, scripts/train.py:358,402,405,664-671,749):
-   * element (m, n) is kept iff the Philox4x32-10 word of flat index m*N+n at (seed, site) maps to u >= p, and
+   * element (m, n) is kept iff the 16-bit Philox4x32-10 draw of flat index e = m*N+n at (seed, site) -- half-word e & 7 of
+   * the call with counter e >> 3 -- is >= ceil(p * 65536), and
    * scaled by 1/(1-p).  dropout_p == 0 disables it.  See csrc/philox.hpp. */
   float dropout_p;
   uint32_t dropout_site;

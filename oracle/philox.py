@@ -1,7 +1,7 @@
 """CPU restatement (numpy) of the dropout mask generator in csrc/philox.hpp -- TEST INFRASTRUCTURE ONLY.
 
-Philox4x32-10 with key = 64-bit seed and counter = (quad index lo, hi, site, 0); element e of a dropout
-site takes word e & 3 of quad e >> 2; keep <=> (word >> 8) * 2^-24 >= p."""
+Philox4x32-10 with key = 64-bit seed and counter = (octet index lo, hi, site, 0); element e of a dropout
+site takes 16-bit draw e & 7 of octet e >> 3 (order w0.lo, w0.hi, w1.lo, ...); keep <=> draw >= ceil(p * 65536)."""
 import numpy as np
 
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
@@ -26,10 +26,11 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def keep_mask(n, p, seed, site):
     """Boolean keep mask of the first n elements of dropout site `site` under `seed`."""
-    nq = (n + 3) // 4
-    q = np.arange(nq, dtype=np.uint64)
-    words = philox4x32_10((q & MASK).astype(np.uint32), (q >> np.uint64(32)).astype(np.uint32),
-                          np.full(nq, site, np.uint32), np.zeros(nq, np.uint32), seed & 0xFFFFFFFF, seed >> 32)
-    w = np.stack(words, axis=1).reshape(-1)[:n]
-    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return u >= np.float32(p)
+    no = (n + 7) // 8
+    o = np.arange(no, dtype=np.uint64)
+    words = philox4x32_10((o & MASK).astype(np.uint32), (o >> np.uint64(32)).astype(np.uint32),
+                          np.full(no, site, np.uint32), np.zeros(no, np.uint32), seed & 0xFFFFFFFF, seed >> 32)
+    w = np.stack(words, axis=1)  # [octets, 4 words]
+    halves = np.stack([w & np.uint32(0xFFFF), w >> np.uint32(16)], axis=2).reshape(-1)[:n]  # w0.lo, w0.hi, w1.lo, ...
+    thr = int(np.ceil(np.float32(p) * np.float32(65536.0)))
+    return halves >= np.uint32(min(thr, 65535))

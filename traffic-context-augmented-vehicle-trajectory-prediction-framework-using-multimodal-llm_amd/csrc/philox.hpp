@@ -1,10 +1,13 @@
 // Counter-based RNG for dropout (train-mode forward; the MC-dropout K-candidate protocol of
 // scripts/test.py:1301-1342 runs the model in train mode under no_grad).  Philox4x32-10 (Salmon et al.,
-// SC'11): key = 64-bit seed, counter = (element-quad index lo, hi, site id, 0) -> four uint32 per call,
-// one per element of a quad.  The mask of element e at dropout site s under seed k is therefore a pure
-// function of (k, s, e): any kernel (forward now, backward later) regenerates it without storing it,
-// and the CPU restatement in oracle/philox.py reproduces it bit for bit.
-// keep(e) <=> uniform24(e) >= p,  y = x * keep / (1 - p)     (torch.nn.functional.dropout semantics)
+// SC'11): key = 64-bit seed, counter = (element-octet index lo, hi, site id, 0) -> four uint32 = eight 16-bit draws per
+// call, one per element of an octet (element e: call e >> 3, half-word e & 7 in the order w0.lo, w0.hi, w1.lo, ...).
+// The mask of element e at dropout site s under seed k is therefore a pure function of (k, s, e): any kernel (forward
+// now, backward later) regenerates it without storing it, and the CPU restatement in oracle/philox.py reproduces it bit
+// for bit.   keep(e) <=> u16(e) >= ceil(p * 65536),  y = x * keep / (1 - p)   (torch.nn.functional.dropout semantics; the
+// keep probability is 1 - ceil(65536 p) / 65536: 0.899994 for p = 0.1).  Sixteen bits per decision instead of a whole
+// word halve the generator's VALU work where a lane masks eight consecutive elements (the LoRA down-projection spends its
+// time here: two masks over all B L x 2048 activations per layer).
 #pragma once
 #include <stdint.h>
 
@@ -13,6 +16,7 @@ namespace tcavt {
 struct DropoutP {
   float p;              // 0 => disabled
   float inv_keep;       // 1 / (1 - p)
+  unsigned int thr16;   // ceil(p * 65536): element kept iff its 16-bit draw >= thr16
   unsigned int seed_lo, seed_hi, site;
   // optional: a device-resident 64-bit "epoch" that is ADDED to the seed when the kernel runs.  A hipGraph bakes kernel
   // arguments, so a captured training step would replay one set of masks forever; with the epoch (advanced by a node of
@@ -28,6 +32,12 @@ inline DropoutP make_dropout(float p, uint64_t seed, uint32_t site) {
   DropoutP d;
   d.p = p;
   d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  {
+    const float t = p * 65536.f;
+    unsigned int thr = (unsigned int)t;
+    if ((float)thr < t) ++thr;  // ceil
+    d.thr16 = thr > 65535u ? 65535u : thr;
+  }
   d.seed_lo = (unsigned int)(seed & 0xffffffffu);
   d.seed_hi = (unsigned int)(seed >> 32);
   d.site = site;
@@ -49,21 +59,39 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// keep-scales (0 or 1/(1-p)) of the four elements 4q .. 4q+3 of a site's flat index space
-__device__ __forceinline__ void dropout_quad(const DropoutP& d, unsigned long long quad, float (&scale)[4]) {
-  unsigned int r[4];
+__device__ __forceinline__ void dropout_words(const DropoutP& d, unsigned long long oct, unsigned int (&r)[4]) {
   unsigned int k0 = d.seed_lo, k1 = d.seed_hi;
   if (d.epoch) {  // (uniform) seed + epoch as one 64-bit sum
     const unsigned long long s = (((unsigned long long)k1 << 32) | k0) + *d.epoch;
     k0 = (unsigned int)(s & 0xffffffffu);
     k1 = (unsigned int)(s >> 32);
   }
-  philox4x32_10((unsigned int)(quad & 0xffffffffu), (unsigned int)(quad >> 32), d.site, 0u, k0, k1, r);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) scale[i] = ((float)(r[i] >> 8) * (1.0f / 16777216.0f) >= d.p) ? d.inv_keep : 0.f;
+  philox4x32_10((unsigned int)(oct & 0xffffffffu), (unsigned int)(oct >> 32), d.site, 0u, k0, k1, r);
 }
 
-// single element e (uses lane e & 3 of quad e >> 2)
+// keep-scales (0 or 1/(1-p)) of the eight elements 8o .. 8o+7 of a site's flat index space: one generator call
+__device__ __forceinline__ void dropout_oct(const DropoutP& d, unsigned long long oct, float (&scale)[8]) {
+  unsigned int r[4];
+  dropout_words(d, oct, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    scale[2 * i] = ((r[i] & 0xffffu) >= d.thr16) ? d.inv_keep : 0.f;
+    scale[2 * i + 1] = ((r[i] >> 16) >= d.thr16) ? d.inv_keep : 0.f;
+  }
+}
+
+// keep-scales of the four elements 4q .. 4q+3: half of octet q >> 1
+__device__ __forceinline__ void dropout_quad(const DropoutP& d, unsigned long long quad, float (&scale)[4]) {
+  unsigned int r[4];
+  dropout_words(d, quad >> 1, r);
+  const unsigned int w0 = (quad & 1) ? r[2] : r[0], w1 = (quad & 1) ? r[3] : r[1];
+  scale[0] = ((w0 & 0xffffu) >= d.thr16) ? d.inv_keep : 0.f;
+  scale[1] = ((w0 >> 16) >= d.thr16) ? d.inv_keep : 0.f;
+  scale[2] = ((w1 & 0xffffu) >= d.thr16) ? d.inv_keep : 0.f;
+  scale[3] = ((w1 >> 16) >= d.thr16) ? d.inv_keep : 0.f;
+}
+
+// single element e (draw e & 7 of octet e >> 3)
 __device__ __forceinline__ float dropout_one(const DropoutP& d, unsigned long long e) {
   float s[4];
   dropout_quad(d, e >> 2, s);

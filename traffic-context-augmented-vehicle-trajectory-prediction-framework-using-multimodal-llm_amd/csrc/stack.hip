@@ -48,14 +48,12 @@ __device__ __forceinline__ f32x4 mfma16s(const u32x4& a, const u32x4& b, const f
 
 template <bool F16>
 __device__ __forceinline__ u32x4 masked8(const u32x4& x, const DropoutP& d, unsigned long long quad) {
-  float s0[4], s1[4];
-  dropout_quad(d, quad, s0);
-  dropout_quad(d, quad + 1, s1);
+  // eight consecutive elements starting at an even quad = one octet = one generator call
+  float s[8];
+  dropout_oct(d, quad >> 1, s);
   u32x4 o;
-  o[0] = pack16x2<F16>(from16_lo<F16>(x[0]) * s0[0], from16_hi<F16>(x[0]) * s0[1]);
-  o[1] = pack16x2<F16>(from16_lo<F16>(x[1]) * s0[2], from16_hi<F16>(x[1]) * s0[3]);
-  o[2] = pack16x2<F16>(from16_lo<F16>(x[2]) * s1[0], from16_hi<F16>(x[2]) * s1[1]);
-  o[3] = pack16x2<F16>(from16_lo<F16>(x[3]) * s1[2], from16_hi<F16>(x[3]) * s1[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack16x2<F16>(from16_lo<F16>(x[i]) * s[2 * i], from16_hi<F16>(x[i]) * s[2 * i + 1]);
   return o;
 }
 
