@@ -296,18 +296,33 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
-// Elementwise dropout, one Philox call per quad of elements.
+// Elementwise dropout, one Philox call per octet of elements (16-byte loads / stores of 16-bit tensors when aligned).
 template <typename T, bool F16 = false>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long n, DropoutP drop,
-                                                      const T* __restrict__ add) {
-  const long nq = (n + 3) >> 2;
+                                                      const T* __restrict__ add, int vec_ok) {
+  const long no = (n + 7) >> 3;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
-    float sc[4];
-    dropout_quad(drop, (unsigned long long)q, sc);
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < no; o += stride) {
+    float sc[8];
+    dropout_oct(drop, (unsigned long long)o, sc);
+    const long i0 = 8 * o;
+    if constexpr (sizeof(T) == 2) {
+      if (vec_ok && i0 + 8 <= n) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + i0);
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (add) av = *reinterpret_cast<const u32x4*>(add + i0);
+        u32x4 ov;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long i = 4 * q + e;
+        for (int e = 0; e < 4; ++e)
+          ov[e] = pack16x2<F16>(from16_lo<F16>(xv[e]) * sc[2 * e] + (add ? from16_lo<F16>(av[e]) : 0.f),
+                                from16_hi<F16>(xv[e]) * sc[2 * e + 1] + (add ? from16_hi<F16>(av[e]) : 0.f));
+        *reinterpret_cast<u32x4*>(out + i0) = ov;
+        continue;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long i = i0 + e;
       if (i < n) {
         if constexpr (sizeof(T) == 2) out[i] = to16<F16>(from16<F16>(x[i]) * sc[e] + (add ? from16<F16>(add[i]) : 0.f));
         else out[i] = x[i] * sc[e] + (add ? add[i] : 0.f);
@@ -356,18 +371,19 @@ extern "C" int tcavt_dropout(const void* x, void* out, int64_t n, int dtype, flo
                              const void* add, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
   TCAVT_CHECK_ARG(dtype == TCAVT_F32 || is16(dtype), "dropout: dtype must be f32, bf16 or fp16");
-  long blocks = ((n + 3) / 4 + 255) / 256;
+  long blocks = ((n + 7) / 8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   const DropoutP d = make_dropout(p, seed, site);
+  const int vec_ok = aligned16(x) && aligned16(out) && (!add || aligned16(add));
   if (dtype == TCAVT_F32)
     hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float*>(x), static_cast<float*>(out), (long)n, d, static_cast<const float*>(add));
+                       static_cast<const float*>(x), static_cast<float*>(out), (long)n, d, static_cast<const float*>(add), vec_ok);
   else if (dtype == TCAVT_F16)
     hipLaunchKernelGGL((dropout_kernel<bf16_t, true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add));
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add), vec_ok);
   else
     hipLaunchKernelGGL((dropout_kernel<bf16_t, false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add));
+                       static_cast<const bf16_t*>(x), static_cast<bf16_t*>(out), (long)n, d, static_cast<const bf16_t*>(add), vec_ok);
   TCAVT_CHECK_LAUNCH("dropout");
   return TCAVT_OK;
 }
