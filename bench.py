@@ -83,6 +83,9 @@ def parse():
                     help="the LoRA-trainable variant (modify_scripts/modify_train.py:512-528,1192; SURVEY 8f.1): adapters of "
                          "q_proj / v_proj train too, the backward walks through the frozen decoder layers, grad clip 1.0; "
                          "not the headline configuration")
+    ap.add_argument("--train-mllm-front", action="store_true",
+                    help="with --lora-trainable: the WHOLE trainable set of modify_scripts/modify_train.py -- the Q-Former, "
+                         "mllm.q_proj and the modality embeddings train too (backward continues below decoder layer 0)")
     ap.add_argument("--no-dropout", action="store_true",
                     help="train mode only: run the step with model.eval() arithmetic (dropout = identity) instead of "
                          "ddp_model.train() (train.py:1152; dropout 0.1 in the lane-polygon encoder, Q-Former, LoRA branch, LTSF)")
@@ -324,7 +327,8 @@ def main():
     trainer = None
     if args.mode == "train":
         trainer = training.Trainer(m, lr=5e-4, weight_decay=1e-4, lora_trainable=args.lora_trainable,
-                                   max_grad_norm=1.0 if args.lora_trainable else None)
+                                   max_grad_norm=1.0 if args.lora_trainable else None,
+                                   train_mllm_front=args.lora_trainable and args.train_mllm_front)
         if args.no_pipeline:
             m.pipeline_decoder = False
 
@@ -469,8 +473,10 @@ def main():
                              "MultiModalTrajectoryModel.forward incl. loss (train.py:914-964)")
                             + "; Llama-3.2-1B shape + LoRA r=8 + Q-Former + LTSF cross-attention head; " + ("dropout on as under ddp_model.train() (in-kernel Philox masks, regenerated in the backward)" if dropout_on else "dropout off (eval arithmetic)"),
                 "mode": args.mode,
-                "variant": ("lora_trainable (modify_scripts/modify_train.py:512-528: adapters train, backward through all "
-                            "decoder layers, clip_grad_norm 1.0)") if (args.lora_trainable and args.mode == "train")
+                "variant": (("modify_train.py, whole trainable set (adapters + Q-Former + q_proj + modality embeddings; backward "
+                             "through all decoder and Q-Former layers, clip_grad_norm 1.0)") if args.train_mllm_front else
+                            ("lora_trainable (modify_scripts/modify_train.py:512-528: adapters train, backward through all "
+                             "decoder layers, clip_grad_norm 1.0)")) if (args.lora_trainable and args.mode == "train")
                            else "train.py (MLLM frozen)",
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
                 "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",

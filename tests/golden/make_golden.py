@@ -167,7 +167,8 @@ def run_train_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_ev
     """Gradient / optimizer / dropout-site fixture of one model case (tests/golden/<name>_train.npz):
       * loss.backward() on the reference model in eval arithmetic (dropout off, deterministic), gradients of the
         train.py trainable set (everything outside mllm, scripts/train.py:1140-1145) and -- for the LoRA-trainable
-        loop of modify_scripts/modify_train.py:512-528 -- of the adapter matrices;
+        loop of modify_scripts/modify_train.py:512-528 -- of the adapter matrices and of the MLLM's front end (Q-Former,
+        mllm.q_proj, modality embeddings: "front");
       * one torch.optim.AdamW(lr=5e-4, weight_decay=1e-4) step on the train.py set (scripts/train.py:1145,1182-1183);
       * the sequence of dropout calls of ONE train-mode forward (ddp_model.train(), scripts/train.py:1152):
         (kind, p, shape) of every F.dropout (nn.Dropout, attention weights of nn.MultiheadAttention's explicit path)
@@ -191,8 +192,11 @@ def run_train_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_ev
     # ---- (1) gradients, eval arithmetic
     named = dict(model.named_parameters())
     trainable = [k for k in named if not k.startswith("mllm.")]
+    # the MLLM's front end: trainable in modify_scripts/modify_train.py (:523-528 freeze only the non-LoRA Llama weights)
+    front = [k for k in named if k.startswith(("mllm.qformer.", "mllm.q_proj.")) or
+             k in ("mllm.vision_modality_embedding", "mllm.text_modality_embedding")]
     for k, p in named.items():
-        p.requires_grad_(k in trainable or k.endswith((".A", ".B")))
+        p.requires_grad_(k in trainable or k in front or k.endswith((".A", ".B")))
     model.eval()
     loss, _ = fwd()
     loss.backward()
@@ -200,6 +204,11 @@ def run_train_case(ref, name, preset, T, To, lora, B, text_len, ragged, empty_ev
            "out_len": np.array(To), "loss": np.array(loss.item(), np.float64),
            "trainable": np.array(trainable)}
     for k in trainable:
+        g = named[k].grad
+        out["grad." + k] = _sample(g)
+        out["gnorm." + k] = np.array(g.double().norm().item())
+    out["front"] = np.array(front)
+    for k in front:
         g = named[k].grad
         out["grad." + k] = _sample(g)
         out["gnorm." + k] = np.array(g.double().norm().item())

@@ -443,3 +443,68 @@ def test_allreduce_flat_on_a_raw_rccl_communicator(gpu):
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def _front_keys(weights):
+    return [k for k in weights if k.startswith(("mllm.qformer.", "mllm.q_proj.")) or k in ("mllm.vision_modality_embedding",
+                                                                                           "mllm.text_modality_embedding")]
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
+    """Trainer(lora_trainable=True, train_mllm_front=True) = the whole trainable set of modify_scripts/modify_train.py
+    (:523-528 freeze only the non-LoRA Llama weights): gradients of the Q-Former, mllm.q_proj and the modality embeddings
+    against torch autograd through the oracle graph (bf16 contract), in eval arithmetic and in train mode with the same
+    Philox masks; an optimizer step then moves them and the next forward."""
+    from oracle import forward as O
+    from tcavt_amd import model, training
+    from tcavt_amd.weights import trainable_keys
+    from tests.util import batch_tensors, load_case
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    W = {k: torch.from_numpy(v).clone() for k, v in weights.items()}
+    lora, front = _lora_keys(W), _front_keys(W)
+    assert any("qformer.decoder.layers.0.multihead_attn.in_proj_weight" in k for k in front) and "mllm.qformer.query_tokens" in front
+    for k in lora + front + trainable_keys(W):
+        W[k].requires_grad_(True)
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev)
+    m.train(train_mode)
+    m._fwd_count = 0
+    tr = training.Trainer(m, lora_trainable=True, train_mllm_front=True, max_grad_norm=1.0)
+    assert set(tr.book.g) == set(lora) | set(front) | set(trainable_keys(W))
+    loss, _ = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                              t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
+                              contract="bf16", dropout_seed=m.dropout_seed if train_mode else None)
+    loss.backward()
+    gq = {k: v.to(dev) for k, v in t.items()}
+    args = (gq["traj_emb"], gq["vision_emb"], gq["lane_polygon"], gq["lane_polygon_len"], gq["target_traj"], gq["norm_stat"],
+            gq["input_ids"], gq["attention_mask"], gq["labels"])
+    l0, _ = tr.forward_backward(*args)
+    torch.cuda.synchronize()
+    assert abs(l0.item() - loss.item()) < 2e-2 * abs(loss.item())
+    groups = {"modality embeddings": [k for k in front if "modality" in k], "q_proj": [k for k in front if ".q_proj." in k],
+              "query tokens": ["mllm.qformer.query_tokens"],
+              "qformer decoder": [k for k in front if "qformer.decoder" in k],
+              "qformer encoder + vision_proj": [k for k in front if "qformer.encoder" in k or "vision_proj" in k]}
+    for name, ks in groups.items():
+        ref = torch.cat([W[k].grad.reshape(-1).double() for k in ks])
+        got = torch.cat([tr.book.g[k].cpu().reshape(-1).double() for k in ks])
+        assert torch.isfinite(got).all() and ref.norm() > 0, name
+        rel = ((got - ref).norm() / ref.norm()).item()
+        cos = (got @ ref / (got.norm() * ref.norm())).item()
+        print(f"[modify_train set, train_mode={train_mode}] {name}: rel {rel:.2e}, cosine {cos:.5f}")
+        # bf16 gradient chain through 16 decoder layers + 8 Q-Former layers vs fp32 autograd of the bf16-contract graph
+        assert rel < 0.15 and cos > 0.99, (name, rel, cos)
+    w0 = m.mllm.qformer.query_tokens.detach().clone()
+    tr.optimizer_step()
+    l1, _ = tr.forward_backward(*args)
+    torch.cuda.synchronize()
+    assert (m.mllm.qformer.query_tokens.detach() - w0).abs().max().item() > 0
+    assert torch.isfinite(l1).item() and l1.item() != l0.item()
+    if not train_mode:
+        for _ in range(6):
+            tr.optimizer_step()
+            l1, _ = tr.forward_backward(*args)
+        assert l1.item() < l0.item()

@@ -123,3 +123,34 @@ def test_dropout_sites_match_reference_train_mode(name):
     # per-adapter LoRA dropout: two sites per decoder layer (q_proj, v_proj), as PEFT instantiates them
     n_lora = len(tapes["lora"].log) if hasattr(tapes["lora"], "log") else 0
     assert n_lora == (2 * cfg.llama.layers if cfg.use_lora else 0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_front_end_gradients_match_reference_autograd(name):
+    """The MLLM's front end (Q-Former, mllm.q_proj, modality embeddings) is trainable in modify_scripts/modify_train.py
+    (:523-528 freeze only the non-LoRA Llama weights): the oracle's autograd for those parameters against the reference
+    model's own loss.backward() (fixture entry "front")."""
+    from oracle import forward as O
+
+    cfg, weights, fx, tr = _load(name)
+    t = batch_tensors(fx)
+    front = [str(k) for k in tr["front"]]
+    assert front and all(k.startswith(("mllm.qformer.", "mllm.q_proj.")) or "modality_embedding" in k for k in front)
+    W = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in weights.items()}
+    assert sorted(front) == sorted(k for k in W if k.startswith(("mllm.qformer.", "mllm.q_proj.")) or
+                                   k in ("mllm.vision_modality_embedding", "mllm.text_modality_embedding"))
+    for k in front:
+        W[k].requires_grad_(True)
+    loss, _ = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
+                              t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"], contract="fp32")
+    loss.backward()
+    gmax = max(float(tr["gnorm." + k]) for k in front)
+    worst = (0.0, None)
+    for k in front:
+        g, ref, nrm = W[k].grad, tr["grad." + k], float(tr["gnorm." + k])
+        assert abs(g.double().norm().item() - nrm) <= 5e-4 * nrm + 1e-6 * gmax, k
+        scale = max(nrm / np.sqrt(g.numel()), 1e-6 * gmax / np.sqrt(g.numel()), 1e-30)
+        err = float(np.abs(_sample(g) - ref).max()) / scale
+        worst = max(worst, (err, k))
+        assert err < 5e-3, (k, err)  # (fp32 summation-order noise only, as for the train.py set)
+    print(f"[oracle front-end grads {name}] worst sampled deviation {worst[0]:.2e} x rms ({worst[1]})")

@@ -110,12 +110,14 @@ class LoraBackward:
         if not self.lw.use_lora:
             raise ValueError("LoraBackward: the model has no LoRA adapters (use_lora=False)")
         self.ws = self.lw._ws
+        self.input_grad = False  # True: also walk through layer 0's projections and return dL/d(inputs_embeds)
 
     def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):  # noqa: D401 (scratch from the decoder's workspace)
         return self.ws.get("llbw." + name, shape, dtype, self.book.grads.device, zero=zero)
 
     def run(self, g_final_a, g_final_b=None):
-        """g_final_a (+ g_final_b): bf16 [B*L, H] gradient of the post-final-norm hidden states."""
+        """g_final_a (+ g_final_b): bf16 [B*L, H] gradient of the post-final-norm hidden states.  Returns the fp32 gradient of
+        the decoder's input embeddings [B*L, H] when `input_grad` is set (qformer_backward.QFormerBackward continues from it)."""
         lw, G = self.lw, self.book.g
         tape = lw.tape
         if tape is None:
@@ -206,7 +208,7 @@ class LoraBackward:
                     adapter_grads()
                     leaf_done[par] = torch.cuda.Event()
                     leaf_done[par].record(leaf)
-            if li == 0:
+            if li == 0 and not self.input_grad:
                 break
             if sv.dspec is None:
                 ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
@@ -219,3 +221,4 @@ class LoraBackward:
             ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True, gx_bf16=g_hb)
         if leaf is not None:
             torch.cuda.current_stream().wait_stream(leaf)
+        return g_h if self.input_grad else None

@@ -231,11 +231,11 @@ class _TLayerRunner:
         self._gemm(xb if self.bf16 else x, p.w_q, out=q, bias=p.b_q, out_dtype=torch.float32)
         kv = self._buf("ckv", (mem.shape[0], 2 * E), torch.float32, dev)
         self._gemm(memb if self.bf16 else mem, p.w_kv, out=kv, bias=p.b_kv, out_dtype=torch.float32)
-        att = self._buf("att", (M, E), act_dt, dev)
+        att = self._buf("catt", (M, E), act_dt, dev)  # (own buffers: a recording decoder layer keeps the self-attention's too)
         dh = E // self.nhead
         ops.mha(q, kv[:, :E], kv[:, E:], att, B, Lq, Lk, self.nhead, dh, 1.0 / math.sqrt(dh), ldq=E, ldk=2 * E,
                 ldv=2 * E, ldo=E, dropout=self._draw())
-        y = self._buf("y", (M, E), torch.float32, dev)
+        y = self._buf("cy", (M, E), torch.float32, dev)
         self._gemm(att, p.w_out, out=y, bias=p.b_out, residual=x, out_dtype=torch.float32,
                    dropout=self._draw())
         return y
@@ -269,7 +269,7 @@ class _TLayerRunner:
             dev = x.device
             self.record.append(dict(
                 drop=specs,  # [attention weights, after out_proj, after ReLU, after linear2] or Nones
-                x=x, y=y, x1=x1, y2=y2, qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev),
+                x=x, xb=xb, y=y, x1=x1, x1b=x1b, y2=y2, qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev),
                 att=self._buf("att", (M, E), self.dt16 if self.bf16 else torch.float32, dev),
                 f=self._buf("ffh", (M, p.w1.shape[0]), self.dt16 if self.bf16 else torch.float32, dev)))
         return out
@@ -280,8 +280,19 @@ class _TLayerRunner:
         y2 = self.cross_attn(p.ca, x1, x1b, mem, memb, B, Lq, Lk)
         x2, x2b = self.norm(y2, p.n2, f"d2_{slot}")
         y3 = self.ffn(p, x2, x2b)
-        self.specs = []
-        return self.norm(y3, p.n3, f"d3_{slot}")
+        specs, self.specs = self.specs, []
+        out = self.norm(y3, p.n3, f"d3_{slot}")
+        if self.record is not None:
+            M, E = x.shape
+            dev = x.device
+            a16 = self.dt16 if self.bf16 else torch.float32
+            self.record.append(dict(
+                drop=specs,  # [self-attn weights, after its out_proj, cross-attn weights, after its out_proj, after ReLU, after linear2]
+                x=x, xb=xb, y=y, x1=x1, x1b=x1b, y2=y2, x2=x2, x2b=x2b, y3=y3,
+                qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev), att=self._buf("att", (M, E), a16, dev),
+                cq=self._buf("cq", (M, E), torch.float32, dev), ckv=self._buf("ckv", (mem.shape[0], 2 * E), torch.float32, dev),
+                catt=self._buf("catt", (M, E), a16, dev), f=self._buf("ffh", (M, p.w1.shape[0]), a16, dev)))
+        return out
 
 
 # --------------------------------------------------------------------------------------
@@ -342,6 +353,8 @@ class BlipQFormer(nn.Module, _Prepared):
         self._ws = _Workspace()
         self._prep = None
         self.dropout_p, self.dctx = 0.1, None  # nn.Transformer*Layer default dropout
+        self.save_for_backward = False  # training.Trainer(train_mllm_front=True): keep per-layer activations
+        self.saved = None
 
     def _prepare(self):
         return SimpleNamespace(
@@ -353,15 +366,19 @@ class BlipQFormer(nn.Module, _Prepared):
         B, Tv, Dv = vision_embs.shape
         dev, E, Nq = vision_embs.device, self.hidden_size, self.num_query_tokens
         P = self._prepared()
+        keep = self.save_for_backward
         run = _TLayerRunner(self._ws, bf16=True, nhead=self.nhead, tag="qf", dctx=self.dctx, p_drop=self.dropout_p,
-                            dt16=self.storage)
+                            dt16=self.storage, record=[] if keep else None)
         vb = self._ws.get("qf.vb", (B * Tv, Dv), self.storage, dev)
         ops.cast16(vision_embs.contiguous().view(B * Tv, Dv), out=vb)
         x = self._ws.get("qf.x0", (B * Tv, E), torch.float32, dev)
         ops.gemm_bf16(vb, P.w_vp, out=x, bias=self.vision_proj.bias)
         xb = self._ws.get("qf.x0b", (B * Tv, E), self.storage, dev)
         ops.cast16(x, out=xb)
+        x0, x0b = x, xb
         for i, p in enumerate(P.enc):
+            if keep:
+                run.layer_tag = f".E{i}"
             x, xb = run.encoder_layer(p, x, xb, B, Tv, slot=i & 1)
         mem, memb = x, xb
         if B not in P.q0:  # learned queries broadcast over the batch (train.py:412); constant per B
@@ -369,7 +386,13 @@ class BlipQFormer(nn.Module, _Prepared):
             P.q0[B] = (q, ops.cast16(q, dtype=self.storage))
         q, qb = P.q0[B]
         for i, p in enumerate(P.dec):
+            if keep:
+                run.layer_tag = f".D{i}"
             q, qb = run.decoder_layer(p, q, qb, mem, memb, B, Nq, Tv, slot=i & 1)
+        if keep:
+            ne = len(P.enc)
+            self.saved = SimpleNamespace(enc=run.record[:ne], dec=run.record[ne:], vb=vb, x0=x0, x0b=x0b, mem=mem, memb=memb,
+                                         out=q, outb=qb, B=B, Tv=Tv)
         out = q.view(B, Nq, E)
         return (out, qb) if return_bf16 else out
 
@@ -777,6 +800,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         P = self._prepared()
         B = vision_embs.shape[0]
         _, imgb = self.qformer(vision_embs, return_bf16=True)
+        self._imgb = imgb  # (the q_proj backward's activation)
         img = self._ws.get("mm.img", (B * self.qformer.num_query_tokens, self.llama_hidden_size), torch.float32,
                            vision_embs.device)
         ops.gemm_bf16(imgb, P.w_qp, out=img, bias=self.q_proj.bias)

@@ -16,6 +16,7 @@ import torch.distributed as dist
 from . import ops
 from .backward import Backward, GradBook
 from .llm_backward import LoraBackward, lora_named_parameters
+from .qformer_backward import QFormerBackward
 
 
 def trainable_named_parameters(model):
@@ -34,7 +35,11 @@ class Trainer:
     are clipped to max_grad_norm (:1192) and an update is skipped when the loss is not finite (:1190-1196, decided on
     the device).  NOT the whole of modify_train.py's trainable set: that script never freezes `mllm`, so its Q-Former,
     mllm.q_proj and the two modality embeddings (54 M parameters) keep requires_grad there; here the backward stops at
-    the input of decoder layer 0 and those stay frozen (DESIGN.md section 7, "LoRA-only subset").
+    the input of decoder layer 0 and those stay frozen (DESIGN.md section 8, "LoRA-only subset").
+
+    lora_trainable=True, train_mllm_front=True: the WHOLE trainable set of modify_train.py -- the backward continues below
+    decoder layer 0 into the modality embeddings, mllm.q_proj and the Q-Former (qformer_backward.QFormerBackward).  The
+    Q-Former then changes every step, so its pass cannot be prefetched under the previous step (next_vision_embs is ignored).
 
     Data parallel (world > 1): the constructor broadcasts rank 0's parameters to all ranks (what the reference's
     DistributedDataParallel wrap does at construction, train.py:1127-1132); gradients are SUM-all-reduced in buckets and
@@ -42,7 +47,7 @@ class Trainer:
 
     def __init__(self, model, lr=5e-4, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None,
                  lora_trainable=False, max_grad_norm=None, skip_nonfinite=None, sync_initial_state=True,
-                 check_flags_every=0):
+                 check_flags_every=0, train_mllm_front=False):
         self.model = model
         dev = next(model.parameters()).device
         named = trainable_named_parameters(model)
@@ -65,6 +70,17 @@ class Trainer:
             for _, p in lora:
                 p.requires_grad_(True)
             named = named + lora  # their gradients are the last to become ready
+        self.train_mllm_front = bool(train_mllm_front)
+        if self.train_mllm_front:
+            if not self.lora_trainable:
+                raise ValueError("Trainer(train_mllm_front=True) needs lora_trainable=True (the gradient reaches the MLLM's "
+                                 "front end through the decoder's backward)")
+            front = [(n, p) for n, p in model.named_parameters()
+                     if n.startswith(("mllm.q_proj.", "mllm.qformer.")) or n in ("mllm.vision_modality_embedding",
+                                                                                  "mllm.text_modality_embedding")]
+            for _, p in front:
+                p.requires_grad_(True)
+            named = named + front  # ready last of all
         self.book = GradBook(named, dev)
         self.n_base = self.book.end_of(named[n_frozen_variant - 1][0])  # end of the train.py parameter set
         self.n_ltsf = self.book.end_of([n for n, _ in named if n.startswith("ltsf.")][-1])
@@ -79,6 +95,11 @@ class Trainer:
             model.mllm.llama_wrapper.save_for_backward = True
             model.ltsf.absorb_kv = False  # _lora_backward starts from dL/dk, dL/dv of the un-absorbed cross-attention
             self._lora_stacked = self._stacked_lora_views(lora)
+        self.qbw = None
+        if self.train_mllm_front:
+            self.qbw = QFormerBackward(model, self.book, self.bw)
+            self.lbw.input_grad = True
+            model.mllm.qformer.save_for_backward = True
         model.lane_polygon_encoder.save_for_backward = True
         model.ltsf.save_for_backward = True
         # train.py's frozen MLLM: its pass reads nothing this step's backward / optimizer writes, so it runs on a stream
@@ -147,7 +168,7 @@ class Trainer:
                               input_ids=input_ids, attention_mask=attention_mask, labels=labels)
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat])
             ns = ns.to(device=x.device, dtype=torch.float32).contiguous()
-            if next_vision_embs is not None:
+            if next_vision_embs is not None and not self.train_mllm_front:
                 m.prefetch(next_vision_embs)  # before the backward: its leaf work shares the prefetch stream's queue
             B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
             fh_b = m.last.final_hidden_bf16  # [B * L + 64 zeroed pad rows, H]
@@ -193,7 +214,9 @@ class Trainer:
             WT = bw._buf(f"lora.WT{tag}", (H, H), torch.bfloat16)
             ops.transpose_f32_bf16(W.detach(), WT, H, H, H)
             ops.gemm_bf16(g[: B * L], WT, out=out)
-        self.lbw.run(gfa, gfb)
+        g_h0 = self.lbw.run(gfa, gfb)
+        if self.qbw is not None:
+            self.qbw.run(g_h0, B, L)
 
     def clip_grad_norm_(self, max_norm, grad_scale=1.0):
         """torch.nn.utils.clip_grad_norm_(trainable, max_norm) (modify_train.py:1192) on the flat gradient vector,
@@ -230,6 +253,9 @@ class Trainer:
             m.ltsf._invalidate()
             if self.lora_trainable:
                 m.mllm.llama_wrapper.refresh_lora(self._lora_stacked)
+            if self.train_mllm_front:
+                m.mllm.qformer._invalidate()
+                m.mllm._invalidate()
 
     def prefetch(self, vision_embs, ready=None):
         """Optional: start the frozen Q-Former of the next batch underneath the step in flight (model.prefetch)."""
