@@ -1317,6 +1317,7 @@ class MultiModalTrajectoryModel(nn.Module):
         # Off by default; training.Trainer turns it on for the frozen-decoder variant.  See forward / inputs_ready.
         self.pipeline_decoder = False
         self.inputs_ready = None  # see forward
+        self.pipe_trace = None
         self._dec_stream, self._dec_slot, self._fwd_start_ev = None, 0, None
         # Train-mode dropout (the MC-dropout K-candidate protocol, test.py:1301-1342): active when the module
         # is in .train() mode; every forward uses seed dropout_seed + number of forwards so far.
@@ -1427,11 +1428,17 @@ class MultiModalTrajectoryModel(nn.Module):
                 D.wait_event(self._fwd_start_ev)
             self._fwd_start_ev = torch.cuda.Event()
             self._fwd_start_ev.record(main)
+            trace = self.pipe_trace  # (tools only) a list that receives (start, stop) timing events of every MLLM pass
             with torch.cuda.stream(D):
+                if trace is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(D)
                 final_hidden, _, final_b = self.mllm(vision_embs, context_str, input_ids=input_ids, attention_mask=attention_mask,
                                                      labels=labels, return_bf16=True, out_slot=self._dec_slot)
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=trace is not None)
                 done.record(D)
+                if trace is not None:
+                    trace.append((t0, done))
             self._dec_slot ^= 1
             final_hidden.record_stream(main)
             main.wait_event(done)
