@@ -7,7 +7,7 @@
 // with k_cache / v_cache set), and every following token is ONE call of tcavt_llama_decode_step:
 //
 //   embed (table[id] + text modality embedding)  ->  16 x [ LoRA down | q|k|v + RoPE at the sample's own position |
-//   append k, v to the cache | attention of the one query over the cached keys | o_proj | gate|up | down ]  ->
+//   attention of the one query over the cached keys (which also appends the new k, v) | o_proj | gate|up | down ]  ->
 //   final RMSNorm  ->  lm_head (tied embedding table)  ->  logits processors + token selection (tcavt_sample_logits)
 //
 // All per-step state (positions, current tokens, token history, step counter, finished flags) lives on the device and
@@ -20,29 +20,16 @@
 
 namespace tcavt {
 
-// k, v of the new token (row b of qkv) -> cache position pos[b]
-__global__ __launch_bounds__(256) void kv_append_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
-                                                        bf16_t* __restrict__ vc, const int* __restrict__ pos, int lmax,
-                                                        int nq, int nkv) {
-  const int b = blockIdx.x, ld = (nq + 2 * nkv) * 64, w = nkv * 64;
-  const int p = min(pos[b], lmax - 1);
-  const bf16_t* src = qkv + (long)b * ld + nq * 64;
-  bf16_t* kd = kc + ((long)b * lmax + p) * w;
-  bf16_t* vd = vc + ((long)b * lmax + p) * w;
-  for (int c = threadIdx.x * 8; c < w; c += 256 * 8) {
-    *reinterpret_cast<u32x4*>(kd + c) = *reinterpret_cast<const u32x4*>(src + c);
-    *reinterpret_cast<u32x4*>(vd + c) = *reinterpret_cast<const u32x4*>(src + w + c);
-  }
-}
-
 // One query per (sample, query head) over the cached keys 0 .. pos[b] (the new token's own key included).
 // One workgroup per (sample, kv head); KS waves per query head of the group split the keys.  Scores: lane = key (each lane
 // reads its key's 128-byte row and keeps the whole query in registers); the KS (max, sum) pairs of a head meet in LDS, the
 // probabilities are normalised with the head's global sum and carried in fp16 as in the prefill kernel; output: lane =
 // head dimension over the wave's key range, the KS partial outputs are added in split order.
+// The new token's own key / value (row b of qkv, position pos[b]) are read from qkv and written to the cache by this kernel
+// (wave 0 of the workgroup that owns the kv head): no separate append launch, and nothing written here is read back here.
 template <bool F16>
-__global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
-                                                           const bf16_t* __restrict__ vc, const int* __restrict__ pos,
+__global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
+                                                           bf16_t* __restrict__ vc, const int* __restrict__ pos,
                                                            bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale,
                                                            int KS) {
   extern __shared__ float sc[];  // [group][lmax] scores | [group][KS][2] (max, sum) | [group][KS][64] partial outputs
@@ -55,6 +42,14 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   const int ld = (nq + 2 * nkv) * 64, w = nkv * 64;
   const bf16_t* kb = kc + (long)b * lmax * w + kvh * 64;
   const bf16_t* vb = vc + (long)b * lmax * w + kvh * 64;
+  const int jn = n - 1;  // the new token's position
+  const bf16_t* knew = qkv + (long)b * ld + (nq + kvh) * 64;
+  const bf16_t* vnew = qkv + (long)b * ld + (nq + nkv + kvh) * 64;
+  if (wv == 0 && lane < 16) {  // append: 8 lanes x 16 bytes of k, 8 of v
+    const int c = (lane & 7) * 8;
+    if (lane < 8) *reinterpret_cast<u32x4*>(kc + ((long)b * lmax + jn) * w + kvh * 64 + c) = *reinterpret_cast<const u32x4*>(knew + c);
+    else *reinterpret_cast<u32x4*>(vc + ((long)b * lmax + jn) * w + kvh * 64 + c) = *reinterpret_cast<const u32x4*>(vnew + c);
+  }
   float* s = sc + hq * lmax;
   float* st = sc + group * lmax + (hq * KS) * 2;
   float* po = sc + group * lmax + group * KS * 2 + (hq * KS) * 64;
@@ -75,7 +70,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   }
   float mx = -1e30f;
   for (int j = j0 + lane; j < j1; j += 64) {
-    const u32x4* kp = reinterpret_cast<const u32x4*>(kb + (long)j * w);
+    const u32x4* kp = reinterpret_cast<const u32x4*>(j == jn ? knew : kb + (long)j * w);
     float d = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -99,15 +94,16 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   for (int k = 0; k < KS; ++k) gm = fmaxf(gm, st[k * 2]);
   for (int k = 0; k < KS; ++k) gl += st[k * 2 + 1] * __expf(st[k * 2] - gm);
   const float inv = 1.f / gl;
+  auto vat = [&](int jj) { return from16<F16>(jj == jn ? vnew[lane] : vb[(long)jj * w + lane]); };
   float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;  // four independent chains over the keys
   int j = j0;
   for (; j + 3 < j1; j += 4) {
-    o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
-    o1 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 1] - gm) * inv)), from16<F16>(vb[(long)(j + 1) * w + lane]), o1);
-    o2 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 2] - gm) * inv)), from16<F16>(vb[(long)(j + 2) * w + lane]), o2);
-    o3 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 3] - gm) * inv)), from16<F16>(vb[(long)(j + 3) * w + lane]), o3);
+    o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), vat(j), o0);
+    o1 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 1] - gm) * inv)), vat(j + 1), o1);
+    o2 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 2] - gm) * inv)), vat(j + 2), o2);
+    o3 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 3] - gm) * inv)), vat(j + 3), o3);
   }
-  for (; j < j1; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), from16<F16>(vb[(long)j * w + lane]), o0);
+  for (; j < j1; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), vat(j), o0);
   po[ks * 64 + lane] = (o0 + o1) + (o2 + o3);
   __syncthreads();
   if (ks == 0) {
@@ -469,8 +465,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     bf16_t* kc = static_cast<bf16_t*>(a->k_cache) + li * per_layer;
     bf16_t* vc = static_cast<bf16_t*>(a->v_cache) + li * per_layer;
-    hipLaunchKernelGGL(kv_append_kernel, dim3(B), dim3(256), 0, st, static_cast<const bf16_t*>(a->qkv), kc, vc, a->pos,
-                       a->kv_lmax, nq, nkv);
+    // (the new token's k / v rows are appended to the cache by attn_decode_kernel itself)
     if (dt == TCAVT_F16)
       hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nkv), dim3(group * KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
                          kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
