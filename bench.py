@@ -28,14 +28,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Data-parallel ranks use two more HIP streams than a single process (the gradient all-reduce's launch stream and the RCCL
-# stream of torch.distributed).  The runtime maps streams onto 4 hardware queues by default, and streams that share a queue
-# run in order: an all-reduce that lands on the frozen-MLLM stream's queue would hold the next step's decoder behind this
-# step's backward and undo the cross-step overlap.  With 8 queues every stream has its own.  (One
-# process: 4 queues measure 1.3 % faster -- fewer kernels truly concurrent with the decoder's GEMMs -- and stay the default.)
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -489,7 +481,6 @@ def main():
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
                 "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",
                 "launch": "eager" if graph is None else "hipGraph replay",
-                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 "pipelining": "; ".join(
                     ([("Q-Former of batch i+1 prefetched on a side stream during step i (every timed step runs one Q-Former "
                        "pass; results identical)")] if prefetch else []) +

@@ -60,7 +60,7 @@ def _worker(rank, world, port, q, lora=False):
             s.copy_(w.detach())
             dist.broadcast(s, src=0)
         ok_bcast = all(torch.equal(s, w.detach()) for s, w in zip(same, (m.ltsf.decoder.out_proj.weight, m.mllm.q_proj.weight)))
-        assert tr.world == world and tr.comm_stream is None
+        assert tr.world == world
         n = tr.book.total
         assert (tr.n_base < n) if lora else (tr.n_base == n)
         base = torch.arange(n, dtype=torch.float32) % 97
@@ -69,7 +69,6 @@ def _worker(rank, world, port, q, lora=False):
         tr._allreduce_bucket(tr.n_ltsf, tr.n_base)
         if lora:  # third bucket: the adapter gradients, ready last (modify_scripts/modify_train.py:512-528)
             tr._allreduce_bucket(tr.n_base, n)
-        tr._wait_comm()
         expect = base * sum(r + 1 for r in range(world))
         ok_sum = torch.equal(tr.book.grads, expect)
         tr._last_loss = torch.zeros(())

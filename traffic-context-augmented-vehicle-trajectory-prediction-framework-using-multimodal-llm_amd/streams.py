@@ -17,9 +17,20 @@ _POOL = {}
 N_SLOTS = int(os.environ.get("TCAVT_SIDE_STREAMS", "3"))  # A/B: 6 gives every logical channel its own stream
 
 
+_ACTIVE = None  # set_active_slots(): use only the first n streams of the pool
+
+
+def set_active_slots(n):
+    """Fold the logical side channels onto the first `n` streams of the pool (training.Trainer, data-parallel ranks: the
+    process group's RCCL stream takes one place in the five-stream budget of the pipelined step).  Streams handed out earlier
+    stay valid; callers that cached one should draw again."""
+    global _ACTIVE
+    _ACTIVE = max(1, min(int(n), N_SLOTS))
+
+
 def side_stream(device, slot):
     dev = torch.device(device)
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _POOL:
         _POOL[key] = [torch.cuda.Stream(device=dev) for _ in range(N_SLOTS)]
-    return _POOL[key][slot % N_SLOTS]
+    return _POOL[key][slot % (_ACTIVE or N_SLOTS)]
