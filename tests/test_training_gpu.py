@@ -480,3 +480,38 @@ def test_pipelined_decoder_is_equivalent(gpu):
     assert torch.equal(da[0], db[0])
     assert np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
     assert not torch.equal(ha[0], ha[1])  # (the two batches do differ)
+
+
+def test_data_parallel_stream_layout_stand_in(gpu, monkeypatch):
+    """The stream layout of a data-parallel rank (all-reduce launched from the bucket's own stream, side channels folded onto
+    two streams) with a stand-in for RCCL's stream (TCAVT_FAKE_DP: an in-place x1.0 kernel where the collective would run):
+    same losses and parameters as the single-process layout, pipelined decoder included."""
+    from tcavt_amd import model, streams, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    args = (g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
+            g["input_ids"], g["attention_mask"], g["labels"])
+
+    def run(fake):
+        if fake:
+            monkeypatch.setenv("TCAVT_FAKE_DP", "1")
+        else:
+            monkeypatch.delenv("TCAVT_FAKE_DP", raising=False)
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
+        tr = training.Trainer(m, lr=1e-4)
+        assert (tr._fake_dp is not None) == fake
+        losses = [tr.step(*args, next_vision_embs=g["vision_emb"], inputs_ready=True)[0] for _ in range(4)]
+        torch.cuda.synchronize()
+        return [l.item() for l in losses], tr.book.params.clone()
+
+    try:
+        la, pa = run(False)
+        lb, pb = run(True)
+        assert streams._ACTIVE == 2
+    finally:
+        streams._ACTIVE = None
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0])
+    assert np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
