@@ -536,6 +536,55 @@ typedef struct tcavt_llama_stack_args {
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Post-LN nn.TransformerEncoderLayer / nn.TransformerDecoderLayer stacks as one call: the Q-Former's encoder and decoder
+ * (scripts/train.py:388-414; dtype16 = TCAVT_F16 / TCAVT_BF16: 16-bit weights and activations on MFMA) and the lane-polygon
+ * encoder's layers (scripts/train.py:352-383; dtype16 = 0: fp32 end to end).  Per layer: self-attention (in_proj, tcavt_mha,
+ * out_proj + residual, LayerNorm), for decoder layers (w_q != NULL) cross-attention over `mem`, feed-forward (ReLU), each
+ * residual sum followed by its LayerNorm.  Train-mode dropout (dropout_p > 0) at the reference's sites -- attention weights,
+ * after out_proj, after ReLU, after linear2 (+ the cross-attention's two) -- numbered in call order from first_site.
+ * All buffers are caller-owned: shared between layers in inference, one set per layer when a backward will read them.
+ * ---------------------------------------------------------------------- */
+typedef struct tcavt_tlayer {
+  const void* w_in;  const float* b_in;   /* self-attention in_proj  [3E][E], [3E]  (weights: 16-bit or fp32 per dtype16) */
+  const void* w_out; const float* b_out;  /* self-attention out_proj [E][E], [E] */
+  const void* w_q;   const float* b_q;    /* cross-attention q projection [E][E] -- NULL: encoder layer */
+  const void* w_kv;  const float* b_kv;   /* cross-attention k|v projection [2E][E] */
+  const void* w_co;  const float* b_co;   /* cross-attention out_proj */
+  const void* w1;    const float* b1;     /* linear1 [FF][E] */
+  const void* w2;    const float* b2;     /* linear2 [E][FF] */
+  const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b; /* LayerNorms (n3: decoder layers) */
+  /* activations of this layer, [M = B*L rows] unless noted; "16" = dtype16 in 16-bit mode, fp32 otherwise */
+  float* qkv;            /* [M][3E] fp32 */
+  void* att;             /* [M][E] 16 */
+  float* y;              /* [M][E] x + self-attention */
+  float* x1; void* x1b;  /* LayerNorm1 output, fp32 + 16-bit copy (16-bit mode) */
+  float* cq;             /* [M][E] fp32 (decoder) */
+  float* ckv;            /* [B*Lk][2E] fp32 (decoder) */
+  void* catt;            /* [M][E] 16 (decoder) */
+  float* cy;             /* [M][E] x1 + cross-attention (decoder) */
+  float* x2; void* x2b;  /* LayerNorm2 output (decoder) */
+  void* ffh;             /* [M][FF] 16 */
+  float* y2;             /* [M][E] feed-forward residual sum */
+  float* out; void* outb;/* layer output (LayerNorm2 / LayerNorm3), fp32 + 16-bit copy */
+} tcavt_tlayer;
+
+typedef struct tcavt_tstack_args {
+  const tcavt_tlayer* layers;  /* HOST array */
+  const float* x;              /* input tokens fp32 [B*L][E] */
+  const void* xb;              /* their 16-bit copy (16-bit mode) */
+  const float* mem;            /* decoder memory fp32 [B*Lk][E] (decoder layers) */
+  const void* memb;
+  const int32_t* key_len;      /* int32 [B] valid self-attention keys per sample, or NULL */
+  int32_t n_layers, B, L, Lk, E, FF, nhead;
+  int32_t dtype16;             /* 0: fp32 layers; TCAVT_F16 / TCAVT_BF16 */
+  float dropout_p;
+  uint32_t first_site;
+  uint64_t dropout_seed;
+} tcavt_tstack_args;
+
+int tcavt_tlayer_stack_forward(const tcavt_tstack_args* args, tcavt_stream_t stream);
+
 /* SUM all-reduce, in place, of a flat fp32 buffer on the caller's RCCL communicator (`nccl_comm` is an ncclComm_t) and
  * stream: one gradient bucket of the data-parallel step (the DistributedDataParallel wrap of scripts/train.py:1127 does
  * this during backward; tcavt_amd.training.Trainer issues the same exchange through torch.distributed).  The mean is taken

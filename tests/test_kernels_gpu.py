@@ -583,3 +583,38 @@ def test_embed_fuse_16bit_stream(gpu):
     ops.rownorm_prep(h, h16c, pc, npart=4, rounded_sums=True)
     assert torch.equal(h16c, h16b) and _rel(pc[:, 0], pb[:, 0]) < 1e-6
     assert flag.item() == 0
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_tlayer_stack_matches_python_composition(gpu, train, monkeypatch):
+    """tcavt_tlayer_stack_forward (Q-Former encoder + decoder stacks in 16-bit, lane-polygon encoder in fp32, as ONE C call each)
+    against the per-layer Python composition of the same kernel-level entry points (TCAVT_PY_TLAYERS=1): bit-identical image
+    tokens and polygon embeddings, eval arithmetic and train mode (same dropout sites)."""
+    from tcavt_amd import model
+    from tests.util import batch_tensors, load_case
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev)
+    m.train(train)
+
+    def run(py):
+        if py:
+            monkeypatch.setenv("TCAVT_PY_TLAYERS", "1")
+        else:
+            monkeypatch.delenv("TCAVT_PY_TLAYERS", raising=False)
+        dc = model.DropoutCtx(1234) if train else None
+        m.mllm.qformer.dctx = dc.sub(1) if dc else None
+        m.lane_polygon_encoder.dctx = dc.sub(0) if dc else None
+        with torch.no_grad():
+            img = m.mllm._image_tokens(g["vision_emb"]).clone()
+            emb = m.lane_polygon_encoder(g["lane_polygon"], g["lane_polygon_len"]).clone()
+        torch.cuda.synchronize()
+        return img, emb
+
+    img_c, emb_c = run(False)
+    img_p, emb_p = run(True)
+    assert torch.isfinite(img_c).all() and torch.isfinite(emb_c).all()
+    assert torch.equal(img_c, img_p) and torch.equal(emb_c, emb_p)

@@ -65,6 +65,29 @@ class LlamaLayer(ctypes.Structure):
                                         "tape_qkv", "tape_gu", "tape_t")]
 
 
+TLAYER_FIELDS = ("w_in", "b_in", "w_out", "b_out", "w_q", "b_q", "w_kv", "b_kv", "w_co", "b_co", "w1", "b1", "w2", "b2",
+                 "n1_w", "n1_b", "n2_w", "n2_b", "n3_w", "n3_b",
+                 "qkv", "att", "y", "x1", "x1b", "cq", "ckv", "catt", "cy", "x2", "x2b", "ffh", "y2", "out", "outb")
+
+
+class TLayer(ctypes.Structure):
+    """Mirror of ``tcavt_tlayer`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in TLAYER_FIELDS]
+
+
+class TStackArgs(ctypes.Structure):
+    """Mirror of ``tcavt_tstack_args`` (include/tcavt.h)."""
+
+    _fields_ = [
+        ("layers", ctypes.POINTER(TLayer)),
+        ("x", c_void_p), ("xb", c_void_p), ("mem", c_void_p), ("memb", c_void_p), ("key_len", c_void_p),
+        ("n_layers", ctypes.c_int32), ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("Lk", ctypes.c_int32),
+        ("E", ctypes.c_int32), ("FF", ctypes.c_int32), ("nhead", ctypes.c_int32), ("dtype16", ctypes.c_int32),
+        ("dropout_p", ctypes.c_float), ("first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
+    ]
+
+
 class LlamaStackArgs(ctypes.Structure):
     """Mirror of ``tcavt_llama_stack_args`` (include/tcavt.h)."""
 
@@ -184,6 +207,7 @@ _SIGNATURES = {
                         ctypes.c_uint32, c_int, c_void_p],
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_allreduce_flat": [c_void_p, c_int64, c_void_p, c_void_p],
+    "tcavt_tlayer_stack_forward": [ctypes.POINTER(TStackArgs), c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

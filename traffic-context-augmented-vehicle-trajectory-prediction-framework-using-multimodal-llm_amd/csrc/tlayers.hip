@@ -1,0 +1,104 @@
+// Stage-level composition of the post-LN nn.TransformerEncoderLayer / nn.TransformerDecoderLayer stacks of the path
+// (SURVEY.md 8b "qformer_forward", "polygon_encoder_forward"): the Q-Former's four encoder + four decoder layers
+// (scripts/train.py:388-414; 16-bit MFMA contractions) and the lane-polygon encoder's layers (scripts/train.py:352-383; fp32
+// end to end) as ONE call each.  Every layer is the launch sequence tcavt_amd.model._TLayerRunner issues from Python --
+//   self-attention:  qkv = x W_in^T + b -> tcavt_mha -> y = x + drop(att W_out^T + b) -> LayerNorm
+//   cross-attention: q = x1 W_q^T + b, k|v = mem W_kv^T + b -> tcavt_mha -> y2 = x1 + drop(..) -> LayerNorm     (decoder layers)
+//   feed-forward:    f = drop(relu(x W_1^T + b)) -> y3 = x + drop(f W_2^T + b) -> LayerNorm
+// -- on the same kernels, with the same buffers (all caller-owned; per layer when a backward will read them) and the same
+// dropout sites (numbered in call order from first_site), so the result is bit-identical to the Python composition.
+#include "common.hpp"
+
+using namespace tcavt;
+
+#define TCAVT_TRY(call)            \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != TCAVT_OK) return rc_; \
+  } while (0)
+
+namespace {
+struct Ctx {
+  const tcavt_tstack_args* a;
+  tcavt_stream_t st;
+  uint32_t site;
+  int M;
+
+  int gemm(const void* A16, const float* A32, const void* W, const float* bias, void* C, int out_dtype, int Mr, int N, int K,
+           bool relu, const float* residual, bool drop) {
+    const float p = drop ? a->dropout_p : 0.f;
+    const uint32_t s = drop && a->dropout_p > 0.f ? site++ : 0u;
+    int flags = (bias ? TCAVT_EPI_BIAS : 0) | (relu ? TCAVT_EPI_RELU : 0) | (residual ? TCAVT_EPI_RESIDUAL : 0);
+    if (a->dtype16) {
+      tcavt_gemm_args g = {};
+      g.A = A16; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = Mr; g.N = N; g.K = K;
+      g.out_dtype = out_dtype; g.in_dtype = a->dtype16; g.epilogue = flags; g.bias = bias; g.residual = residual; g.ldr = N;
+      g.dropout_p = p; g.dropout_seed = a->dropout_seed; g.dropout_site = s;
+      return tcavt_gemm_bf16(&g, st);
+    }
+    return tcavt_gemm_f32(A32, K, static_cast<const float*>(W), K, bias, residual, N, static_cast<float*>(C), N, Mr, N, K, flags, p,
+                          a->dropout_seed, s, st);
+  }
+  int norm(const float* y, const float* w, const float* b, float* out, void* outb) {
+    return tcavt_layernorm(y, nullptr, w, b, 1e-5f, out, a->dtype16 ? outb : nullptr, M, a->E, a->dtype16 ? a->dtype16 : TCAVT_BF16, st);
+  }
+};
+}  // namespace
+
+extern "C" int tcavt_tlayer_stack_forward(const tcavt_tstack_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->layers && a->n_layers > 0 && a->x && a->B > 0 && a->L > 0 && a->E > 0 && a->FF > 0 && a->nhead > 0 &&
+                      a->E % a->nhead == 0,
+                  "tlayer_stack_forward: bad args");
+  TCAVT_CHECK_ARG(a->dtype16 == 0 || is16(a->dtype16), "tlayer_stack_forward: dtype16 must be 0 (fp32 layers), TCAVT_BF16 or TCAVT_F16");
+  TCAVT_CHECK_ARG(!a->dtype16 || a->xb, "tlayer_stack_forward: 16-bit layers need the 16-bit copy of the input tokens");
+  TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "tlayer_stack_forward: dropout_p must be in [0, 1)");
+  const int E = a->E, FF = a->FF, nh = a->nhead, dh = E / nh, M = a->B * a->L;
+  const int act = a->dtype16 ? a->dtype16 : TCAVT_F32;
+  const float scale = (float)(1.0 / sqrt((double)dh));  // (as the Python caller forms it: double, rounded once)
+  Ctx c{a, stream, a->first_site, M};
+  auto mha_site = [&]() -> uint32_t { return a->dropout_p > 0.f ? c.site++ : 0u; };
+  const float* x = a->x;
+  const void* xb = a->xb;
+  for (int li = 0; li < a->n_layers; ++li) {
+    const tcavt_tlayer& l = a->layers[li];
+    const bool dec = l.w_q != nullptr;
+    TCAVT_CHECK_ARG(l.w_in && l.b_in && l.w_out && l.b_out && l.w1 && l.b1 && l.w2 && l.b2 && l.n1_w && l.n1_b && l.n2_w && l.n2_b &&
+                        l.qkv && l.att && l.y && l.x1 && l.ffh && l.y2 && l.out && (!a->dtype16 || (l.x1b && l.outb)),
+                    "tlayer_stack_forward: layer %d: null weight / buffer", li);
+    if (dec)
+      TCAVT_CHECK_ARG(a->mem && (!a->dtype16 || a->memb) && a->Lk > 0 && l.b_q && l.w_kv && l.b_kv && l.w_co && l.b_co && l.n3_w &&
+                          l.n3_b && l.cq && l.ckv && l.catt && l.cy && l.x2 && (!a->dtype16 || l.x2b),
+                      "tlayer_stack_forward: layer %d: decoder layer without memory / cross-attention buffers", li);
+    // ---- self-attention block
+    TCAVT_TRY(c.gemm(xb, x, l.w_in, l.b_in, l.qkv, TCAVT_F32, M, 3 * E, E, false, nullptr, false));
+    {
+      const uint32_t s = mha_site();
+      TCAVT_TRY(tcavt_mha(l.qkv, 3 * E, l.qkv + E, 3 * E, l.qkv + 2 * E, 3 * E, l.att, E, a->key_len, a->B, a->L, a->L, nh, dh, scale,
+                          TCAVT_F32, act, a->dropout_p, a->dropout_seed, s, stream));
+    }
+    TCAVT_TRY(c.gemm(l.att, static_cast<const float*>(l.att), l.w_out, l.b_out, l.y, TCAVT_F32, M, E, E, false, x, true));
+    TCAVT_TRY(c.norm(l.y, l.n1_w, l.n1_b, l.x1, l.x1b));
+    const float* xin = l.x1;
+    const void* xinb = l.x1b;
+    // ---- cross-attention block (decoder layers)
+    if (dec) {
+      const int Mk = a->B * a->Lk;
+      TCAVT_TRY(c.gemm(l.x1b, l.x1, l.w_q, l.b_q, l.cq, TCAVT_F32, M, E, E, false, nullptr, false));
+      TCAVT_TRY(c.gemm(a->memb, a->mem, l.w_kv, l.b_kv, l.ckv, TCAVT_F32, Mk, 2 * E, E, false, nullptr, false));
+      const uint32_t s = mha_site();
+      TCAVT_TRY(tcavt_mha(l.cq, E, l.ckv, 2 * E, l.ckv + E, 2 * E, l.catt, E, nullptr, a->B, a->L, a->Lk, nh, dh, scale, TCAVT_F32, act,
+                          a->dropout_p, a->dropout_seed, s, stream));
+      TCAVT_TRY(c.gemm(l.catt, static_cast<const float*>(l.catt), l.w_co, l.b_co, l.cy, TCAVT_F32, M, E, E, false, l.x1, true));
+      TCAVT_TRY(c.norm(l.cy, l.n2_w, l.n2_b, l.x2, l.x2b));
+      xin = l.x2;
+      xinb = l.x2b;
+    }
+    // ---- feed-forward block
+    TCAVT_TRY(c.gemm(xinb, xin, l.w1, l.b1, l.ffh, act, M, FF, E, true, nullptr, true));
+    TCAVT_TRY(c.gemm(l.ffh, static_cast<const float*>(l.ffh), l.w2, l.b2, l.y2, TCAVT_F32, M, E, FF, false, xin, true));
+    TCAVT_TRY(c.norm(l.y2, dec ? l.n3_w : l.n2_w, dec ? l.n3_b : l.n2_b, l.out, l.outb));
+    x = l.out;
+    xb = l.outb;
+  }
+  return TCAVT_OK;
+}

@@ -18,6 +18,7 @@ Differences from the reference that are deliberate and documented in DESIGN.md:
 """
 import contextlib
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -274,6 +275,84 @@ class _TLayerRunner:
                 f=self._buf("ffh", (M, p.w1.shape[0]), self.dt16 if self.bf16 else torch.float32, dev)))
         return out
 
+    def run_stack(self, layers, x, xb, B, L, mem=None, memb=None, Lk=0, key_len=None, tag_fmt=None):
+        """All `layers` (prepared encoder or decoder layers) in ONE C call (tcavt_tlayer_stack_forward, csrc/tlayers.hip): the
+        launch sequence, buffers and dropout sites of encoder_layer / decoder_layer below, issued from C++.  Returns the last
+        layer's (out, out16).  TCAVT_PY_TLAYERS=1 runs the per-layer Python composition instead (A/B, bit-identical)."""
+        from . import capi
+
+        decoder = mem is not None
+        if os.environ.get("TCAVT_PY_TLAYERS", "0") == "1":
+            for i, p in enumerate(layers):
+                if self.record is not None and tag_fmt:
+                    self.layer_tag = tag_fmt.format(i)
+                x, xb = (self.decoder_layer(p, x, xb, mem, memb, B, L, Lk, slot=i & 1) if decoder else
+                         self.encoder_layer(p, x, xb, B, L, key_len=key_len, slot=i & 1))
+            return x, xb
+        dev, (M, E) = x.device, x.shape
+        a16 = self.dt16 if self.bf16 else torch.float32
+        arr = (capi.TLayer * len(layers))()
+        keep = [x, xb, mem, memb, key_len]
+        first_site, recs = None, []
+        x_in, xb_in = x, xb
+        for i, p in enumerate(layers):
+            if self.record is not None and tag_fmt:
+                self.layer_tag = tag_fmt.format(i)
+            slot = i & 1
+            ff = p.w1.shape[0]
+            n = "d" if decoder else "x"
+            bufs = dict(qkv=self._buf("qkv", (M, 3 * E), torch.float32, dev), att=self._buf("att", (M, E), a16, dev),
+                        y=self._buf("y", (M, E), torch.float32, dev), x1=self._buf(f"{n}1_{slot}", (M, E), torch.float32, dev),
+                        ffh=self._buf("ffh", (M, ff), a16, dev), y2=self._buf("y2", (M, E), torch.float32, dev))
+            last = f"d3_{slot}" if decoder else f"x2_{slot}"
+            bufs["out"] = self._buf(last, (M, E), torch.float32, dev)
+            if self.bf16:
+                bufs["x1b"] = self._buf(f"{n}1_{slot}b", (M, E), self.dt16, dev)
+                bufs["outb"] = self._buf(last + "b", (M, E), self.dt16, dev)
+            if decoder:
+                bufs.update(cq=self._buf("cq", (M, E), torch.float32, dev), ckv=self._buf("ckv", (mem.shape[0], 2 * E), torch.float32, dev),
+                            catt=self._buf("catt", (M, E), a16, dev), cy=self._buf("cy", (M, E), torch.float32, dev),
+                            x2=self._buf(f"d2_{slot}", (M, E), torch.float32, dev))
+                if self.bf16:
+                    bufs["x2b"] = self._buf(f"d2_{slot}b", (M, E), self.dt16, dev)
+            w = dict(w_in=p.sa.w_in, b_in=p.sa.b_in, w_out=p.sa.w_out, b_out=p.sa.b_out, w1=p.w1, b1=p.b1, w2=p.w2, b2=p.b2,
+                     n1_w=p.n1.weight, n1_b=p.n1.bias, n2_w=p.n2.weight, n2_b=p.n2.bias)
+            if decoder:
+                w.update(w_q=p.ca.w_q, b_q=p.ca.b_q, w_kv=p.ca.w_kv, b_kv=p.ca.b_kv, w_co=p.ca.w_out, b_co=p.ca.b_out,
+                         n3_w=p.n3.weight, n3_b=p.n3.bias)
+            for k_, t_ in list(bufs.items()) + list(w.items()):
+                setattr(arr[i], k_, t_.data_ptr())
+                keep.append(t_)
+            specs = [self._draw() for _ in range(6 if decoder else 4)]  # the sites of this layer, in the kernels' call order
+            self.specs = []
+            if specs[0] is not None and first_site is None:
+                first_site = specs[0]
+            if self.record is not None:
+                r = dict(drop=specs, x=x_in, xb=xb_in, y=bufs["y"], x1=bufs["x1"], x1b=bufs.get("x1b"), qkv=bufs["qkv"],
+                         att=bufs["att"], f=bufs["ffh"])
+                if decoder:
+                    r.update(y2=bufs["cy"], x2=bufs["x2"], x2b=bufs.get("x2b"), y3=bufs["y2"], cq=bufs["cq"], ckv=bufs["ckv"],
+                             catt=bufs["catt"])
+                else:
+                    r.update(y2=bufs["y2"])
+                recs.append(r)
+            x_in, xb_in = bufs["out"], bufs.get("outb")
+        args = capi.TStackArgs()
+        args.layers, args.n_layers = arr, len(layers)
+        args.x, args.xb = x.data_ptr(), (xb.data_ptr() if xb is not None else None)
+        if decoder:
+            args.mem, args.memb = mem.data_ptr(), (memb.data_ptr() if memb is not None else None)
+        args.key_len = key_len.data_ptr() if key_len is not None else None
+        args.B, args.L, args.Lk, args.E, args.FF, args.nhead = B, L, Lk, E, layers[0].w1.shape[0], self.nhead
+        args.dtype16 = (capi.F16 if self.dt16 == torch.float16 else capi.BF16) if self.bf16 else 0
+        if first_site is not None:
+            args.dropout_p, args.dropout_seed, args.first_site = first_site[0], first_site[1] & 0xFFFFFFFFFFFFFFFF, first_site[2]
+        ops.tlayer_stack_forward(args)
+        del keep
+        if self.record is not None:
+            self.record.extend(recs)
+        return x_in, xb_in
+
     def decoder_layer(self, p, x, xb, mem, memb, B, Lq, Lk, slot=0):
         y = self.self_attn(p.sa, x, xb, B, Lq, None)
         x1, x1b = self.norm(y, p.n1, f"d1_{slot}")
@@ -326,11 +405,7 @@ class LanePolygonEncoder(nn.Module, _Prepared):
         polygon_batch = polygon_batch.contiguous()
         ops.poly_embed(polygon_batch, self.input_proj.weight, self.input_proj.bias,
                        self.pos_embedding[0, :P].contiguous(), x)
-        xb = None
-        for i, p in enumerate(self._prepared()):
-            if keep:
-                run.layer_tag = f".L{i}"
-            x, xb = run.encoder_layer(p, x, xb, B, P, key_len=lens, slot=i & 1)
+        x, _ = run.run_stack(self._prepared(), x, None, B, P, key_len=lens, tag_fmt=".L{}" if keep else None)
         emb = torch.empty((B, D), dtype=torch.float32, device=dev)
         ops.masked_mean(x, lens, emb, B, P, D)
         if keep:
@@ -376,19 +451,13 @@ class BlipQFormer(nn.Module, _Prepared):
         xb = self._ws.get("qf.x0b", (B * Tv, E), self.storage, dev)
         ops.cast16(x, out=xb)
         x0, x0b = x, xb
-        for i, p in enumerate(P.enc):
-            if keep:
-                run.layer_tag = f".E{i}"
-            x, xb = run.encoder_layer(p, x, xb, B, Tv, slot=i & 1)
+        x, xb = run.run_stack(P.enc, x, xb, B, Tv, tag_fmt=".E{}" if keep else None)
         mem, memb = x, xb
         if B not in P.q0:  # learned queries broadcast over the batch (train.py:412); constant per B
             q = self.query_tokens.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, E).contiguous()
             P.q0[B] = (q, ops.cast16(q, dtype=self.storage))
         q, qb = P.q0[B]
-        for i, p in enumerate(P.dec):
-            if keep:
-                run.layer_tag = f".D{i}"
-            q, qb = run.decoder_layer(p, q, qb, mem, memb, B, Nq, Tv, slot=i & 1)
+        q, qb = run.run_stack(P.dec, q, qb, B, Nq, mem=mem, memb=memb, Lk=Tv, tag_fmt=".D{}" if keep else None)
         if keep:
             ne = len(P.enc)
             self.saved = SimpleNamespace(enc=run.record[:ne], dec=run.record[ne:], vb=vb, x0=x0, x0b=x0b, mem=mem, memb=memb,
