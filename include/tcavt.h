@@ -585,6 +585,30 @@ typedef struct tcavt_tstack_args {
 
 int tcavt_tlayer_stack_forward(const tcavt_tstack_args* args, tcavt_stream_t stream);
 
+/* The trajectory head's cross-attention over the LLM's final hidden states (scripts/train.py:795-798) in absorbed form, one
+ * call: q'_h = q_h W_k[h], scores = q' F^T / sqrt(dh), P = dropout(softmax), ctx = P F, att_h = ctx_h W_v[h]^T + b_v[h]
+ * (identical to nn.MultiheadAttention in exact arithmetic: b_k is softmax-invariant, rows of P sum to 1).  fp16 storage. */
+typedef struct tcavt_cross_attn_args {
+  const void* q;       /* fp16 [B*To][H]: projected queries (in_proj_weight[:H], bias included) */
+  const void* wk_t;    /* fp16 [nhead][H][dh]: W_k per head, transposed */
+  const void* w_v;     /* fp16 [H][H]: in_proj_weight[2H:] */
+  const float* b_v;    /* fp32 [H] */
+  const void* fh;      /* fp16 [B*L (+ >= Lp - L zeroed rows)][H]: final hidden states */
+  void* fh_t;          /* fp16 [H][B*Lp] workspace: receives F^T per sample */
+  void* qp;            /* fp16 [nhead][B*To][H] workspace (kept for the backward) */
+  float* scores;       /* fp32 [B*nhead*To][Lp] */
+  void* probs;         /* fp16 [B*nhead*To][Lp]: dropped probabilities, zero beyond L */
+  void* ctx;           /* fp16 [nhead][B*To][H] (kept for the backward) */
+  void* att;           /* fp16 [B*To][H]: output, heads side by side */
+  int32_t B, To, L, Lp, H, nhead, dtype16;
+  float dropout_p;     /* attention-weight dropout (train mode) */
+  uint32_t dropout_site;
+  uint32_t reserved0;
+  uint64_t dropout_seed;
+} tcavt_cross_attn_args;
+
+int tcavt_cross_attn_forward(const tcavt_cross_attn_args* args, tcavt_stream_t stream);
+
 /* SUM all-reduce, in place, of a flat fp32 buffer on the caller's RCCL communicator (`nccl_comm` is an ncclComm_t) and
  * stream: one gradient bucket of the data-parallel step (the DistributedDataParallel wrap of scripts/train.py:1127 does
  * this during backward; tcavt_amd.training.Trainer issues the same exchange through torch.distributed).  The mean is taken

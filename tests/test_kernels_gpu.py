@@ -588,8 +588,9 @@ def test_embed_fuse_16bit_stream(gpu):
 @pytest.mark.parametrize("train", [False, True])
 def test_tlayer_stack_matches_python_composition(gpu, train, monkeypatch):
     """tcavt_tlayer_stack_forward (Q-Former encoder + decoder stacks in 16-bit, lane-polygon encoder in fp32, as ONE C call each)
-    against the per-layer Python composition of the same kernel-level entry points (TCAVT_PY_TLAYERS=1): bit-identical image
-    tokens and polygon embeddings, eval arithmetic and train mode (same dropout sites)."""
+    and tcavt_cross_attn_forward (the head's absorbed cross-attention) against the per-launch Python composition of the same
+    kernel-level entry points (TCAVT_PY_TLAYERS=1): bit-identical image tokens, polygon embeddings and decoded trajectories,
+    eval arithmetic and train mode (same dropout sites)."""
     from tcavt_amd import model
     from tests.util import batch_tensors, load_case
 
@@ -611,10 +612,14 @@ def test_tlayer_stack_matches_python_composition(gpu, train, monkeypatch):
         with torch.no_grad():
             img = m.mllm._image_tokens(g["vision_emb"]).clone()
             emb = m.lane_polygon_encoder(g["lane_polygon"], g["lane_polygon_len"]).clone()
+            # the whole model: also the head's cross-attention (tcavt_cross_attn_forward vs its per-launch composition)
+            m._fwd_count = 0
+            dec = m(g["traj_emb"], g["vision_emb"], None, g["lane_polygon"], g["lane_polygon_len"], input_ids=g["input_ids"],
+                    attention_mask=g["attention_mask"]).clone()
         torch.cuda.synchronize()
-        return img, emb
+        return img, emb, dec
 
-    img_c, emb_c = run(False)
-    img_p, emb_p = run(True)
-    assert torch.isfinite(img_c).all() and torch.isfinite(emb_c).all()
-    assert torch.equal(img_c, img_p) and torch.equal(emb_c, emb_p)
+    img_c, emb_c, dec_c = run(False)
+    img_p, emb_p, dec_p = run(True)
+    assert torch.isfinite(img_c).all() and torch.isfinite(emb_c).all() and torch.isfinite(dec_c).all()
+    assert torch.equal(img_c, img_p) and torch.equal(emb_c, emb_p) and torch.equal(dec_c, dec_p)

@@ -88,6 +88,15 @@ class TStackArgs(ctypes.Structure):
     ]
 
 
+class CrossAttnArgs(ctypes.Structure):
+    """Mirror of ``tcavt_cross_attn_args`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("q", "wk_t", "w_v", "b_v", "fh", "fh_t", "qp", "scores", "probs", "ctx", "att")] + [
+        (n, ctypes.c_int32) for n in ("B", "To", "L", "Lp", "H", "nhead", "dtype16")] + [
+        ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("dropout_seed", ctypes.c_uint64)]
+
+
 class LlamaStackArgs(ctypes.Structure):
     """Mirror of ``tcavt_llama_stack_args`` (include/tcavt.h)."""
 
@@ -208,6 +217,7 @@ _SIGNATURES = {
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_allreduce_flat": [c_void_p, c_int64, c_void_p, c_void_p],
     "tcavt_tlayer_stack_forward": [ctypes.POINTER(TStackArgs), c_void_p],
+    "tcavt_cross_attn_forward": [ctypes.POINTER(CrossAttnArgs), c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

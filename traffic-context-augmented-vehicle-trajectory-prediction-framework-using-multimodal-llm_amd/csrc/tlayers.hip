@@ -102,3 +102,66 @@ extern "C" int tcavt_tlayer_stack_forward(const tcavt_tstack_args* a, tcavt_stre
   }
   return TCAVT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The trajectory head's cross-attention over the LLM's final hidden states (nn.MultiheadAttention with query = the To
+// decoder tokens of a sample, key = value = its L hidden states; scripts/train.py:795-798) in ABSORBED form, one call
+// (SURVEY.md 8b "cross_attn_forward").  Per head h with F = the sample's hidden states:
+//     q'_h = q_h W_k[h]                     scores_h = q'_h F^T / sqrt(dh)   (+ a per-query constant from b_k: softmax-invariant)
+//     P_h  = dropout(softmax(scores_h))     ctx_h = P_h F                    att_h = ctx_h W_v[h]^T + b_v[h]
+// so the K / V projections act on B*To query rows instead of B*L hidden-state rows.  Launches: one
+// transpose of F (per sample, keys padded to Lp), nh small GEMMs, one batched GEMM, the row softmax, one batched GEMM,
+// nh small GEMMs -- the sequence tcavt_amd.model.TransformerLTSF.forward issued from Python.
+// ---------------------------------------------------------------------------
+extern "C" int tcavt_cross_attn_forward(const tcavt_cross_attn_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->q && a->wk_t && a->w_v && a->b_v && a->fh && a->fh_t && a->qp && a->scores && a->probs && a->ctx && a->att,
+                  "cross_attn_forward: null pointer");
+  TCAVT_CHECK_ARG(a->B > 0 && a->To > 0 && a->L > 0 && a->Lp >= a->L && a->Lp % 64 == 0 && a->H > 0 && a->nhead > 0 &&
+                      a->H % a->nhead == 0 && (a->H / a->nhead) % 64 == 0 && a->H % 64 == 0,
+                  "cross_attn_forward: bad shape (Lp %% 64 == 0 >= L, head dim %% 64 == 0)");
+  TCAVT_CHECK_ARG(a->dtype16 == TCAVT_F16, "cross_attn_forward: fp16 storage only (the probabilities are carried in fp16)");
+  TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "cross_attn_forward: dropout_p must be in [0, 1)");
+  const int B = a->B, To = a->To, L = a->L, Lp = a->Lp, H = a->H, nh = a->nhead, dh = H / nh, M = B * To, dt = a->dtype16;
+  const char* q = static_cast<const char*>(a->q);
+  const char* wk_t = static_cast<const char*>(a->wk_t);
+  const char* w_v = static_cast<const char*>(a->w_v);
+  char* qp = static_cast<char*>(a->qp);
+  char* ctx = static_cast<char*>(a->ctx);
+  char* att = static_cast<char*>(a->att);
+  // F^T per sample: [H][B * Lp], keys L..Lp-1 zero
+  TCAVT_TRY(tcavt_transpose16(a->fh, H, a->fh_t, (int64_t)B * Lp, L, H, Lp, B, (int64_t)L * H, Lp, 0, stream));
+  for (int h = 0; h < nh; ++h) {  // q'_h = q[:, h] W_k[h]   (W operand: W_k[h]^T, [H][dh])
+    tcavt_gemm_args g = {};
+    g.A = q + (size_t)h * dh * 2; g.lda = H; g.W = wk_t + (size_t)h * H * dh * 2; g.ldw = dh;
+    g.C = qp + (size_t)h * M * H * 2; g.ldc = H; g.M = M; g.N = H; g.K = dh; g.out_dtype = dt; g.in_dtype = dt;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  {  // scores[b, h] = q'_h[b] F[b]^T / sqrt(dh)
+    tcavt_gemm_args g = {};
+    g.A = a->qp; g.lda = H; g.W = a->fh; g.ldw = H; g.C = a->scores; g.ldc = Lp; g.M = To; g.N = Lp; g.K = H;
+    g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = 64; g.acc_scale = (float)(1.0 / sqrt((double)dh));
+    g.batch = B * nh; g.batch_inner = nh;
+    g.sAo = (int64_t)To * H; g.sAi = (int64_t)M * H; g.sWo = (int64_t)L * H; g.sWi = 0;
+    g.sCo = (int64_t)nh * To * Lp; g.sCi = (int64_t)To * Lp;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  TCAVT_TRY(tcavt_softmax_rows(a->scores, Lp, a->probs, Lp, TCAVT_F16, B * nh * To, L, Lp, a->dropout_p, a->dropout_seed,
+                               a->dropout_site, stream));
+  {  // ctx[h][b] = P[b, h] F[b]
+    tcavt_gemm_args g = {};
+    g.A = a->probs; g.lda = Lp; g.W = a->fh_t; g.ldw = (int64_t)B * Lp; g.C = a->ctx; g.ldc = H; g.M = To; g.N = H; g.K = Lp;
+    g.out_dtype = dt; g.in_dtype = TCAVT_F16; g.tile = 64;
+    g.batch = B * nh; g.batch_inner = nh;
+    g.sAo = (int64_t)nh * To * Lp; g.sAi = (int64_t)To * Lp; g.sWo = Lp; g.sWi = 0;
+    g.sCo = (int64_t)To * H; g.sCi = (int64_t)M * H;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  for (int h = 0; h < nh; ++h) {  // att[:, h] = ctx_h W_v[h]^T + b_v[h]
+    tcavt_gemm_args g = {};
+    g.A = ctx + (size_t)h * M * H * 2; g.lda = H; g.W = w_v + (size_t)h * dh * H * 2; g.ldw = H;
+    g.C = att + (size_t)h * dh * 2; g.ldc = H; g.M = M; g.N = dh; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
+    g.bias = a->b_v + (size_t)h * dh; g.epilogue = TCAVT_EPI_BIAS;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  return TCAVT_OK;
+}

@@ -1266,7 +1266,6 @@ class TransformerLTSF(nn.Module, _Prepared):
             # fh^T per sample [H][B*Lp] (keys padded to Lp with zeros): the W operand of ctx = P . fh.  No K / V projection:
             # see the absorbed form below.
             fhT = ws.get("lt.fhT", (H, B * Lp), self.storage, dev)
-            ops.transpose16(final_hidden_bf16, fhT, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
         else:
             with kv_ctx:
                 # K projection [B*L, H] bf16 (tail rows only ever feed score columns >= L, which softmax ignores)
@@ -1313,19 +1312,33 @@ class TransformerLTSF(nn.Module, _Prepared):
             # Same arithmetic as nn.MultiheadAttention (train.py:795-798) in exact arithmetic; the rounding points move from
             # k, v to q' = q_h W_k[h] and ctx_h = P_h fh (oracle/forward.py restates both forms).
             qp = ws.get("lt.qp", (nh, M, H), self.storage, dev)
-            for h in range(nh):
-                ops.gemm_bf16(q[:, h * dh:(h + 1) * dh], P.wk_T[h], out=qp[h])
-            ops.gemm_batched(qp, final_hidden_bf16, S, M=To, N=Lp, K=H, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
-                             sA=(To * H, M * H), sW=(L * H, 0), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh),
-                             tile=64)
-            self.drop_xattn = _spec(self.dctx, self.dropout_p)
-            ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
             ctx = ws.get("lt.ctx", (nh, M, H), self.storage, dev)
-            ops.gemm_batched(Pm, fhT, ctx, M=To, N=H, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
-                             sA=(nh * To * Lp, To * Lp), sW=(Lp, 0), sC=(To * H, M * H), tile=64)
-            for h in range(nh):
-                ops.gemm_bf16(ctx[h], P.w_v[h * dh:(h + 1) * dh], out=att[:, h * dh:(h + 1) * dh],
-                              bias=P.b_v[h * dh:(h + 1) * dh])
+            self.drop_xattn = _spec(self.dctx, self.dropout_p)
+            if os.environ.get("TCAVT_PY_TLAYERS", "0") == "1":  # the per-launch Python composition (A/B, bit-identical)
+                ops.transpose16(final_hidden_bf16, fhT, L, H, Lp, ld_in=H, ld_out=B * Lp, batch=B, s_in=L * H, s_out=Lp)
+                for h in range(nh):
+                    ops.gemm_bf16(q[:, h * dh:(h + 1) * dh], P.wk_T[h], out=qp[h])
+                ops.gemm_batched(qp, final_hidden_bf16, S, M=To, N=Lp, K=H, lda=H, ldw=H, ldc=Lp, batch=B * nh, inner=nh,
+                                 sA=(To * H, M * H), sW=(L * H, 0), sC=(nh * To * Lp, To * Lp), acc_scale=1.0 / math.sqrt(dh),
+                                 tile=64)
+                ops.softmax_rows(S, Pm, B * nh * To, L, Lp, Lp, Lp, dropout=self.drop_xattn)
+                ops.gemm_batched(Pm, fhT, ctx, M=To, N=H, K=Lp, lda=Lp, ldw=B * Lp, ldc=H, batch=B * nh, inner=nh,
+                                 sA=(nh * To * Lp, To * Lp), sW=(Lp, 0), sC=(To * H, M * H), tile=64)
+                for h in range(nh):
+                    ops.gemm_bf16(ctx[h], P.w_v[h * dh:(h + 1) * dh], out=att[:, h * dh:(h + 1) * dh],
+                                  bias=P.b_v[h * dh:(h + 1) * dh])
+            else:  # one C call: tcavt_cross_attn_forward (csrc/tlayers.hip), the same launch sequence
+                from . import capi
+                ca_args = capi.CrossAttnArgs()
+                for k_, t_ in (("q", q), ("wk_t", P.wk_T), ("w_v", P.w_v), ("b_v", P.b_v), ("fh", final_hidden_bf16), ("fh_t", fhT),
+                               ("qp", qp), ("scores", S), ("probs", Pm), ("ctx", ctx), ("att", att)):
+                    setattr(ca_args, k_, t_.data_ptr())
+                ca_args.B, ca_args.To, ca_args.L, ca_args.Lp, ca_args.H, ca_args.nhead = B, To, L, Lp, H, nh
+                ca_args.dtype16 = capi.F16
+                if self.drop_xattn is not None:
+                    ca_args.dropout_p, ca_args.dropout_seed, ca_args.dropout_site = (
+                        self.drop_xattn[0], self.drop_xattn[1] & 0xFFFFFFFFFFFFFFFF, self.drop_xattn[2])
+                ops.cross_attn_forward(ca_args)
         else:
             if main is not None:
                 main.wait_stream(self._kv_stream)

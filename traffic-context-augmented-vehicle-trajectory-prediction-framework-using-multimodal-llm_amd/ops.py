@@ -805,6 +805,11 @@ def tlayer_stack_forward(args):
     check(lib().tcavt_tlayer_stack_forward(ctypes.byref(args), stream_ptr()), "tcavt_tlayer_stack_forward")
 
 
+def cross_attn_forward(args):
+    """args: capi.CrossAttnArgs filled by model.TransformerLTSF.forward (which owns and sizes every buffer)."""
+    check(lib().tcavt_cross_attn_forward(ctypes.byref(args), stream_ptr()), "tcavt_cross_attn_forward")
+
+
 def allreduce_flat(buf, nccl_comm):
     """In-place SUM all-reduce of a flat fp32 buffer on a raw RCCL communicator (an ncclComm_t as int / c_void_p) and the
     current stream: tcavt_allreduce_flat, the C host's form of the gradient-bucket exchange (Trainer itself goes through
