@@ -609,6 +609,52 @@ typedef struct tcavt_cross_attn_args {
 
 int tcavt_cross_attn_forward(const tcavt_cross_attn_args* args, tcavt_stream_t stream);
 
+/* TransformerLTSF.forward (scripts/train.py:808-842), one call per phase: 1 = the LLM-independent front (token projection,
+ * N-Linear encoder, SelfAttentionBlock), 2 = the head (N-Linear decoder .. cross-attention .. output head), 3 = both.
+ * fp16 storage; every buffer caller-owned. */
+typedef struct tcavt_ltsf_args {
+  /* ---- phase 1: LLM-independent front (fp32) */
+  const float* x;        /* [B][F][T] normalised input trajectories (also the head's "last position" residual) */
+  const float* conv_w;   /* token_proj.weight [C][F] */
+  const float* conv_b;   /* [C] */
+  const float* enc_w;    /* N-Linear encoder weights, stacked [C][T][T] */
+  const float* enc_b;    /* [C][T] */
+  const float* pos;      /* pos_encoding [C][T] */
+  float* tok;            /* [B*T][C] tokens */
+  float* xp_tok;         /* optional [B*T][C]: projected input, kept for the backward */
+  const float *sa_n1_w, *sa_n1_b, *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b, *sa_n2_w, *sa_n2_b, *sa_f0_w, *sa_f0_b, *sa_f3_w, *sa_f3_b;
+  float *sa_xn, *sa_qkv, *sa_att, *sa_res1, *sa_rn, *sa_f; /* SelfAttentionBlock activations: [B*T][C], [.][3C], [.][C], [.][C], [.][C], [.][4C] */
+  float* e;              /* [B*T][C]: output of the front (input of phase 2) */
+  /* ---- phase 2: the head */
+  const float* poly_emb; /* [B][poly_dim] lane-polygon embedding */
+  const float *lane_w, *lane_b;  /* lane_fc [C*To][poly_dim], [C*To] */
+  const float *dec_w, *dec_b;    /* N-Linear decoder, stacked [C][To][T], [C][To] */
+  float *lane, *d0;              /* [B][C*To] each */
+  const float *pm0_w, *pm0_b, *pm3_w, *pm3_b; /* post-MLP (post_hidden > 0): [post_hidden][C*To], [C*To][post_hidden] */
+  float *hid, *d1;               /* [B][post_hidden], [B][C*To] */
+  float* dec_t;                  /* [B*To][C] fp32 */
+  void* dec_tb;                  /* its fp16 copy */
+  const void* w_dp; const float* b_dp;  /* dec_proj fp16 [H][C] */
+  void* proj;                    /* fp16 [B*To][H] */
+  const void* w_q; const float* b_q;    /* cross-attention q projection fp16 [H][H] */
+  tcavt_cross_attn_args xattn;   /* its q / att buffers are the stage's */
+  const void* w_co; const float* b_co;  /* cross-attention out_proj fp16 [H][H] */
+  void* cross;                   /* fp16 [B*To][H] */
+  const void* w_un; const float* b_un;  /* dec_unproj fp16 [C][H] */
+  float* fused;                  /* [B*To][C] = dec_t + unproj */
+  const float *fl_n_w, *fl_n_b; float* fn;          /* fusion LayerNorm */
+  const float *fl1_w, *fl1_b; float* f1;            /* fusion Linear + ReLU */
+  const float *fl3_w, *fl3_b; float* f2;            /* fusion Linear */
+  const float *out_w, *out_b;    /* out_proj [F][C] */
+  float* out;                    /* [B][F][To] */
+  int32_t B, C, T, To, F, H, nhead_sa, poly_dim, post_hidden, add_last;
+  float dropout_p;               /* LTSF dropout (train mode); sites first_site + 0..3 (self-attention block), + 4 (post-MLP) */
+  uint32_t first_site;
+  uint64_t dropout_seed;
+} tcavt_ltsf_args;
+
+int tcavt_ltsf_forward(const tcavt_ltsf_args* args, int phase, tcavt_stream_t stream);
+
 /* SUM all-reduce, in place, of a flat fp32 buffer on the caller's RCCL communicator (`nccl_comm` is an ncclComm_t) and
  * stream: one gradient bucket of the data-parallel step (the DistributedDataParallel wrap of scripts/train.py:1127 does
  * this during backward; tcavt_amd.training.Trainer issues the same exchange through torch.distributed).  The mean is taken

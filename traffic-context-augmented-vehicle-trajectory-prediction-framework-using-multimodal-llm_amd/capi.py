@@ -97,6 +97,14 @@ class CrossAttnArgs(ctypes.Structure):
         ("dropout_seed", ctypes.c_uint64)]
 
 
+class LtsfArgs(ctypes.Structure):
+    """Mirror of ``tcavt_ltsf_args`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ('x', 'conv_w', 'conv_b', 'enc_w', 'enc_b', 'pos', 'tok', 'xp_tok', 'sa_n1_w', 'sa_n1_b', 'sa_in_w', 'sa_in_b', 'sa_out_w', 'sa_out_b', 'sa_n2_w', 'sa_n2_b', 'sa_f0_w', 'sa_f0_b', 'sa_f3_w', 'sa_f3_b', 'sa_xn', 'sa_qkv', 'sa_att', 'sa_res1', 'sa_rn', 'sa_f', 'e', 'poly_emb', 'lane_w', 'lane_b', 'dec_w', 'dec_b', 'lane', 'd0', 'pm0_w', 'pm0_b', 'pm3_w', 'pm3_b', 'hid', 'd1', 'dec_t', 'dec_tb', 'w_dp', 'b_dp', 'proj', 'w_q', 'b_q')] + [("xattn", CrossAttnArgs)] + [(n, c_void_p) for n in ('w_co', 'b_co', 'cross', 'w_un', 'b_un', 'fused', 'fl_n_w', 'fl_n_b', 'fn', 'fl1_w', 'fl1_b', 'f1', 'fl3_w', 'fl3_b', 'f2', 'out_w', 'out_b', 'out')] + [
+        (n, ctypes.c_int32) for n in ("B", "C", "T", "To", "F", "H", "nhead_sa", "poly_dim", "post_hidden", "add_last")] + [
+        ("dropout_p", ctypes.c_float), ("first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64)]
+
+
 class LlamaStackArgs(ctypes.Structure):
     """Mirror of ``tcavt_llama_stack_args`` (include/tcavt.h)."""
 
@@ -218,6 +226,7 @@ _SIGNATURES = {
     "tcavt_allreduce_flat": [c_void_p, c_int64, c_void_p, c_void_p],
     "tcavt_tlayer_stack_forward": [ctypes.POINTER(TStackArgs), c_void_p],
     "tcavt_cross_attn_forward": [ctypes.POINTER(CrossAttnArgs), c_void_p],
+    "tcavt_ltsf_forward": [ctypes.POINTER(LtsfArgs), c_int, c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

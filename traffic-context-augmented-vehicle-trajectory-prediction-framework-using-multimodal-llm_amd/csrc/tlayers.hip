@@ -165,3 +165,85 @@ extern "C" int tcavt_cross_attn_forward(const tcavt_cross_attn_args* a, tcavt_st
   }
   return TCAVT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// TransformerLTSF.forward (scripts/train.py:808-842) as one call per phase (SURVEY.md 8b "ltsf_forward"):
+//   phase 1 (independent of the LLM: the caller runs it on a side stream under the decoder stack): token projection +
+//           per-channel N-Linear encoder + positional term (tcavt_ltsf_front) and the SelfAttentionBlock (train.py:674-686:
+//           LayerNorm, MHA, residual from the NORMED tensor, LayerNorm, FFN, residual);
+//   phase 2 (needs the final hidden states): lane_fc, N-Linear decoder, post-MLP, transpose, dec_proj, q projection,
+//           cross-attention (tcavt_cross_attn_forward), out_proj, dec_unproj + residual, fusion layer, output head.
+// Same kernels, buffers and dropout sites (first_site + 0..3: self-attention block; + 4: post-MLP; + 5: cross-attention
+// weights) as tcavt_amd.model.TransformerLTSF issues from Python; fp32 where the reference's pixel-space arithmetic needs
+// it, fp16 contractions around the cross-attention.
+// ---------------------------------------------------------------------------
+extern "C" int tcavt_ltsf_forward(const tcavt_ltsf_args* a, int phase, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && (phase == 1 || phase == 2 || phase == 3), "ltsf_forward: phase must be 1 (front), 2 (head) or 3 (both)");
+  TCAVT_CHECK_ARG(a->B > 0 && a->C > 0 && a->T > 0 && a->To > 0 && a->F > 0 && a->nhead_sa > 0 && a->C % a->nhead_sa == 0,
+                  "ltsf_forward: bad shape");
+  TCAVT_CHECK_ARG(a->dropout_p >= 0.f && a->dropout_p < 1.f, "ltsf_forward: dropout_p must be in [0, 1)");
+  const int B = a->B, C = a->C, T = a->T, To = a->To, Mt = B * T, Mo = B * To;
+  const float p = a->dropout_p;
+  const uint64_t seed = a->dropout_seed;
+  const uint32_t s0 = a->first_site;
+  auto gf32 = [&](const float* A, const float* W, const float* bias, float* Cc, int M, int N, int K, bool relu, const float* res,
+                  int site_off) {
+    const int flags = (bias ? TCAVT_EPI_BIAS : 0) | (relu ? TCAVT_EPI_RELU : 0) | (res ? TCAVT_EPI_RESIDUAL : 0);
+    const bool drop = site_off >= 0 && p > 0.f;
+    return tcavt_gemm_f32(A, K, W, K, bias, res, N, Cc, N, M, N, K, flags, drop ? p : 0.f, seed, drop ? s0 + (uint32_t)site_off : 0u,
+                          stream);
+  };
+  if (phase & 1) {
+    TCAVT_CHECK_ARG(a->x && a->conv_w && a->conv_b && a->enc_w && a->enc_b && a->pos && a->tok && a->sa_n1_w && a->sa_n1_b &&
+                        a->sa_in_w && a->sa_in_b && a->sa_out_w && a->sa_out_b && a->sa_n2_w && a->sa_n2_b && a->sa_f0_w &&
+                        a->sa_f0_b && a->sa_f3_w && a->sa_f3_b && a->sa_xn && a->sa_qkv && a->sa_att && a->sa_res1 && a->sa_rn &&
+                        a->sa_f && a->e,
+                    "ltsf_forward: phase 1: null pointer");
+    TCAVT_TRY(tcavt_ltsf_front(a->x, a->conv_w, a->conv_b, a->enc_w, a->enc_b, a->pos, a->tok, a->xp_tok, B, C, T, stream));
+    const int dh = C / a->nhead_sa;
+    TCAVT_TRY(tcavt_layernorm(a->tok, nullptr, a->sa_n1_w, a->sa_n1_b, 1e-5f, a->sa_xn, nullptr, Mt, C, TCAVT_BF16, stream));
+    TCAVT_TRY(gf32(a->sa_xn, a->sa_in_w, a->sa_in_b, a->sa_qkv, Mt, 3 * C, C, false, nullptr, -1));
+    TCAVT_TRY(tcavt_mha(a->sa_qkv, 3 * C, a->sa_qkv + C, 3 * C, a->sa_qkv + 2 * C, 3 * C, a->sa_att, C, nullptr, B, T, T, a->nhead_sa,
+                        dh, (float)(1.0 / sqrt((double)dh)), TCAVT_F32, TCAVT_F32, p, seed, p > 0.f ? s0 : 0u, stream));
+    TCAVT_TRY(gf32(a->sa_att, a->sa_out_w, a->sa_out_b, a->sa_res1, Mt, C, C, false, a->sa_xn, 1));
+    TCAVT_TRY(tcavt_layernorm(a->sa_res1, nullptr, a->sa_n2_w, a->sa_n2_b, 1e-5f, a->sa_rn, nullptr, Mt, C, TCAVT_BF16, stream));
+    TCAVT_TRY(gf32(a->sa_rn, a->sa_f0_w, a->sa_f0_b, a->sa_f, Mt, 4 * C, C, true, nullptr, 2));
+    TCAVT_TRY(gf32(a->sa_f, a->sa_f3_w, a->sa_f3_b, a->e, Mt, C, 4 * C, false, a->sa_rn, 3));
+  }
+  if (phase & 2) {
+    TCAVT_CHECK_ARG(a->e && a->poly_emb && a->lane_w && a->lane_b && a->dec_w && a->dec_b && a->lane && a->d0 && a->dec_t &&
+                        a->dec_tb && a->w_dp && a->b_dp && a->proj && a->w_q && a->b_q && a->xattn.q && a->w_co && a->b_co &&
+                        a->cross && a->w_un && a->b_un && a->fused && a->fl_n_w && a->fl_n_b && a->fn && a->fl1_w && a->fl1_b &&
+                        a->f1 && a->fl3_w && a->fl3_b && a->f2 && a->out_w && a->out_b && a->x && a->out && a->poly_dim > 0 &&
+                        a->H > 0,
+                    "ltsf_forward: phase 2: null pointer");
+    const int H = a->H, CT = C * To;
+    TCAVT_TRY(gf32(a->poly_emb, a->lane_w, a->lane_b, a->lane, B, CT, a->poly_dim, false, nullptr, -1));
+    TCAVT_TRY(tcavt_ltsf_decode(a->e, a->dec_w, a->dec_b, a->lane, a->d0, B, C, T, To, stream));
+    const float* d1 = a->d0;
+    if (a->post_hidden > 0) {
+      TCAVT_CHECK_ARG(a->pm0_w && a->pm0_b && a->pm3_w && a->pm3_b && a->hid && a->d1, "ltsf_forward: post-MLP: null pointer");
+      TCAVT_TRY(gf32(a->d0, a->pm0_w, a->pm0_b, a->hid, B, a->post_hidden, CT, true, nullptr, 4));
+      TCAVT_TRY(gf32(a->hid, a->pm3_w, a->pm3_b, a->d1, B, CT, a->post_hidden, false, nullptr, -1));
+      d1 = a->d1;
+    }
+    TCAVT_TRY(tcavt_transpose_ct(d1, a->dec_t, a->dec_tb, B, C, To, TCAVT_F16, stream));
+    auto g16 = [&](const void* A, const void* W, const float* bias, void* Cc, int out_dtype, int M, int N, int K, const float* res) {
+      tcavt_gemm_args g = {};
+      g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = Cc; g.ldc = N; g.M = M; g.N = N; g.K = K; g.out_dtype = out_dtype;
+      g.in_dtype = TCAVT_F16; g.bias = bias; g.residual = res; g.ldr = N;
+      g.epilogue = (bias ? TCAVT_EPI_BIAS : 0) | (res ? TCAVT_EPI_RESIDUAL : 0);
+      return tcavt_gemm_bf16(&g, stream);
+    };
+    TCAVT_TRY(g16(a->dec_tb, a->w_dp, a->b_dp, a->proj, TCAVT_F16, Mo, H, C, nullptr));
+    TCAVT_TRY(g16(a->proj, a->w_q, a->b_q, const_cast<void*>(a->xattn.q), TCAVT_F16, Mo, H, H, nullptr));
+    TCAVT_TRY(tcavt_cross_attn_forward(&a->xattn, stream));
+    TCAVT_TRY(g16(a->xattn.att, a->w_co, a->b_co, a->cross, TCAVT_F16, Mo, H, H, nullptr));
+    TCAVT_TRY(g16(a->cross, a->w_un, a->b_un, a->fused, TCAVT_F32, Mo, C, H, a->dec_t));
+    TCAVT_TRY(tcavt_layernorm(a->fused, nullptr, a->fl_n_w, a->fl_n_b, 1e-5f, a->fn, nullptr, Mo, C, TCAVT_BF16, stream));
+    TCAVT_TRY(gf32(a->fn, a->fl1_w, a->fl1_b, a->f1, Mo, C, C, true, nullptr, -1));
+    TCAVT_TRY(gf32(a->f1, a->fl3_w, a->fl3_b, a->f2, Mo, C, C, false, nullptr, -1));
+    TCAVT_TRY(tcavt_out_head(a->f2, a->out_w, a->out_b, a->x, a->out, B, To, C, a->F, T, a->add_last, stream));
+  }
+  return TCAVT_OK;
+}

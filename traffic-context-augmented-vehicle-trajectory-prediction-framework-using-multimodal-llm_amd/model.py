@@ -1226,8 +1226,90 @@ class TransformerLTSF(nn.Module, _Prepared):
         P = self._prepared()
         tok = ws.get("lt.tok", (B * T, C), torch.float32, dev)
         xp_tok = ws.get("lt.xp", (B * T, C), torch.float32, dev) if self.save_for_backward else None
+        if self._stage_ok(dev):  # one C call: tcavt_ltsf_forward phase 1 (csrc/tlayers.hip), the same launch sequence
+            from . import capi
+            sab, a = self.attn_block, capi.LtsfArgs()
+            sw, E, M = sab._ws, C, B * T
+            sab.drop_specs = sp = [_spec(sab.dctx, sab.dropout_p) for _ in range(4)]
+            bufs = dict(sa_xn=sw.get("sab.xn", (M, E), torch.float32, dev), sa_qkv=sw.get("sab.qkv", (M, 3 * E), torch.float32, dev),
+                        sa_att=sw.get("sab.att", (M, E), torch.float32, dev), sa_res1=sw.get("sab.res1", (M, E), torch.float32, dev),
+                        sa_rn=sw.get("sab.rn", (M, E), torch.float32, dev), sa_f=sw.get("sab.f", (M, 4 * E), torch.float32, dev),
+                        e=sw.get("sab.out", (M, E), torch.float32, dev), tok=tok, x=x)
+            wts = dict(conv_w=P.conv_w, conv_b=self.token_proj.bias, enc_w=P.enc_w, enc_b=P.enc_b, pos=P.pos,
+                       sa_n1_w=sab.norm1.weight, sa_n1_b=sab.norm1.bias, sa_in_w=sab.mha.in_proj_weight, sa_in_b=sab.mha.in_proj_bias,
+                       sa_out_w=sab.mha.out_proj.weight, sa_out_b=sab.mha.out_proj.bias, sa_n2_w=sab.norm2.weight,
+                       sa_n2_b=sab.norm2.bias, sa_f0_w=sab.ffn[0].weight, sa_f0_b=sab.ffn[0].bias, sa_f3_w=sab.ffn[3].weight,
+                       sa_f3_b=sab.ffn[3].bias)
+            keep = []
+            for k_, t_ in list(bufs.items()) + list(wts.items()):
+                setattr(a, k_, t_.data_ptr())
+                keep.append(t_)
+            if xp_tok is not None:
+                a.xp_tok = xp_tok.data_ptr()
+            a.B, a.C, a.T, a.To, a.F, a.nhead_sa = B, C, T, self.out_len, F, sab.nhead
+            if sp[0] is not None:
+                a.dropout_p, a.dropout_seed, a.first_site = sp[0][0], sp[0][1] & 0xFFFFFFFFFFFFFFFF, sp[0][2]
+            ops.ltsf_forward(a, 1)
+            del keep
+            return bufs["e"]
         ops.ltsf_front(x, P.conv_w, self.token_proj.bias, P.enc_w, P.enc_b, P.pos, tok, B, C, T, xp_tok=xp_tok)
         return self.attn_block.forward_tokens(tok, B, T)
+
+    def _head_stage(self, x, e, lane_polygon_emb, fh16, fhT, B, T, L, Lp, H, add_last):
+        """Phase 2 of tcavt_ltsf_forward: the launches of forward() below, from C++, on the same named buffers (the backward
+        finds them by name)."""
+        from . import capi
+
+        dev, C, To, ws = x.device, self.d_model, self.out_len, self._ws
+        dec, P = self.decoder, self._prepared()
+        nh = dec.cross_nhead
+        M = B * To
+        f32, st = torch.float32, self.storage
+        g = lambda n, shape, dt=f32: ws.get("lt." + n, shape, dt, dev)
+        a = capi.LtsfArgs()
+        post = dec.post_mlp[0].weight.shape[0] if dec.use_post_mlp else 0
+        self.drop_post = _spec(self.dctx, self.dropout_p) if dec.use_post_mlp else None
+        self.drop_xattn = _spec(self.dctx, self.dropout_p)
+        out = torch.empty((B, self.feature_size, To), dtype=f32, device=dev)
+        bufs = dict(x=x, e=e, poly_emb=lane_polygon_emb.contiguous(), lane=g("lane", (B, C * To)), d0=g("dec0", (B, C * To)),
+                    dec_t=g("dect", (M, C)), dec_tb=g("dectb", (M, C), st), proj=g("proj", (M, H), st), cross=g("cross", (M, H), st),
+                    fused=g("fused", (M, C)), fn=g("fn", (M, C)), f1=g("f1", (M, C)), f2=g("f2", (M, C)), out=out)
+        if post:
+            bufs.update(hid=g("hid", (B, post)), d1=g("dec1", (B, C * To)))
+        fl = dec.fusion_layer
+        wts = dict(lane_w=dec.lane_fc.weight, lane_b=dec.lane_fc.bias, dec_w=P.dec_w, dec_b=P.dec_b, w_dp=P.w_dp, b_dp=dec.dec_proj.bias,
+                   w_q=P.w_q, b_q=P.b_q, w_co=P.w_co, b_co=dec.cross_attn.out_proj.bias, w_un=P.w_un, b_un=dec.dec_unproj.bias,
+                   fl_n_w=fl[0].weight, fl_n_b=fl[0].bias, fl1_w=fl[1].weight, fl1_b=fl[1].bias, fl3_w=fl[3].weight, fl3_b=fl[3].bias,
+                   out_w=dec.out_proj.weight, out_b=dec.out_proj.bias)
+        if post:
+            wts.update(pm0_w=dec.post_mlp[0].weight, pm0_b=dec.post_mlp[0].bias, pm3_w=dec.post_mlp[3].weight,
+                       pm3_b=dec.post_mlp[3].bias)
+        xa = dict(q=g("q", (M, H), st), wk_t=P.wk_T, w_v=P.w_v, b_v=P.b_v, fh=fh16, fh_t=fhT, qp=g("qp", (nh, M, H), st),
+                  scores=g("S", (B * nh * To, Lp)), probs=g("P", (B * nh * To, Lp), torch.float16), ctx=g("ctx", (nh, M, H), st),
+                  att=g("att", (M, H), st))
+        keep = []
+        for k_, t_ in list(bufs.items()) + list(wts.items()):
+            setattr(a, k_, t_.data_ptr())
+            keep.append(t_)
+        for k_, t_ in xa.items():
+            setattr(a.xattn, k_, t_.data_ptr())
+            keep.append(t_)
+        a.xattn.B, a.xattn.To, a.xattn.L, a.xattn.Lp, a.xattn.H, a.xattn.nhead, a.xattn.dtype16 = B, To, L, Lp, H, nh, capi.F16
+        if self.drop_xattn is not None:
+            a.xattn.dropout_p, a.xattn.dropout_seed, a.xattn.dropout_site = (
+                self.drop_xattn[0], self.drop_xattn[1] & 0xFFFFFFFFFFFFFFFF, self.drop_xattn[2])
+        a.B, a.C, a.T, a.To, a.F, a.H, a.nhead_sa = B, C, T, To, self.feature_size, H, self.attn_block.nhead
+        a.poly_dim, a.post_hidden, a.add_last = lane_polygon_emb.shape[1], post, int(bool(add_last))
+        if self.drop_post is not None:  # sites: the self-attention block drew first_site .. + 3 in front(), the post-MLP + 4
+            a.dropout_p, a.dropout_seed, a.first_site = self.drop_post[0], self.drop_post[1] & 0xFFFFFFFFFFFFFFFF, self.drop_post[2] - 4
+        ops.ltsf_forward(a, 2)
+        del keep
+        return out
+
+    def _stage_ok(self, dev):
+        """The C++ stage (tcavt_ltsf_forward) covers the default form: fp16 storage, absorbed cross-attention."""
+        return (dev.type == "cuda" or ops._ALLOW_CPU) and self.absorb_kv and self.storage == torch.float16 and \
+            os.environ.get("TCAVT_PY_TLAYERS", "0") != "1"
 
     def forward(self, x, lane_polygon_emb, final_hidden, final_hidden_bf16=None, _fuse_last_residual=False, _front=None):
         """x (B,2,T) fp32; lane_polygon_emb (B,64); final_hidden (B,L,H) -> (B,2,To), as
@@ -1278,6 +1360,8 @@ class TransformerLTSF(nn.Module, _Prepared):
                 ops.gemm_batched(P.w_v, final_hidden_bf16, vT, M=H, N=Lp, K=H, lda=H, ldw=H, ldc=B * Lp, batch=B, inner=1,
                                  sA=(0, 0), sW=(L * H, 0), sC=(Lp, 0), bias_row=P.b_v)
         e = _front if _front is not None else self.front(x)
+        if absorb and self._stage_ok(dev):
+            return self._head_stage(x, e, lane_polygon_emb, final_hidden_bf16, fhT, B, T, L, Lp, H, _fuse_last_residual)
         lane = ws.get("lt.lane", (B, C * To), torch.float32, dev)
         ops.gemm_f32(lane_polygon_emb.contiguous(), dec.lane_fc.weight, out=lane, bias=dec.lane_fc.bias)
         d0 = ws.get("lt.dec0", (B, C * To), torch.float32, dev)

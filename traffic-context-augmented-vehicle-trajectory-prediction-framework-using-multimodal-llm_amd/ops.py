@@ -810,6 +810,11 @@ def cross_attn_forward(args):
     check(lib().tcavt_cross_attn_forward(ctypes.byref(args), stream_ptr()), "tcavt_cross_attn_forward")
 
 
+def ltsf_forward(args, phase):
+    """args: capi.LtsfArgs filled by model.TransformerLTSF (which owns and sizes every buffer); phase 1 / 2 / 3."""
+    check(lib().tcavt_ltsf_forward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_forward")
+
+
 def allreduce_flat(buf, nccl_comm):
     """In-place SUM all-reduce of a flat fp32 buffer on a raw RCCL communicator (an ncclComm_t as int / c_void_p) and the
     current stream: tcavt_allreduce_flat, the C host's form of the gradient-bucket exchange (Trainer itself goes through
