@@ -51,7 +51,7 @@ class Rounder:
     """r(t, tag) rounds `t` to the storage type of the rounding point `tag`.  A contract is either one mode for every
     point ("fp32" | "bf16" | "fp16") or a dict {tag or scope or "scope.tag": mode, "default": mode}; the stage functions
     name their points (llama: w, xn, t, qkv, att, act; scopes: qf = Q-Former + q_proj, xa = LTSF cross-attention head,
-    emb = embedding table, fh = final hidden states handed to the head) -- tools/error_budget.py toggles them one by one."""
+    emb = embedding table, fh = final hidden states handed to the head) -- tests/tools/error_budget.py toggles them one by one."""
 
     def __init__(self, contract, scope=None):
         # Named contracts of the HIP path (model.set_storage): "fp16" = its default storage type, "bf16" = the round-1

@@ -5,7 +5,7 @@ tabulates the relative error of final_hidden / decoded and the relative differen
   * the whole contract in bf16 (the round-1 HIP path), in fp16, and mixed forms;
   * every rounding point toggled alone (everything else fp32), in bf16 and in fp16.
 CPU only (no GPU, nothing from the product package but config / synth / weights).  Usage:
-    python tools/error_budget.py [--preset llama32_1b|midi|tiny] [--batch 2] [--text-len 240] [--out profiles/x.json]
+    python tests/tools/error_budget.py [--preset llama32_1b|midi|tiny] [--batch 2] [--text-len 240] [--out profiles/x.json]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from oracle import forward as O  # noqa: E402

@@ -1,12 +1,12 @@
 """Full-size gradient parity (train.py parameter set and the LoRA adapters of the LoRA-trainable variant) (Llama-3.2-1B shape, L = 256): the HIP path's adapter gradients for a few
 synthetic samples against torch autograd through the oracle (bf16 contract and fp32), same host-generated weights.
-Prints one JSON object; the numbers are quoted in DESIGN.md.   usage: tools/parity_grads_full.py [samples=2]"""
+Prints one JSON object; the numbers are quoted in DESIGN.md.   usage: tests/tools/parity_grads_full.py [samples=2]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from oracle import forward as O
