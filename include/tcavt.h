@@ -609,6 +609,31 @@ typedef struct tcavt_cross_attn_args {
 
 int tcavt_cross_attn_forward(const tcavt_cross_attn_args* args, tcavt_stream_t stream);
 
+/* Backward of tcavt_cross_attn_forward for constant hidden states (frozen MLLM): weight / bias gradients of the packed
+ * in_proj ([3H][H] / [3H]: rows H.. of W_k, 2H.. of W_v; the key bias gets no gradient: softmax-invariant) and the gradient of
+ * the projected queries.  Gradient-side tensors are bf16. */
+typedef struct tcavt_cross_attn_bwd_args {
+  const tcavt_cross_attn_args* fwd; /* the forward call's arguments (q, ctx, probs, scores, fh, shapes, dropout) */
+  const void* g_att;     /* bf16 [B*To][H]: dL/d att */
+  const float* w_in;     /* fp32 [3H][H]: cross_attn.in_proj_weight (the parameter itself) */
+  float* gw_in;          /* fp32 [3H][H]: its gradient; rows H..3H are WRITTEN */
+  float* gb_in;          /* fp32 [3H]: bias gradient; entries 2H..3H are ADDED to */
+  void* g_q;             /* bf16 [B*To][H]: dL/d q (out) */
+  /* workspaces (Mp = B*To rounded up to 64) */
+  void* fh_tb;           /* bf16 [H][B*Lp] */
+  void* fh_b;            /* bf16 [B*Lp][H] */
+  void* ga_t;            /* bf16 [H][Mp] */
+  void* g_ctx;           /* bf16 [nhead][B*To][H] */
+  void* w_t;             /* bf16 [H*dh] */
+  void* x_t;             /* bf16 [H][Mp] */
+  float* d_p;            /* fp32 [B*nhead*To][Lp] */
+  void* d_s;             /* bf16 [B*nhead*To][Lp] */
+  void* g_qp;            /* bf16 [nhead][B*To][H] */
+  void* p_undropped;     /* fp16 [B*nhead*To][Lp]: needed when the forward ran with dropout */
+} tcavt_cross_attn_bwd_args;
+
+int tcavt_cross_attn_backward(const tcavt_cross_attn_bwd_args* args, tcavt_stream_t stream);
+
 /* TransformerLTSF.forward (scripts/train.py:808-842), one call per phase: 1 = the LLM-independent front (token projection,
  * N-Linear encoder, SelfAttentionBlock), 2 = the head (N-Linear decoder .. cross-attention .. output head), 3 = both.
  * fp16 storage; every buffer caller-owned. */

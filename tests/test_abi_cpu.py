@@ -47,7 +47,8 @@ def _struct_fields(name):
                                           ("tcavt_llama_stack_args", "LlamaStackArgs"),
                                           ("tcavt_sample_params", "SampleParams"), ("tcavt_decode_args", "DecodeArgs"),
                                           ("tcavt_tlayer", "TLayer"), ("tcavt_tstack_args", "TStackArgs"),
-                                          ("tcavt_cross_attn_args", "CrossAttnArgs"), ("tcavt_ltsf_args", "LtsfArgs")])
+                                          ("tcavt_cross_attn_args", "CrossAttnArgs"), ("tcavt_ltsf_args", "LtsfArgs"),
+                                          ("tcavt_cross_attn_bwd_args", "CrossAttnBwdArgs")])
 def test_struct_mirrors_match_header_layout(cname, mirror, tmp_path):
     """Field order of each ctypes mirror follows the C struct, and -- compiled with the host C compiler against the real
     header -- so do sizeof and every field offset."""

@@ -10,6 +10,7 @@ Precision: fp32 wherever the forward is fp32; the cross-attention projections ru
 contractions in bf16 MFMA with fp32 accumulation (standard mixed precision), writing fp32 gradients.
 """
 import contextlib
+import ctypes
 import math
 import os
 
@@ -403,6 +404,32 @@ class Backward:
         scale = 1.0 / math.sqrt(dh)
         ctx = ws.get("lt.ctx", (nh, M, H), st, dev)
         Pm = ws.get("lt.P", (B * nh * To, Lp), torch.float16, dev)
+        if os.environ.get("TCAVT_PY_TLAYERS", "0") != "1":  # one C call: tcavt_cross_attn_backward (csrc/tlayers.hip)
+            from . import capi
+            f = capi.CrossAttnArgs()
+            fwd = dict(q=q, fh=self._fh_b, scores=ws.get("lt.S", (B * nh * To, Lp), torch.float32, dev), probs=Pm, ctx=ctx)
+            for k_, t_ in fwd.items():
+                setattr(f, k_, t_.data_ptr())
+            f.B, f.To, f.L, f.Lp, f.H, f.nhead, f.dtype16 = B, To, L, Lp, H, nh, capi.F16
+            xsp = getattr(m, "drop_xattn", None)
+            if xsp is not None:
+                f.dropout_p, f.dropout_seed, f.dropout_site = xsp[0], xsp[1] & 0xFFFFFFFFFFFFFFFF, xsp[2]
+            a = capi.CrossAttnBwdArgs()
+            a.fwd = ctypes.pointer(f)
+            g_q = self._buf("xa.g_q", (M, H), bf)
+            bufs = dict(g_att=g_att, w_in=ca.in_proj_weight.detach(), gw_in=gWin, gb_in=gbin, g_q=g_q,
+                        fh_tb=self._buf("xa.fhTb", (H, B * Lp), bf), fh_b=self._buf("xa.fhb", (B * Lp, H), bf),
+                        ga_t=self._buf("xa.gaT2", (H, Mp), bf), g_ctx=self._buf("xa.g_ctx", (nh, M, H), bf),
+                        w_t=self._buf("xa.w_t", (H * dh,), bf), x_t=self._buf("xa.x_t", (H, Mp), bf),
+                        d_p=self._buf("xa.dP", (B * nh * To, Lp)), d_s=self._buf("xa.dS", (B * nh * To, Lp), bf),
+                        g_qp=self._buf("xa.g_qp", (nh, M, H), bf))
+            if xsp is not None:
+                bufs["p_undropped"] = self._buf("xa.Pu", (B * nh * To, Lp), torch.float16)
+            for k_, t_ in bufs.items():
+                setattr(a, k_, t_.data_ptr())
+            ops.cross_attn_backward(a)
+            del fwd, bufs
+            return g_q
         # bf16 copies of the hidden states for the gradient-side contractions: per-sample transposed [H][B*Lp] (converted
         # while transposing, keys padded to Lp with zeros) and, transposed back, row-major [B*Lp][H]
         fhTb = self._buf("xa.fhTb", (H, B * Lp), bf)

@@ -97,6 +97,13 @@ class CrossAttnArgs(ctypes.Structure):
         ("dropout_seed", ctypes.c_uint64)]
 
 
+class CrossAttnBwdArgs(ctypes.Structure):
+    """Mirror of ``tcavt_cross_attn_bwd_args`` (include/tcavt.h)."""
+
+    _fields_ = [("fwd", ctypes.POINTER(CrossAttnArgs))] + [(n, c_void_p) for n in (
+        "g_att", "w_in", "gw_in", "gb_in", "g_q", "fh_tb", "fh_b", "ga_t", "g_ctx", "w_t", "x_t", "d_p", "d_s", "g_qp", "p_undropped")]
+
+
 class LtsfArgs(ctypes.Structure):
     """Mirror of ``tcavt_ltsf_args`` (include/tcavt.h)."""
 
@@ -227,6 +234,7 @@ _SIGNATURES = {
     "tcavt_tlayer_stack_forward": [ctypes.POINTER(TStackArgs), c_void_p],
     "tcavt_cross_attn_forward": [ctypes.POINTER(CrossAttnArgs), c_void_p],
     "tcavt_ltsf_forward": [ctypes.POINTER(LtsfArgs), c_int, c_void_p],
+    "tcavt_cross_attn_backward": [ctypes.POINTER(CrossAttnBwdArgs), c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

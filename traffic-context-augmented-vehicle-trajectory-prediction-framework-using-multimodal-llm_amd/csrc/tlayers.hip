@@ -247,3 +247,82 @@ extern "C" int tcavt_ltsf_forward(const tcavt_ltsf_args* a, int phase, tcavt_str
   }
   return TCAVT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Backward of tcavt_cross_attn_forward (SURVEY.md 8b "cross_attn_backward"), the hidden states being a constant (frozen
+// MLLM): given g_att = dL/d att,
+//     gW_v[h] = g_att_h^T ctx_h      gb_v += colsum(g_att)      g_ctx_h = g_att_h W_v[h]
+//     g_P = g_ctx F^T                g_S = softmax'(P, g_P) (with the forward's attention-weight mask)      g_q' = g_S F
+//     gW_k[h] = q_h^T g_q'_h         gb_k = 0 (softmax-invariant)                                            g_q_h = g_q'_h W_k[h]^T
+// Gradient-side operands are bf16 (forward activations are converted while they are transposed), weight gradients fp32
+// straight into the caller's in_proj_weight gradient rows.  Every contraction runs over the B*To query rows.
+// ---------------------------------------------------------------------------
+extern "C" int tcavt_cross_attn_backward(const tcavt_cross_attn_bwd_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->fwd && a->g_att && a->w_in && a->gw_in && a->gb_in && a->g_q && a->fh_tb && a->fh_b && a->ga_t &&
+                      a->g_ctx && a->w_t && a->x_t && a->d_p && a->d_s && a->g_qp,
+                  "cross_attn_backward: null pointer");
+  const tcavt_cross_attn_args& f = *a->fwd;
+  const int B = f.B, To = f.To, L = f.L, Lp = f.Lp, H = f.H, nh = f.nhead, dh = H / nh, M = B * To, Mp = (M + 63) / 64 * 64;
+  TCAVT_CHECK_ARG(f.dtype16 == TCAVT_F16 && (f.dropout_p == 0.f || a->p_undropped), "cross_attn_backward: fp16 forward; train mode needs p_undropped");
+  const float scale = (float)(1.0 / sqrt((double)dh));
+  const int BF = TCAVT_BF16;
+  char* g_att = static_cast<char*>(const_cast<void*>(a->g_att));
+  char* g_ctx = static_cast<char*>(a->g_ctx);
+  char* g_qp = static_cast<char*>(a->g_qp);
+  char* g_q = static_cast<char*>(a->g_q);
+  char* ga_t = static_cast<char*>(a->ga_t);
+  const char* ctx = static_cast<const char*>(f.ctx);
+  const char* q = static_cast<const char*>(f.q);
+  auto gemm = [&](const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int out_dtype, int Mr, int N, int K) {
+    tcavt_gemm_args g = {};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = Mr; g.N = N; g.K = K; g.out_dtype = out_dtype; g.in_dtype = BF;
+    return tcavt_gemm_bf16(&g, stream);
+  };
+  // bf16 copies of the hidden states: per-sample transposed [H][B*Lp] (converted while transposing) and, transposed back, row-major
+  TCAVT_TRY(tcavt_transpose16(f.fh, H, a->fh_tb, (int64_t)B * Lp, L, H, Lp, B, (int64_t)L * H, Lp, 1, stream));
+  TCAVT_TRY(tcavt_transpose16(a->fh_tb, (int64_t)B * Lp, a->fh_b, H, H, B * Lp, H, 1, 0, 0, 0, stream));
+  // ---- value side
+  TCAVT_TRY(tcavt_colsum(a->g_att, H, BF, a->gb_in + 2 * H, M, H, 1, stream));
+  TCAVT_TRY(tcavt_transpose16(a->g_att, H, a->ga_t, Mp, M, H, Mp, 1, 0, 0, 0, stream));
+  for (int h = 0; h < nh; ++h) {
+    const float* Wv_h = a->w_in + (size_t)(2 * H + h * dh) * H;
+    TCAVT_TRY(tcavt_transpose_f32_bf16(Wv_h, H, a->w_t, dh, dh, H, dh, stream));                         // W_v[h]^T  [H][dh]
+    TCAVT_TRY(gemm(g_att + (size_t)h * dh * 2, H, a->w_t, dh, g_ctx + (size_t)h * M * H * 2, H, BF, M, H, dh));
+    TCAVT_TRY(tcavt_transpose16(ctx + (size_t)h * M * H * 2, H, a->x_t, Mp, M, H, Mp, 1, 0, 0, 1, stream));  // ctx_h^T  [H][Mp]
+    TCAVT_TRY(gemm(ga_t + (size_t)h * dh * Mp * 2, Mp, a->x_t, Mp, a->gw_in + (size_t)(2 * H + h * dh) * H, H, TCAVT_F32, dh, H, Mp));
+  }
+  // ---- scores
+  {
+    tcavt_gemm_args g = {};
+    g.A = a->g_ctx; g.lda = H; g.W = a->fh_b; g.ldw = H; g.C = a->d_p; g.ldc = Lp; g.M = To; g.N = Lp; g.K = H;
+    g.out_dtype = TCAVT_F32; g.in_dtype = BF; g.tile = 64; g.batch = B * nh; g.batch_inner = nh;
+    g.sAo = (int64_t)To * H; g.sAi = (int64_t)M * H; g.sWo = (int64_t)Lp * H; g.sWi = 0;
+    g.sCo = (int64_t)nh * To * Lp; g.sCi = (int64_t)To * Lp;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  const void* p_used = f.probs;
+  if (f.dropout_p > 0.f) {  // the softmax backward needs the un-dropped probabilities and the masked dP
+    TCAVT_TRY(tcavt_dropout(a->d_p, a->d_p, (int64_t)B * nh * To * Lp, TCAVT_F32, f.dropout_p, f.dropout_seed, f.dropout_site, nullptr, stream));
+    TCAVT_TRY(tcavt_softmax_rows(f.scores, Lp, a->p_undropped, Lp, TCAVT_F16, B * nh * To, L, Lp, 0.f, 0, 0, stream));
+    p_used = a->p_undropped;
+  }
+  TCAVT_TRY(tcavt_softmax_bwd_rows(p_used, Lp, a->d_p, Lp, a->d_s, Lp, scale, B * nh * To, L, Lp, stream));
+  // ---- query side
+  {
+    tcavt_gemm_args g = {};
+    g.A = a->d_s; g.lda = Lp; g.W = a->fh_tb; g.ldw = (int64_t)B * Lp; g.C = a->g_qp; g.ldc = H; g.M = To; g.N = H; g.K = Lp;
+    g.out_dtype = BF; g.in_dtype = BF; g.tile = 64; g.batch = B * nh; g.batch_inner = nh;
+    g.sAo = (int64_t)nh * To * Lp; g.sAi = (int64_t)To * Lp; g.sWo = Lp; g.sWi = 0;
+    g.sCo = (int64_t)To * H; g.sCi = (int64_t)M * H;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+  }
+  for (int h = 0; h < nh; ++h) {
+    const float* Wk_h = a->w_in + (size_t)(H + h * dh) * H;
+    TCAVT_TRY(tcavt_cast_f32_16(Wk_h, a->w_t, (int64_t)dh * H, BF, stream));                              // W_k[h] bf16 [dh][H]
+    TCAVT_TRY(gemm(g_qp + (size_t)h * M * H * 2, H, a->w_t, H, g_q + (size_t)h * dh * 2, H, BF, M, dh, H));
+    TCAVT_TRY(tcavt_transpose16(q + (size_t)h * dh * 2, H, a->ga_t, Mp, M, dh, Mp, 1, 0, 0, 1, stream));     // q_h^T [dh][Mp] (ga_t is free now)
+    TCAVT_TRY(tcavt_transpose16(g_qp + (size_t)h * M * H * 2, H, a->x_t, Mp, M, H, Mp, 1, 0, 0, 0, stream)); // g_q'_h^T [H][Mp]
+    TCAVT_TRY(gemm(a->ga_t, Mp, a->x_t, Mp, a->gw_in + (size_t)(H + h * dh) * H, H, TCAVT_F32, dh, H, Mp));
+  }
+  return TCAVT_OK;
+}

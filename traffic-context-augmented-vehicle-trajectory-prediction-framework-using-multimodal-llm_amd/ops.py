@@ -810,6 +810,11 @@ def cross_attn_forward(args):
     check(lib().tcavt_cross_attn_forward(ctypes.byref(args), stream_ptr()), "tcavt_cross_attn_forward")
 
 
+def cross_attn_backward(args):
+    """args: capi.CrossAttnBwdArgs filled by backward.Backward._xattn_absorbed."""
+    check(lib().tcavt_cross_attn_backward(ctypes.byref(args), stream_ptr()), "tcavt_cross_attn_backward")
+
+
 def ltsf_forward(args, phase):
     """args: capi.LtsfArgs filled by model.TransformerLTSF (which owns and sizes every buffer); phase 1 / 2 / 3."""
     check(lib().tcavt_ltsf_forward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_forward")
