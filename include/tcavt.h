@@ -680,6 +680,49 @@ typedef struct tcavt_ltsf_args {
 
 int tcavt_ltsf_forward(const tcavt_ltsf_args* args, int phase, tcavt_stream_t stream);
 
+/* Backward of tcavt_ltsf_forward (SURVEY.md 8b "ltsf_backward"; what autograd does for TransformerLTSF in the training step of
+ * scripts/train.py:1168-1183), one call per phase:
+ *   1 = the head, from dL/d out down to the lane-polygon embedding's gradient g_poly (output head, fusion layer, dec_unproj,
+ *       cross-attention out_proj, tcavt_cross_attn_backward, q projection, dec_proj, transpose, post-MLP, lane_fc) -- after
+ *       it the caller may start the lane-polygon encoder's backward on another stream;
+ *   2 = the rest: N-Linear decoder, SelfAttentionBlock, N-Linear encoder, positional term, token projection;
+ *   3 = both.
+ * `fwd` carries the pointers of BOTH forward phases (activations as the forward left them, the forward's weights, shapes and
+ * dropout sites).  Parameter gradients are fp32 and must be zeroed by the caller (most are ADDED to); the per-channel
+ * nn.Linear gradients of the two N-Linear blocks are written with a stride between channels, so that they can live inside a
+ * flat gradient buffer in parameter order (weight, bias, weight, bias, ...).  Gradient-side 16-bit tensors are bf16. */
+typedef struct tcavt_ltsf_bwd_args {
+  const tcavt_ltsf_args* fwd;
+  tcavt_cross_attn_bwd_args xattn; /* .fwd = &fwd->xattn; .g_att / .g_q are this stage's buffers; .w_in / .gw_in / .gb_in: the packed in_proj */
+  const float* g_out;              /* [B][F][To]: dL/d out */
+  const float *w_un, *w_co, *w_dp; /* fp32 master weights of the head's 16-bit projections: [C][H], [H][H], [H][C] */
+  /* ---- parameter gradients */
+  float *g_out_w, *g_out_b, *g_fl3_w, *g_fl3_b, *g_fl1_w, *g_fl1_b, *g_fl_n_w, *g_fl_n_b;
+  float *g_un_w, *g_un_b, *g_co_w, *g_co_b, *g_dp_w, *g_dp_b;
+  float *g_pm3_w, *g_pm3_b, *g_pm0_w, *g_pm0_b, *g_lane_w, *g_lane_b;
+  float *g_dec_w, *g_dec_b;        /* decoder_linears.c.{weight [To][T], bias [To]} of channel c at + c * dec_stride */
+  float *g_sa_n1_w, *g_sa_n1_b, *g_sa_in_w, *g_sa_in_b, *g_sa_out_w, *g_sa_out_b, *g_sa_n2_w, *g_sa_n2_b, *g_sa_f0_w, *g_sa_f0_b,
+      *g_sa_f3_w, *g_sa_f3_b;
+  float *g_enc_w, *g_enc_b;        /* encoder_linears.c.{weight [T][T], bias [T]} of channel c at + c * enc_stride */
+  float* g_pos;                    /* pos_encoding gradient [C][pos_ld]; columns 0..T-1 are written */
+  float *g_conv_w, *g_conv_b;      /* token_proj [C][F], [C] */
+  /* ---- output */
+  float* g_poly;                   /* [B][poly_dim]: dL/d lane-polygon embedding */
+  /* ---- gradient workspaces (Mo = B*To, Mt = B*T, Mp = Mo rounded up to 64) */
+  float *g_f2, *g_f1, *g_fn, *g_dec_t, *g_dt2; /* [Mo][C] each */
+  void *g_cross, *g_proj;          /* bf16 [Mo][H] */
+  float *g_d1, *g_hid, *g_d0;      /* [B][C*To], [B][post_hidden], [B][C*To] (g_hid / g_d0: with the post-MLP only) */
+  float *g_dw, *g_db, *g_e;        /* [C][To][T], [C][To], [Mt][C] */
+  float *g_e_d, *g_res1_d;         /* [Mt][C] each: masked copies (train mode only) */
+  float *g_ff, *g_rn, *g_res1, *g_att_sa, *g_qkv, *g_xn, *g_tok; /* [Mt][4C], [Mt][C] x3, [Mt][3C], [Mt][C] x2 */
+  float *g_ew, *g_eb, *g_xp;       /* [C][T][T], [C][T], [Mt][C] */
+  void *s_gyb, *s_gyt, *s_xt, *s_wt; /* bf16 scratch of the 16-bit linear backwards: [Mo][H], [H][Mp], [H][Mp], [H][H] */
+  int64_t dec_stride, enc_stride;
+  int32_t pos_ld, reserved0;
+} tcavt_ltsf_bwd_args;
+
+int tcavt_ltsf_backward(const tcavt_ltsf_bwd_args* args, int phase, tcavt_stream_t stream);
+
 /* SUM all-reduce, in place, of a flat fp32 buffer on the caller's RCCL communicator (`nccl_comm` is an ncclComm_t) and
  * stream: one gradient bucket of the data-parallel step (the DistributedDataParallel wrap of scripts/train.py:1127 does
  * this during backward; tcavt_amd.training.Trainer issues the same exchange through torch.distributed).  The mean is taken

@@ -48,7 +48,8 @@ def _struct_fields(name):
                                           ("tcavt_sample_params", "SampleParams"), ("tcavt_decode_args", "DecodeArgs"),
                                           ("tcavt_tlayer", "TLayer"), ("tcavt_tstack_args", "TStackArgs"),
                                           ("tcavt_cross_attn_args", "CrossAttnArgs"), ("tcavt_ltsf_args", "LtsfArgs"),
-                                          ("tcavt_cross_attn_bwd_args", "CrossAttnBwdArgs")])
+                                          ("tcavt_cross_attn_bwd_args", "CrossAttnBwdArgs"),
+                                          ("tcavt_ltsf_bwd_args", "LtsfBwdArgs")])
 def test_struct_mirrors_match_header_layout(cname, mirror, tmp_path):
     """Field order of each ctypes mirror follows the C struct, and -- compiled with the host C compiler against the real
     header -- so do sizeof and every field offset."""

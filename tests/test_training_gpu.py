@@ -550,3 +550,42 @@ def test_cross_attn_backward_stage_matches_python_composition(gpu, train, monkey
         assert rel_err(ga[k].cpu(), gb[k].cpu()) < 1e-4, k
     H = ga["ltsf.decoder.cross_attn.in_proj_bias"].numel() // 3
     assert ga["ltsf.decoder.cross_attn.in_proj_bias"][H:2 * H].abs().max().item() == 0.0  # key bias: softmax-invariant
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_ltsf_backward_stage_matches_python_composition(gpu, train, monkeypatch):
+    """tcavt_ltsf_backward (SURVEY 8b ltsf_backward: one C call per phase, single stream) against the per-launch Python
+    composition on leaf streams (TCAVT_PY_TLAYERS=1): every gradient of the trainable set, the lane-polygon encoder's
+    included (it consumes the stage's g_poly)."""
+    from tcavt_amd import backward, model, training
+
+    dev = gpu["device"]
+    cfg, weights, fx = load_case("tiny_6_12_lora_ragged")
+    t = batch_tensors(fx)
+    g = {k: v.to(dev) for k, v in t.items()}
+    args = (g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
+            g["input_ids"], g["attention_mask"], g["labels"])
+    used = []
+    orig = backward.Backward._ltsf_stage
+    monkeypatch.setattr(backward.Backward, "_ltsf_stage", lambda self, *a, **k: (used.append(1), orig(self, *a, **k))[1])
+
+    def run(py):
+        if py:
+            monkeypatch.setenv("TCAVT_PY_TLAYERS", "1")
+        else:
+            monkeypatch.delenv("TCAVT_PY_TLAYERS", raising=False)
+        m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev)
+        m.train(train)
+        m._fwd_count = 0
+        tr = training.Trainer(m, lr=1e-4)
+        tr.forward_backward(*args)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in tr.book.g.items()}
+
+    ga = run(False)
+    assert used == [1]  # the stage ran
+    gb = run(True)
+    assert used == [1]  # ... and the Python composition did not go through it
+    assert len(ga) > 40
+    for k in ga:  # same kernels on the same operands; the atomically accumulated reductions (LayerNorm / bias sums) differ in order
+        assert rel_err(ga[k].cpu(), gb[k].cpu()) < 1e-4, k

@@ -179,6 +179,8 @@ class Backward:
         H = dec.cross_dim
         nh = dec.cross_nhead
         dh = H // nh
+        if self._ltsf_stage_specs() is not None:  # one C call per phase: tcavt_ltsf_backward (csrc/tlayers.hip)
+            return self._ltsf_stage(g_out, x_in, on_poly_grad)
         fwd = lambda name, shape, dt=torch.float32: ws.get("lt." + name, shape, dt, dev)
         st = m.storage  # 16-bit type of the forward's activations (fp16 by default); gradient-side tensors are bf16, and
         # a forward activation that enters a gradient-side contraction is converted while it is transposed (ops.transpose16)
@@ -278,6 +280,138 @@ class Backward:
         with self._leaf():
             gpos.view(C, -1)[:, :T].copy_(g_eb)
         ops.conv1x1_bwd(g_xp, x_in, G[pl + "token_proj.weight"].view(C, F), G[pl + "token_proj.bias"], B, C, T, F)
+        return g_poly
+
+    def _ltsf_stage_specs(self):
+        """(p, seed, first_site) of the forward's dropout sites when tcavt_ltsf_backward covers this backward: the default
+        form (fp16 storage, absorbed cross-attention, C++ stage forward) with the sites numbered as the stage numbers them
+        (self-attention block first_site .. + 3, post-MLP + 4); None -> the Python composition below."""
+        m = self.m.ltsf
+        if not (m._absorbed and m._stage_ok(self.book.grads.device)):
+            return None
+        sp = getattr(m.attn_block, "drop_specs", None) or [None] * 4
+        post = getattr(m, "drop_post", None) if m.decoder.use_post_mlp else None
+        xs = getattr(m, "drop_xattn", None)
+        if all(s is None for s in sp) and post is None and xs is None:
+            return (0.0, 0, 0)
+        if any(s is None for s in sp) or xs is None or (m.decoder.use_post_mlp and post is None):
+            return None
+        p, seed, s0 = sp[0]
+        sites = [s[2] for s in sp] + ([post[2]] if post is not None else [])
+        same = all(s[0] == p and s[1] == seed for s in sp + ([post] if post is not None else []))
+        if not same or sites != list(range(s0, s0 + len(sites))):
+            return None
+        return (p, seed, s0)
+
+    def _ltsf_stage(self, g_out, x_in, on_poly_grad):
+        """Backward.ltsf as tcavt_ltsf_backward: phase 1 (head .. g_poly), the lane-polygon hand-off, phase 2 (the rest);
+        the same kernels on the same named buffers as the composition in ltsf()/_sab()/_xattn_absorbed(), on one stream."""
+        from . import capi
+
+        m, G, ws = self.m.ltsf, self.book.g, self.m.ltsf._ws
+        dec, sab, pl = m.decoder, m.attn_block, self.pl
+        B, F, T = x_in.shape
+        C, To, dev = m.d_model, m.out_len, g_out.device
+        Mo, Mt, H, nh = B * To, B * T, dec.cross_dim, dec.cross_nhead
+        dh, L = H // nh, self._L
+        Lp, Mp = _rup(L, XATTN_PAD), _rup(Mo, 64)
+        f32, bf, st = torch.float32, torch.bfloat16, m.storage
+        p, seed, s0 = self._ltsf_stage_specs()
+        P = m._prepared()
+        fl, ca = dec.fusion_layer, dec.cross_attn
+        post = dec.post_mlp[0].weight.shape[0] if dec.use_post_mlp else 0
+        keep = []
+
+        def put(obj, **kw):
+            for k_, t_ in kw.items():
+                if t_ is not None:
+                    setattr(obj, k_, t_.data_ptr())
+                    keep.append(t_)
+
+        lt = lambda n, shape, dt=f32: ws.get("lt." + n, shape, dt, dev)
+        sa = lambda n, shape: sab._ws.get("sab." + n, shape, f32, dev)
+        # ---- the forward's arguments (both phases): activations by their workspace names, weights as the forward used them
+        f = capi.LtsfArgs()
+        put(f, x=x_in, enc_w=P.enc_w, tok=lt("tok", (Mt, C)), xp_tok=lt("xp", (Mt, C)),
+            sa_n1_w=sab.norm1.weight, sa_in_w=sab.mha.in_proj_weight, sa_out_w=sab.mha.out_proj.weight, sa_n2_w=sab.norm2.weight,
+            sa_f0_w=sab.ffn[0].weight, sa_f3_w=sab.ffn[3].weight,
+            sa_xn=sa("xn", (Mt, C)), sa_qkv=sa("qkv", (Mt, 3 * C)), sa_att=sa("att", (Mt, C)), sa_res1=sa("res1", (Mt, C)),
+            sa_rn=sa("rn", (Mt, C)), sa_f=sa("f", (Mt, 4 * C)), e=sa("out", (Mt, C)),
+            poly_emb=self._poly_emb.contiguous(), lane_w=dec.lane_fc.weight, dec_w=P.dec_w, d0=lt("dec0", (B, C * To)),
+            dec_tb=lt("dectb", (Mo, C), st), proj=lt("proj", (Mo, H), st), cross=lt("cross", (Mo, H), st),
+            fused=lt("fused", (Mo, C)), fl_n_w=fl[0].weight, fn=lt("fn", (Mo, C)), fl1_w=fl[1].weight, f1=lt("f1", (Mo, C)),
+            fl3_w=fl[3].weight, f2=lt("f2", (Mo, C)), out_w=dec.out_proj.weight)
+        if post:
+            put(f, pm0_w=dec.post_mlp[0].weight, pm3_w=dec.post_mlp[3].weight, hid=lt("hid", (B, post)))
+        put(f.xattn, q=lt("q", (Mo, H), st), fh=self._fh_b, scores=lt("S", (B * nh * To, Lp)),
+            probs=lt("P", (B * nh * To, Lp), torch.float16), ctx=lt("ctx", (nh, Mo, H), st), att=lt("att", (Mo, H), st))
+        fx = f.xattn
+        fx.B, fx.To, fx.L, fx.Lp, fx.H, fx.nhead, fx.dtype16 = B, To, L, Lp, H, nh, capi.F16
+        xsp = getattr(m, "drop_xattn", None)
+        if xsp is not None:
+            fx.dropout_p, fx.dropout_seed, fx.dropout_site = xsp[0], xsp[1] & 0xFFFFFFFFFFFFFFFF, xsp[2]
+        f.B, f.C, f.T, f.To, f.F, f.H, f.nhead_sa = B, C, T, To, F, H, sab.nhead
+        f.poly_dim, f.post_hidden = self._poly_emb.shape[1], post
+        f.dropout_p, f.dropout_seed, f.first_site = p, seed & 0xFFFFFFFFFFFFFFFF, s0
+        # ---- gradients, workspaces
+        a = capi.LtsfBwdArgs()
+        a.fwd = ctypes.pointer(f)
+        a.xattn.fwd = ctypes.cast(ctypes.addressof(f) + capi.LtsfArgs.xattn.offset, ctypes.POINTER(capi.CrossAttnArgs))
+        b = self._buf
+        g_q = b("xa.g_q", (Mo, H), bf)
+        put(a.xattn, g_att=b("g_att", (Mo, H), bf), w_in=ca.in_proj_weight.detach(), gw_in=G[pl + "decoder.cross_attn.in_proj_weight"],
+            gb_in=G[pl + "decoder.cross_attn.in_proj_bias"], g_q=g_q, fh_tb=b("xa.fhTb", (H, B * Lp), bf),
+            fh_b=b("xa.fhb", (B * Lp, H), bf), ga_t=b("xa.gaT2", (H, Mp), bf), g_ctx=b("xa.g_ctx", (nh, Mo, H), bf),
+            w_t=b("xa.w_t", (H * dh,), bf), x_t=b("xa.x_t", (H, Mp), bf), d_p=b("xa.dP", (B * nh * To, Lp)),
+            d_s=b("xa.dS", (B * nh * To, Lp), bf), g_qp=b("xa.g_qp", (nh, Mo, H), bf),
+            p_undropped=b("xa.Pu", (B * nh * To, Lp), torch.float16) if xsp is not None else None)
+        g = lambda n: G[pl + n]
+        g_poly = b("g_poly", tuple(self._poly_emb.shape))
+        put(a, g_out=g_out, w_un=dec.dec_unproj.weight, w_co=ca.out_proj.weight, w_dp=dec.dec_proj.weight,
+            g_out_w=g("decoder.out_proj.weight"), g_out_b=g("decoder.out_proj.bias"),
+            g_fl3_w=g("decoder.fusion_layer.3.weight"), g_fl3_b=g("decoder.fusion_layer.3.bias"),
+            g_fl1_w=g("decoder.fusion_layer.1.weight"), g_fl1_b=g("decoder.fusion_layer.1.bias"),
+            g_fl_n_w=g("decoder.fusion_layer.0.weight"), g_fl_n_b=g("decoder.fusion_layer.0.bias"),
+            g_un_w=g("decoder.dec_unproj.weight"), g_un_b=g("decoder.dec_unproj.bias"),
+            g_co_w=g("decoder.cross_attn.out_proj.weight"), g_co_b=g("decoder.cross_attn.out_proj.bias"),
+            g_dp_w=g("decoder.dec_proj.weight"), g_dp_b=g("decoder.dec_proj.bias"),
+            g_lane_w=g("decoder.lane_fc.weight"), g_lane_b=g("decoder.lane_fc.bias"),
+            g_sa_n1_w=g("attn_block.norm1.weight"), g_sa_n1_b=g("attn_block.norm1.bias"),
+            g_sa_in_w=g("attn_block.mha.in_proj_weight"), g_sa_in_b=g("attn_block.mha.in_proj_bias"),
+            g_sa_out_w=g("attn_block.mha.out_proj.weight"), g_sa_out_b=g("attn_block.mha.out_proj.bias"),
+            g_sa_n2_w=g("attn_block.norm2.weight"), g_sa_n2_b=g("attn_block.norm2.bias"),
+            g_sa_f0_w=g("attn_block.ffn.0.weight"), g_sa_f0_b=g("attn_block.ffn.0.bias"),
+            g_sa_f3_w=g("attn_block.ffn.3.weight"), g_sa_f3_b=g("attn_block.ffn.3.bias"),
+            g_pos=g("pos_encoding"), g_conv_w=g("token_proj.weight"), g_conv_b=g("token_proj.bias"), g_poly=g_poly,
+            g_f2=b("g_f2", (Mo, C)), g_f1=b("g_f1", (Mo, C)), g_fn=b("g_fn", (Mo, C)), g_dec_t=b("g_dec_t", (Mo, C)),
+            g_dt2=b("g_dt2", (Mo, C)), g_cross=b("g_cross", (Mo, H), bf), g_proj=b("g_proj", (Mo, H), bf),
+            g_d1=b("g_d1", (B, C * To)), g_dw=b("g_dw", (C, To, T)), g_db=b("g_db", (C, To)), g_e=b("g_e", (Mt, C)),
+            g_ff=b("sab.g_ff", (Mt, 4 * C)), g_rn=b("sab.g_rn", (Mt, C)), g_res1=b("sab.g_res1", (Mt, C)),
+            g_att_sa=b("sab.g_att", (Mt, C)), g_qkv=b("sab.g_qkv", (Mt, 3 * C)), g_xn=b("sab.g_xn", (Mt, C)),
+            g_tok=b("sab.g_tok", (Mt, C)), g_ew=b("g_ew", (C, T, T)), g_eb=b("g_eb", (C, T)), g_xp=b("g_xp", (Mt, C)),
+            s_gyb=b("st.gyb", (Mo, H), bf), s_gyt=b("st.gyT", (H, Mp), bf), s_xt=b("st.xT", (H, Mp), bf),
+            s_wt=b("st.WT", (H, H), bf))
+        if post:
+            put(a, g_pm3_w=g("decoder.post_mlp.3.weight"), g_pm3_b=g("decoder.post_mlp.3.bias"),
+                g_pm0_w=g("decoder.post_mlp.0.weight"), g_pm0_b=g("decoder.post_mlp.0.bias"),
+                g_hid=b("g_hid", (B, post)), g_d0=b("g_d0", (B, C * To)))
+        if p > 0.0:
+            put(a, g_e_d=b("sab.g_e_d", (Mt, C)), g_res1_d=b("sab.g_res1_d", (Mt, C)))
+        # per-channel nn.Linear gradients of the N-Linear blocks: contiguous in the flat book in channel order (weight, bias, ...)
+        flat, off = self.book.grads, self.book.offsets
+        for name, prefix in (("dec", pl + "decoder.decoder_linears."), ("enc", pl + "nlinear_encoder.encoder_linears.")):
+            o0, ob = off[prefix + "0.weight"][0], off[prefix + "0.bias"][0]
+            setattr(a, f"g_{name}_w", flat.data_ptr() + 4 * o0)
+            setattr(a, f"g_{name}_b", flat.data_ptr() + 4 * ob)
+            setattr(a, f"{name}_stride", off[prefix + "1.weight"][0] - o0 if C > 1 else 0)
+        a.pos_ld = G[pl + "pos_encoding"].shape[-1]
+        if on_poly_grad is None:
+            ops.ltsf_backward(a, 3)
+        else:
+            ops.ltsf_backward(a, 1)
+            on_poly_grad(g_poly)  # the lane-polygon encoder's backward can start here, beside the rest of this one
+            ops.ltsf_backward(a, 2)
+        del keep
         return g_poly
 
     def _scatter_channels(self, gW, gb, prefix, C):

@@ -112,6 +112,22 @@ class LtsfArgs(ctypes.Structure):
         ("dropout_p", ctypes.c_float), ("first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64)]
 
 
+class LtsfBwdArgs(ctypes.Structure):
+    """Mirror of ``tcavt_ltsf_bwd_args`` (include/tcavt.h)."""
+
+    _fields_ = [("fwd", ctypes.POINTER(LtsfArgs)), ("xattn", CrossAttnBwdArgs)] + [(n, c_void_p) for n in (
+        "g_out", "w_un", "w_co", "w_dp",
+        "g_out_w", "g_out_b", "g_fl3_w", "g_fl3_b", "g_fl1_w", "g_fl1_b", "g_fl_n_w", "g_fl_n_b",
+        "g_un_w", "g_un_b", "g_co_w", "g_co_b", "g_dp_w", "g_dp_b",
+        "g_pm3_w", "g_pm3_b", "g_pm0_w", "g_pm0_b", "g_lane_w", "g_lane_b", "g_dec_w", "g_dec_b",
+        "g_sa_n1_w", "g_sa_n1_b", "g_sa_in_w", "g_sa_in_b", "g_sa_out_w", "g_sa_out_b", "g_sa_n2_w", "g_sa_n2_b", "g_sa_f0_w",
+        "g_sa_f0_b", "g_sa_f3_w", "g_sa_f3_b", "g_enc_w", "g_enc_b", "g_pos", "g_conv_w", "g_conv_b", "g_poly",
+        "g_f2", "g_f1", "g_fn", "g_dec_t", "g_dt2", "g_cross", "g_proj", "g_d1", "g_hid", "g_d0", "g_dw", "g_db", "g_e",
+        "g_e_d", "g_res1_d", "g_ff", "g_rn", "g_res1", "g_att_sa", "g_qkv", "g_xn", "g_tok", "g_ew", "g_eb", "g_xp",
+        "s_gyb", "s_gyt", "s_xt", "s_wt")] + [("dec_stride", c_int64), ("enc_stride", c_int64), ("pos_ld", ctypes.c_int32),
+                                              ("reserved0", ctypes.c_int32)]
+
+
 class LlamaStackArgs(ctypes.Structure):
     """Mirror of ``tcavt_llama_stack_args`` (include/tcavt.h)."""
 
@@ -235,6 +251,7 @@ _SIGNATURES = {
     "tcavt_cross_attn_forward": [ctypes.POINTER(CrossAttnArgs), c_void_p],
     "tcavt_ltsf_forward": [ctypes.POINTER(LtsfArgs), c_int, c_void_p],
     "tcavt_cross_attn_backward": [ctypes.POINTER(CrossAttnBwdArgs), c_void_p],
+    "tcavt_ltsf_backward": [ctypes.POINTER(LtsfBwdArgs), c_int, c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

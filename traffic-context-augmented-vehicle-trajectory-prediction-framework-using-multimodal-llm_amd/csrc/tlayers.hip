@@ -326,3 +326,165 @@ extern "C" int tcavt_cross_attn_backward(const tcavt_cross_attn_bwd_args* a, tca
   }
   return TCAVT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Backward of tcavt_ltsf_forward (SURVEY.md 8b "ltsf_backward"): what autograd does for TransformerLTSF in the training step
+// (scripts/train.py:1168-1183; the module: :808-842), as the launch sequence tcavt_amd.backward.Backward.ltsf issues from
+// Python -- same kernels, same operands, so the gradients are bit-identical; here everything runs on the caller's one
+// stream, the Python composition moves the weight-gradient leaves to side streams.
+//   fp32 nn.Linear y = x W^T + b:   gW += gy^T x   gb += colsum(gy)   gx = gy W                       (strided fp32 GEMMs)
+//   16-bit projection (MFMA):       gW = gy16^T x16 over transposed bf16 copies, gb += colsum(gy), gx = gy16 W16
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, long ld_src, float* __restrict__ dst,
+                                                        long ld_dst, int width) {
+  const float* s = src + (long)blockIdx.x * ld_src;
+  float* d = dst + (long)blockIdx.x * ld_dst;
+  for (int i = threadIdx.x; i < width; i += 256) d[i] = s[i];
+}
+
+int copy_rows(const float* src, long ld_src, float* dst, long ld_dst, int rows, int width, tcavt_stream_t stream) {
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld_src, dst, ld_dst, width);
+  TCAVT_CHECK_LAUNCH("ltsf_backward: copy_rows");
+  return TCAVT_OK;
+}
+}  // namespace
+
+extern "C" int tcavt_ltsf_backward(const tcavt_ltsf_bwd_args* a, int phase, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->fwd && (phase == 1 || phase == 2 || phase == 3), "ltsf_backward: phase must be 1 (head), 2 (front) or 3 (both)");
+  const tcavt_ltsf_args& f = *a->fwd;
+  TCAVT_CHECK_ARG(f.B > 0 && f.C > 0 && f.T > 0 && f.To > 0 && f.F > 0 && f.H > 0 && f.nhead_sa > 0 && f.C % f.nhead_sa == 0 &&
+                      f.poly_dim > 0,
+                  "ltsf_backward: bad shape");
+  TCAVT_CHECK_ARG(f.dropout_p >= 0.f && f.dropout_p < 1.f, "ltsf_backward: dropout_p must be in [0, 1)");
+  const int B = f.B, C = f.C, T = f.T, To = f.To, H = f.H, Mo = B * To, Mt = B * T, CT = C * To, Mp = (Mo + 63) / 64 * 64;
+  const float p = f.dropout_p;
+  const uint64_t seed = f.dropout_seed;
+  const uint32_t s0 = f.first_site;
+  const int BF = TCAVT_BF16;
+  // fp32 nn.Linear backward: x [M][K], W [N][K], gy [M][N]
+  auto lin32 = [&](const float* x, const float* W, const float* gy, float* gW, float* gb, float* gx, int M, int N, int K) -> int {
+    TCAVT_TRY(tcavt_gemm_f32_strided(gy, 1, N, x, 1, K, nullptr, nullptr, 0, gW, K, N, K, M, TCAVT_EPI_ACCUM, stream));
+    TCAVT_TRY(tcavt_colsum(gy, N, TCAVT_F32, gb, M, N, 1, stream));
+    if (gx) TCAVT_TRY(tcavt_gemm_f32_strided(gy, N, 1, W, 1, K, nullptr, nullptr, 0, gx, K, M, K, N, 0, stream));
+    return TCAVT_OK;
+  };
+  // 16-bit projection backward over the Mo decoder-token rows: x16 fp16 [Mo][K] (forward activation), W fp32 [N][K],
+  // gy [Mo][N] fp32 or bf16, gx [Mo][K] of gx_dtype
+  auto lin16 = [&](const void* x16, const float* W, const void* gy, int gy_dtype, float* gW, float* gb, void* gx, int gx_dtype,
+                   int N, int K) -> int {
+    const void* gyb = gy;
+    if (gy_dtype == TCAVT_F32) {
+      TCAVT_TRY(tcavt_cast_f32_16(static_cast<const float*>(gy), a->s_gyb, (int64_t)Mo * N, BF, stream));
+      gyb = a->s_gyb;
+    }
+    TCAVT_TRY(tcavt_transpose16(gyb, N, a->s_gyt, Mp, Mo, N, Mp, 1, 0, 0, 0, stream));
+    TCAVT_TRY(tcavt_transpose16(x16, K, a->s_xt, Mp, Mo, K, Mp, 1, 0, 0, 1, stream));
+    tcavt_gemm_args g = {};
+    g.A = a->s_gyt; g.lda = Mp; g.W = a->s_xt; g.ldw = Mp; g.C = gW; g.ldc = K; g.M = N; g.N = K; g.K = Mp;
+    g.out_dtype = TCAVT_F32; g.in_dtype = BF;
+    TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    TCAVT_TRY(tcavt_colsum(gy, N, gy_dtype, gb, Mo, N, 1, stream));
+    TCAVT_TRY(tcavt_transpose_f32_bf16(W, K, a->s_wt, N, N, K, N, stream));
+    tcavt_gemm_args d = {};
+    d.A = gyb; d.lda = N; d.W = a->s_wt; d.ldw = N; d.C = gx; d.ldc = K; d.M = Mo; d.N = K; d.K = N;
+    d.out_dtype = gx_dtype; d.in_dtype = BF;
+    return tcavt_gemm_bf16(&d, stream);
+  };
+  // gradient through a dropout site of the forward
+  auto drop = [&](const float* g, float* out, int64_t n, int site_off) -> int {
+    return tcavt_dropout(g, out, n, TCAVT_F32, p, seed, s0 + (uint32_t)site_off, nullptr, stream);
+  };
+
+  if (phase & 1) {
+    TCAVT_CHECK_ARG(a->g_out && f.f2 && f.f1 && f.fn && f.fused && f.cross && f.xattn.att && f.xattn.q && f.proj && f.dec_tb && f.d0 &&
+                        f.poly_emb && f.out_w && f.fl3_w && f.fl1_w && f.fl_n_w && f.lane_w && a->w_un && a->w_co && a->w_dp &&
+                        a->xattn.w_in && a->xattn.gw_in && a->xattn.gb_in && a->xattn.g_att && a->xattn.g_q,
+                    "ltsf_backward: phase 1: null forward pointer");
+    TCAVT_CHECK_ARG(a->g_out_w && a->g_out_b && a->g_fl3_w && a->g_fl3_b && a->g_fl1_w && a->g_fl1_b && a->g_fl_n_w && a->g_fl_n_b &&
+                        a->g_un_w && a->g_un_b && a->g_co_w && a->g_co_b && a->g_dp_w && a->g_dp_b && a->g_lane_w && a->g_lane_b &&
+                        a->g_poly && a->g_f2 && a->g_f1 && a->g_fn && a->g_dec_t && a->g_dt2 && a->g_cross && a->g_proj && a->g_d1 &&
+                        a->s_gyb && a->s_gyt && a->s_xt && a->s_wt,
+                    "ltsf_backward: phase 1: null gradient pointer / workspace");
+    TCAVT_CHECK_ARG(a->xattn.fwd == &f.xattn, "ltsf_backward: xattn.fwd must point at fwd->xattn");
+    // output head: out = f2 W_out^T + b (+ last position: no gradient needed)
+    TCAVT_TRY(tcavt_out_head_bwd(a->g_out, f.f2, f.out_w, a->g_f2, a->g_out_w, a->g_out_b, B, To, C, f.F, stream));
+    // fusion layer: LayerNorm -> Linear -> ReLU -> Linear
+    TCAVT_TRY(lin32(f.f1, f.fl3_w, a->g_f2, a->g_fl3_w, a->g_fl3_b, a->g_f1, Mo, C, C));
+    TCAVT_TRY(tcavt_relu_bwd(a->g_f1, f.f1, TCAVT_F32, (int64_t)Mo * C, stream));
+    TCAVT_TRY(lin32(f.fn, f.fl1_w, a->g_f1, a->g_fl1_w, a->g_fl1_b, a->g_fn, Mo, C, C));
+    TCAVT_TRY(tcavt_layernorm_bwd(f.fused, f.fl_n_w, a->g_fn, 1e-5f, a->g_dec_t, a->g_fl_n_w, a->g_fl_n_b, Mo, C, stream));
+    // fused = cross W_un^T + b_un + dec_t;  cross = att W_co^T + b_co
+    TCAVT_TRY(lin16(f.cross, a->w_un, a->g_dec_t, TCAVT_F32, a->g_un_w, a->g_un_b, a->g_cross, BF, C, H));
+    TCAVT_TRY(lin16(f.xattn.att, a->w_co, a->g_cross, BF, a->g_co_w, a->g_co_b, const_cast<void*>(a->xattn.g_att), BF, H, H));
+    // attention core (absorbed K / V projections), then the q projection (rows 0..H of the packed in_proj)
+    TCAVT_TRY(tcavt_cross_attn_backward(&a->xattn, stream));
+    TCAVT_TRY(lin16(f.proj, a->xattn.w_in, a->xattn.g_q, BF, a->xattn.gw_in, a->xattn.gb_in, a->g_proj, BF, H, H));
+    // proj = dec_t W_dp^T + b_dp; total gradient of dec_t; dec_t [B][To][C] -> d1 [B][C][To]
+    TCAVT_TRY(lin16(f.dec_tb, a->w_dp, a->g_proj, BF, a->g_dp_w, a->g_dp_b, a->g_dt2, TCAVT_F32, H, C));
+    TCAVT_TRY(tcavt_add_inplace(a->g_dt2, a->g_dec_t, (int64_t)Mo * C, stream));
+    TCAVT_TRY(tcavt_transpose_ct(a->g_dt2, a->g_d1, nullptr, B, To, C, BF, stream));
+    // post-MLP: d1 = drop(relu(d0 W0^T + b0)) W3^T + b3
+    const float* g_d0 = a->g_d1;
+    if (f.post_hidden > 0) {
+      TCAVT_CHECK_ARG(f.hid && f.pm0_w && f.pm3_w && a->g_hid && a->g_d0 && a->g_pm0_w && a->g_pm0_b && a->g_pm3_w && a->g_pm3_b,
+                      "ltsf_backward: post-MLP: null pointer");
+      TCAVT_TRY(lin32(f.hid, f.pm3_w, a->g_d1, a->g_pm3_w, a->g_pm3_b, a->g_hid, B, CT, f.post_hidden));
+      if (p > 0.f) TCAVT_TRY(drop(a->g_hid, a->g_hid, (int64_t)B * f.post_hidden, 4));
+      TCAVT_TRY(tcavt_relu_bwd(a->g_hid, f.hid, TCAVT_F32, (int64_t)B * f.post_hidden, stream));
+      TCAVT_TRY(lin32(f.d0, f.pm0_w, a->g_hid, a->g_pm0_w, a->g_pm0_b, a->g_d0, B, f.post_hidden, CT));
+      g_d0 = a->g_d0;
+    }
+    // d0 = NLinear_dec(e) + lane_fc(poly_emb)
+    TCAVT_TRY(lin32(f.poly_emb, f.lane_w, g_d0, a->g_lane_w, a->g_lane_b, a->g_poly, B, CT, f.poly_dim));
+  }
+  if (phase & 2) {
+    TCAVT_CHECK_ARG(f.e && f.dec_w && f.enc_w && f.tok && f.xp_tok && f.x && f.sa_xn && f.sa_qkv && f.sa_att && f.sa_res1 && f.sa_rn &&
+                        f.sa_f && f.sa_n1_w && f.sa_in_w && f.sa_out_w && f.sa_n2_w && f.sa_f0_w && f.sa_f3_w,
+                    "ltsf_backward: phase 2: null forward pointer (the forward must keep xp_tok)");
+    TCAVT_CHECK_ARG(a->g_dec_w && a->g_dec_b && a->g_enc_w && a->g_enc_b && a->g_pos && a->pos_ld >= T && a->g_conv_w && a->g_conv_b &&
+                        a->g_sa_n1_w && a->g_sa_n1_b && a->g_sa_in_w && a->g_sa_in_b && a->g_sa_out_w && a->g_sa_out_b && a->g_sa_n2_w &&
+                        a->g_sa_n2_b && a->g_sa_f0_w && a->g_sa_f0_b && a->g_sa_f3_w && a->g_sa_f3_b && a->g_dw && a->g_db && a->g_e &&
+                        a->g_ff && a->g_rn && a->g_res1 && a->g_att_sa && a->g_qkv && a->g_xn && a->g_tok && a->g_ew && a->g_eb &&
+                        a->g_xp && (p == 0.f || (a->g_e_d && a->g_res1_d)) && (f.post_hidden > 0 ? a->g_d0 != nullptr : a->g_d1 != nullptr),
+                    "ltsf_backward: phase 2: null gradient pointer / workspace");
+    const float* g_d0 = f.post_hidden > 0 ? a->g_d0 : a->g_d1;
+    // N-Linear decoder: stacked gradients, then one strided copy into the per-channel nn.Linear gradient views
+    TCAVT_TRY(tcavt_nlinear_bwd(f.e, f.dec_w, g_d0, CT, To, 1, a->g_dw, a->g_db, a->g_e, B, C, T, To, stream));
+    TCAVT_TRY(copy_rows(a->g_dw, (long)To * T, a->g_dec_w, a->dec_stride, C, To * T, stream));
+    TCAVT_TRY(copy_rows(a->g_db, To, a->g_dec_b, a->dec_stride, C, To, stream));
+    // SelfAttentionBlock (train.py:674-686): e = drop(ff W3^T + b3) + rn, ff = drop(relu(rn W0^T + b0)), rn = LN2(res1),
+    // res1 = drop(att Wo^T + bo) + xn, att = MHA(xn), xn = LN1(tok)
+    const float* g_e_d = a->g_e;
+    if (p > 0.f) {
+      TCAVT_TRY(drop(a->g_e, a->g_e_d, (int64_t)Mt * C, 3));
+      g_e_d = a->g_e_d;
+    }
+    TCAVT_TRY(lin32(f.sa_f, f.sa_f3_w, g_e_d, a->g_sa_f3_w, a->g_sa_f3_b, a->g_ff, Mt, C, 4 * C));
+    if (p > 0.f) TCAVT_TRY(drop(a->g_ff, a->g_ff, (int64_t)Mt * 4 * C, 2));
+    TCAVT_TRY(tcavt_relu_bwd(a->g_ff, f.sa_f, TCAVT_F32, (int64_t)Mt * 4 * C, stream));
+    TCAVT_TRY(lin32(f.sa_rn, f.sa_f0_w, a->g_ff, a->g_sa_f0_w, a->g_sa_f0_b, a->g_rn, Mt, 4 * C, C));
+    TCAVT_TRY(tcavt_add_inplace(a->g_rn, a->g_e, (int64_t)Mt * C, stream));
+    TCAVT_TRY(tcavt_layernorm_bwd(f.sa_res1, f.sa_n2_w, a->g_rn, 1e-5f, a->g_res1, a->g_sa_n2_w, a->g_sa_n2_b, Mt, C, stream));
+    const float* g_res1_d = a->g_res1;
+    if (p > 0.f) {
+      TCAVT_TRY(drop(a->g_res1, a->g_res1_d, (int64_t)Mt * C, 1));
+      g_res1_d = a->g_res1_d;
+    }
+    TCAVT_TRY(lin32(f.sa_att, f.sa_out_w, g_res1_d, a->g_sa_out_w, a->g_sa_out_b, a->g_att_sa, Mt, C, C));
+    const int dh = C / f.nhead_sa;
+    TCAVT_TRY(tcavt_mha_bwd(f.sa_qkv, 3 * C, f.sa_qkv + C, 3 * C, f.sa_qkv + 2 * C, 3 * C, a->g_att_sa, C, a->g_qkv, a->g_qkv + C,
+                            a->g_qkv + 2 * C, 3 * C, nullptr, B, T, T, f.nhead_sa, dh, (float)(1.0 / sqrt((double)dh)), p, seed,
+                            p > 0.f ? s0 : 0u, stream));
+    TCAVT_TRY(lin32(f.sa_xn, f.sa_in_w, a->g_qkv, a->g_sa_in_w, a->g_sa_in_b, a->g_xn, Mt, 3 * C, C));
+    TCAVT_TRY(tcavt_add_inplace(a->g_xn, a->g_res1, (int64_t)Mt * C, stream));
+    TCAVT_TRY(tcavt_layernorm_bwd(f.tok, f.sa_n1_w, a->g_xn, 1e-5f, a->g_tok, a->g_sa_n1_w, a->g_sa_n1_b, Mt, C, stream));
+    // front: tok = NLinear_enc(conv(x)) + pos
+    TCAVT_TRY(tcavt_nlinear_bwd(f.xp_tok, f.enc_w, a->g_tok, (int64_t)T * C, 1, C, a->g_ew, a->g_eb, a->g_xp, B, C, T, T, stream));
+    TCAVT_TRY(copy_rows(a->g_ew, (long)T * T, a->g_enc_w, a->enc_stride, C, T * T, stream));
+    TCAVT_TRY(copy_rows(a->g_eb, T, a->g_enc_b, a->enc_stride, C, T, stream));
+    TCAVT_TRY(copy_rows(a->g_eb, T, a->g_pos, a->pos_ld, C, T, stream));  // pos_encoding: the reduction of the encoder bias
+    TCAVT_TRY(tcavt_conv1x1_bwd(a->g_xp, f.x, a->g_conv_w, a->g_conv_b, B, C, T, f.F, stream));
+  }
+  return TCAVT_OK;
+}

@@ -820,6 +820,11 @@ def ltsf_forward(args, phase):
     check(lib().tcavt_ltsf_forward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_forward")
 
 
+def ltsf_backward(args, phase):
+    """args: capi.LtsfBwdArgs filled by backward.Backward._ltsf_stage; phase 1 (head .. g_poly) / 2 (the rest) / 3."""
+    check(lib().tcavt_ltsf_backward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_backward")
+
+
 def allreduce_flat(buf, nccl_comm):
     """In-place SUM all-reduce of a flat fp32 buffer on a raw RCCL communicator (an ncclComm_t as int / c_void_p) and the
     current stream: tcavt_allreduce_flat, the C host's form of the gradient-bucket exchange (Trainer itself goes through
