@@ -21,3 +21,11 @@ for sh in gateup down o; do
   done
   python3 $R/tools/pmc_parse.py $D > $O/pmc_$sh.json; echo "pmc $sh done"
 done
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lora-trainable --train-mllm-front > $O/bench_lora_full.json 2> $O/bench_lora_full.err; tail -1 $O/bench_lora_full.err
+# LoRA-trainable step under the profiler (kernel stats + trace: tools/lora_timeline.py reads the trace)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lora -o lora -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --lora-trainable > $O/prof_lora.log 2>&1; echo "rocprof lora rc=$?"
+python3 $R/tools/lora_timeline.py $O/prof_lora/lora_kernel_trace.csv > $O/lora_timeline.txt 2>&1; tail -3 $O/lora_timeline.txt
+# two data-parallel ranks sharing the one card over gloo: rehearses the N > 1 code of bench.py / Trainer with GPU tensors
+# (RCCL refuses two ranks on one device; the number is NOT a scaling figure)
+cd $R && timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+  bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err; echo "gloo2 rc=$?"; tail -2 $O/bench_gloo2.err
