@@ -1472,6 +1472,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + wave * kper + kq * 8;
   const bool two = p.M > 16;
   constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms)
+  // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
+  // loads is in flight instead of after the K loop: the row scale's partial sums, the RoPE position -> cos / sin rows, the
+  // 16-bit residual, and (wave 0) the LoRA second source.  Each of these was one more dependent global-memory round trip
+  // at the tail of a kernel that is a few microseconds long (decode step).
+  const int pm = wave * 16 + r16;          // (meaningful for wave < 2)
+  const long pmm = pm < p.M ? pm : 0;
+  float rs = 1.f;
+  f32x4 rope_c = {1.f, 1.f, 1.f, 1.f}, rope_s = {0.f, 0.f, 0.f, 0.f};
+  u32x2 old16[NCB];
+  u32x4 l_a0[2], l_a1[2], l_w[2][NCB];
   for (int k = 0; k < kper; k += 32 * U) {
     u32x4 wf[U][NCB], x0[U], x1[U];
 #pragma unroll
@@ -1481,6 +1491,37 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + k + 32 * u);
         x0[u] = *reinterpret_cast<const u32x4*>(xp0 + k + 32 * u);
         if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + k + 32 * u);
+      }
+    }
+    if (k == 0 && wave < 2) {
+      if constexpr (EPI == EPI_SILU || EPI == EPI_ROPE) {
+        if (p.rs_part) rs = row_rscale(p, pmm);
+      }
+      if constexpr (EPI == EPI_ROPE) {
+        if (ncol[0] < p.rope_cols) {
+          const int pos = p.rope_pos ? p.rope_pos[pmm] : (int)(pmm % p.rope_L);
+          const int d = (blockIdx.x & 1) * 16 + 4 * kq;
+          rope_c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
+          rope_s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
+        }
+        if (wave == 0 && p.K2 > 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (32 * u < p.K2) {
+              l_a0[u] = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(r16, p.M - 1) * p.lda2 + 32 * u + kq * 8);
+              l_a1[u] = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + 32 * u + kq * 8);
+#pragma unroll
+              for (int c = 0; c < NCB; ++c)
+                l_w[u][c] = *reinterpret_cast<const u32x4*>(p.W2 + (long)(ncol[c] + r16) * p.ldw2 + 32 * u + kq * 8);
+            }
+          }
+        }
+      }
+      if constexpr (EPI == EPI_NORM16) {
+        if (p.flags & TCAVT_EPI_RESIDUAL) {
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) old16[c] = *reinterpret_cast<const u32x2*>(p.norm_h16 + pmm * p.ldc + n0 + c * 16 + 4 * kq);
+        }
       }
     }
 #pragma unroll
@@ -1496,7 +1537,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   }
   if constexpr (EPI == EPI_ROPE) {  // LoRA second K source (K2 = 64: two steps), done by wave 0
     if (p.K2 > 0 && wave == 0) {
-      for (int k = 0; k < p.K2; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // the first two steps come from the registers filled under the first weight batch
+        if (32 * u < p.K2) {
+#pragma unroll
+          for (int c = 0; c < NCB; ++c) {
+            acc[c][0] = mfma16<F16>(l_w[u][c], l_a0[u], acc[c][0]);
+            if (two) acc[c][1] = mfma16<F16>(l_w[u][c], l_a1[u], acc[c][1]);
+          }
+        }
+      }
+      for (int k = 64; k < p.K2; k += 32) {
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(r16, p.M - 1) * p.lda2 + k + kq * 8);
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + k + kq * 8);
 #pragma unroll
@@ -1529,10 +1580,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     for (int w = 1; w < SK_WAVES; ++w) t += red[w][c * 2 + mb][lane];
     v[c] = t;
   }
-  float rs = 1.f;
-  if constexpr (EPI == EPI_SILU || EPI == EPI_ROPE) {
-    if (p.rs_part) rs = row_rscale(p, mm);
-  }
   constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
   if constexpr (EPI == EPI_GENERIC) {
     if (!rowok) return;
@@ -1547,7 +1594,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       const long off = mm * p.ldc + n0 + c * 16 + nq;
       if constexpr (EPI == EPI_NORM16) {  // 16-bit residual stream: in place, sums of the rounded values (see gemm_epilogue)
         if (res) {
-          const u32x2 old = *reinterpret_cast<const u32x2*>(p.norm_h16 + off);
+          const u32x2 old = old16[c];
           o += f32x4{from16_lo<F16>(old[0]), from16_hi<F16>(old[0]), from16_lo<F16>(old[1]), from16_hi<F16>(old[1])};
         }
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
@@ -1580,12 +1627,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     static_assert(EPI != EPI_ROPE || NCB == 2, "two partner blocks per workgroup");
     if (!rowok) return;
     const bool rot = ncol[0] < p.rope_cols;
-    const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
-    const int d = (blockIdx.x & 1) * 16 + nq;
     f32x4 lo = v[0] * rs, hi = v[NCB - 1] * rs;
     if (rot) {
-      const f32x4 c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
-      const f32x4 sn = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
+      const f32x4 c = rope_c, sn = rope_s;
       const f32x4 l2 = lo * c - hi * sn, h2 = hi * c + lo * sn;
       lo = l2;
       hi = h2;

@@ -21,23 +21,26 @@
 namespace tcavt {
 
 // One query per (sample, query head) over the cached keys 0 .. pos[b] (the new token's own key included).
-// One workgroup per (sample, kv head); KS waves per query head of the group split the keys.  Scores: lane = key (each lane
-// reads its key's 128-byte row and keeps the whole query in registers); the KS (max, sum) pairs of a head meet in LDS, the
-// probabilities are normalised with the head's global sum and carried in fp16 as in the prefill kernel; output: lane =
-// head dimension over the wave's key range, the KS partial outputs are added in split order.
-// The new token's own key / value (row b of qkv, position pos[b]) are read from qkv and written to the cache by this kernel
-// (wave 0 of the workgroup that owns the kv head): no separate append launch, and nothing written here is read back here.
+// One workgroup per (sample, query head) -- B * nq workgroups, so a batch of 8 already covers the 256 CUs; the heads of a
+// GQA group re-read their kv head's rows through L2 -- with KS waves that split the keys in chunks of whole 64-key rounds.
+// A round is read COALESCED: lane = (key g = lane / 8 of an 8-key row group, 16-byte column c = lane % 8), so one load
+// instruction covers eight whole 128-byte rows and all eight loads of a round are in flight together (the first version gave
+// a lane a whole key row -- 64 cache lines per load instruction -- and walked the values one key at a time: 26 us per layer,
+// latency bound).  Scores: 8-feature partial dot products, added over the 8 lanes of a key; the KS (max, sum) pairs meet in
+// LDS; the probabilities are normalised with the head's global sum and carried in fp16 as in the prefill kernel; output:
+// 8 features per lane over the lane's keys, added over the 8 key groups by shuffles and over the KS waves in split order.
+// The new token's own key / value (row b of qkv, position pos[b]) are read from qkv and written to the cache by the
+// workgroup of the kv head's first query head: no separate append launch, and nothing written here is read back here.
 template <bool F16>
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ vc, const int* __restrict__ pos,
                                                            bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale,
                                                            int KS) {
-  extern __shared__ float sc[];  // [group][lmax] scores | [group][KS][2] (max, sum) | [group][KS][64] partial outputs
+  extern __shared__ float sc[];  // [lmax] scores | [KS][2] (max, sum) | [KS][64] partial outputs
   const int group = nq / nkv;
-  const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int hq = wv % group, ks = wv / group;  // query head of the group, key split
-  const int head = kvh * group + hq;
+  const int b = blockIdx.x / nq, head = blockIdx.x % nq, kvh = head / group;
+  const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int g = lane >> 3, c = lane & 7;
   const int n = min(pos[b] + 1, lmax);
   const int ld = (nq + 2 * nkv) * 64, w = nkv * 64;
   const bf16_t* kb = kc + (long)b * lmax * w + kvh * 64;
@@ -45,44 +48,50 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   const int jn = n - 1;  // the new token's position
   const bf16_t* knew = qkv + (long)b * ld + (nq + kvh) * 64;
   const bf16_t* vnew = qkv + (long)b * ld + (nq + nkv + kvh) * 64;
-  if (wv == 0 && lane < 16) {  // append: 8 lanes x 16 bytes of k, 8 of v
-    const int c = (lane & 7) * 8;
-    if (lane < 8) *reinterpret_cast<u32x4*>(kc + ((long)b * lmax + jn) * w + kvh * 64 + c) = *reinterpret_cast<const u32x4*>(knew + c);
-    else *reinterpret_cast<u32x4*>(vc + ((long)b * lmax + jn) * w + kvh * 64 + c) = *reinterpret_cast<const u32x4*>(vnew + c);
+  if (head % group == 0 && ks == 0 && lane < 16) {  // append: 8 lanes x 16 bytes of k, 8 of v
+    const int cc = (lane & 7) * 8;
+    if (lane < 8) *reinterpret_cast<u32x4*>(kc + ((long)b * lmax + jn) * w + kvh * 64 + cc) = *reinterpret_cast<const u32x4*>(knew + cc);
+    else *reinterpret_cast<u32x4*>(vc + ((long)b * lmax + jn) * w + kvh * 64 + cc) = *reinterpret_cast<const u32x4*>(vnew + cc);
   }
-  float* s = sc + hq * lmax;
-  float* st = sc + group * lmax + (hq * KS) * 2;
-  float* po = sc + group * lmax + group * KS * 2 + (hq * KS) * 64;
+  float* s = sc;
+  float* st = sc + lmax;
+  float* po = st + KS * 2;
   const int chunk = ((n + KS - 1) / KS + 63) / 64 * 64;  // keys per split, whole 64-key rounds
   const int j0 = ks * chunk, j1 = min(j0 + chunk, n);
-  float q[64];
+  float q[8];
   {
-    const u32x4* qp = reinterpret_cast<const u32x4*>(qkv + (long)b * ld + head * 64);
+    const u32x4 t = *reinterpret_cast<const u32x4*>(qkv + (long)b * ld + head * 64 + c * 8);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const u32x4 t = qp[c];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        q[c * 8 + 2 * e] = from16_lo<F16>(t[e]) * scale;
-        q[c * 8 + 2 * e + 1] = from16_hi<F16>(t[e]) * scale;
-      }
+    for (int e = 0; e < 4; ++e) {
+      q[2 * e] = from16_lo<F16>(t[e]) * scale;
+      q[2 * e + 1] = from16_hi<F16>(t[e]) * scale;
     }
   }
   float mx = -1e30f;
-  for (int j = j0 + lane; j < j1; j += 64) {
-    const u32x4* kp = reinterpret_cast<const u32x4*>(j == jn ? knew : kb + (long)j * w);
-    float d = 0.f;
+  for (int jb = j0; jb < j1; jb += 64) {
+    u32x4 kr[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const u32x4 t = kp[c];
+    for (int i = 0; i < 8; ++i) {
+      const int j = min(jb + i * 8 + g, jn);
+      kr[i] = *reinterpret_cast<const u32x4*>((j == jn ? knew : kb + (long)j * w) + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float d = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        d = fmaf(q[c * 8 + 2 * e], from16_lo<F16>(t[e]), d);
-        d = fmaf(q[c * 8 + 2 * e + 1], from16_hi<F16>(t[e]), d);
+        d = fmaf(q[2 * e], from16_lo<F16>(kr[i][e]), d);
+        d = fmaf(q[2 * e + 1], from16_hi<F16>(kr[i][e]), d);
+      }
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      const int j = jb + i * 8 + g;
+      if (j < j1) {
+        if (c == 0) s[j] = d;
+        mx = fmaxf(mx, d);
       }
     }
-    s[j] = d;
-    mx = fmaxf(mx, d);
   }
   mx = wave_max(mx);
   float sum = 0.f;
@@ -94,17 +103,37 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   for (int k = 0; k < KS; ++k) gm = fmaxf(gm, st[k * 2]);
   for (int k = 0; k < KS; ++k) gl += st[k * 2 + 1] * __expf(st[k * 2] - gm);
   const float inv = 1.f / gl;
-  auto vat = [&](int jj) { return from16<F16>(jj == jn ? vnew[lane] : vb[(long)jj * w + lane]); };
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;  // four independent chains over the keys
-  int j = j0;
-  for (; j + 3 < j1; j += 4) {
-    o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), vat(j), o0);
-    o1 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 1] - gm) * inv)), vat(j + 1), o1);
-    o2 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 2] - gm) * inv)), vat(j + 2), o2);
-    o3 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j + 3] - gm) * inv)), vat(j + 3), o3);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int jb = j0; jb < j1; jb += 64) {
+    u32x4 vr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = min(jb + i * 8 + g, jn);
+      vr[i] = *reinterpret_cast<const u32x4*>((j == jn ? vnew : vb + (long)j * w) + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = jb + i * 8 + g;
+      const float pr = j < j1 ? f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] = fmaf(pr, from16_lo<F16>(vr[i][e]), acc[2 * e]);
+        acc[2 * e + 1] = fmaf(pr, from16_hi<F16>(vr[i][e]), acc[2 * e + 1]);
+      }
+    }
   }
-  for (; j < j1; ++j) o0 = fmaf(f16_to_f32(f32_to_f16(__expf(s[j] - gm) * inv)), vat(j), o0);
-  po[ks * 64 + lane] = (o0 + o1) + (o2 + o3);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 8, 64);
+    acc[e] += __shfl_xor(acc[e], 16, 64);
+    acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) po[ks * 64 + c * 8 + e] = acc[e];
+  }
   __syncthreads();
   if (ks == 0) {
     float o = po[lane];
@@ -158,6 +187,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   __shared__ int ci[SMP_CAP];
   __shared__ float rv[SMP_T / 64];
   __shared__ int ri[SMP_T / 64];
+  __shared__ float rm[SMP_T / 64];
   __shared__ float bestv;
   __shared__ int besti;
   __shared__ int hist_bins[SMP_BINS];
@@ -193,70 +223,82 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     }
     __syncthreads();
   }
-  // block-wide arg-max of the elements that come after (pv, pi) in (value desc, index asc) order
-  auto next_best = [&](float pv, int pi, float scale) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += SMP_T) {
-      const float v = x[i] * scale;
-      if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
+  // every logit of the sample, 16 bytes per lane and load when the row allows (V % 4 == 0, aligned) and several loads in flight:
+  // the passes below are latency bound (one workgroup per sample), so fewer and wider loads are what shortens them
+  auto walk = [&](auto&& f) {
+    if ((V & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      const int V4 = V >> 2;
+#pragma unroll 4
+      for (int i4 = tid; i4 < V4; i4 += SMP_T) {
+        const f32x4 t = x4[i4];
+        f(t[0], 4 * i4);
+        f(t[1], 4 * i4 + 1);
+        f(t[2], 4 * i4 + 2);
+        f(t[3], 4 * i4 + 3);
+      }
+    } else {
+#pragma unroll 4
+      for (int i = tid; i < V; i += SMP_T) f(x[i], i);
     }
+  };
+  // block-wide arg-max of the elements that come after (pv, pi) in (value desc, index asc) order; with_min: also the
+  // smallest finite value (left in rv[0] region -> minv) in the same pass
+  __shared__ float minv;
+  auto next_best = [&](float pv, int pi, float scale, bool with_min) {
+    float bv = -INFINITY, lmin = INFINITY;
+    int bi = 0x7fffffff;
+    walk([&](float raw, int i) {
+      const float v = raw * scale;
+      if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
+      if (with_min && v > -INFINITY) lmin = fminf(lmin, v);
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o, 64);
       const int oi = __shfl_xor(bi, o, 64);
       if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) { rv[wv] = bv; ri[wv] = bi; }
+    if (with_min) lmin = -wave_max(-lmin);
+    if (lane == 0) { rv[wv] = bv; ri[wv] = bi; rm[wv] = lmin; }
     __syncthreads();
     if (tid == 0) {
-      float v = rv[0];
+      float v = rv[0], m_ = rm[0];
       int i = ri[0];
-      for (int k = 1; k < SMP_T / 64; ++k)
+      for (int k = 1; k < SMP_T / 64; ++k) {
         if (better(rv[k], ri[k], v, i)) { v = rv[k]; i = ri[k]; }
+        m_ = fminf(m_, rm[k]);
+      }
       bestv = v;
       besti = i;
+      minv = m_;
     }
     __syncthreads();
   };
   long tok;
   if (!sp.do_sample) {  // greedy: arg-max of the processed scores, first maximum wins (torch.argmax)
-    next_best(INFINITY, -1, 1.f);
+    next_best(INFINITY, -1, 1.f, false);
     tok = besti;
   } else {
-    // Candidate collection in four passes over the vocabulary instead of one pass per candidate: (1) the maximum and the
-    // minimum, (2) a histogram of (max - score) in SMP_BINS bins over that range (integer counts: order-independent), from which the narrowest
+    // Candidate collection in three passes over the vocabulary instead of one pass per candidate: (1) the maximum and the
+    // minimum (one pass), (2) a histogram of (max - score) in SMP_BINS bins over that range (integer counts: order-independent), from which the narrowest
     // threshold that keeps at least top_k scores follows, (3) everything at or above that threshold goes to an LDS list
     // (top_k + the rest of the threshold bin; insertion order does not matter, the selection below orders by
     // (value, index)).  The list is then ordered by top_k rounds of a wave-level arg-max over <= SMP_LIST entries.
     const float invT = 1.f / sp.temperature;
-    next_best(INFINITY, -1, invT);
+    next_best(INFINITY, -1, invT, true);  // (1): the maximum and, in the same pass, the smallest finite score
     const float gmax = bestv;
     // bin width from the spread of the finite scores: SMP_BINS bins between the maximum and the minimum
-    float lmin = INFINITY;
-    for (int i = tid; i < V; i += SMP_T) {
-      const float v = x[i] * invT;
-      if (v > -INFINITY) lmin = fminf(lmin, v);
-    }
-    lmin = -wave_max(-lmin);
-    if (lane == 0) rv[wv] = lmin;
-    __syncthreads();
-    if (tid == 0) {
-      float m_ = rv[0];
-      for (int q_ = 1; q_ < SMP_T / 64; ++q_) m_ = fminf(m_, rv[q_]);
-      bestv = m_;
-    }
-    __syncthreads();
-    const float bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - bestv, 1e-20f);
+    const float bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - minv, 1e-20f);
     __syncthreads();
     const int k = min(max(sp.top_k, 1), SMP_CAP);
     for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
     if (tid == 0) list_n = 0;
     __syncthreads();
-    for (int i = tid; i < V; i += SMP_T) {
-      const float d = (gmax - x[i] * invT) * bscale;
+    walk([&](float raw, int) {
+      const float d = (gmax - raw * invT) * bscale;
       if (d < (float)SMP_BINS) atomicAdd(&hist_bins[(int)d], 1);  // (-inf scores: d = +inf, skipped)
-    }
+    });
     __syncthreads();
     if (tid == 0) {
       int cum = 0, tb = SMP_BINS - 1;
@@ -270,13 +312,13 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     int n = 0;
     if (thr_bin >= 0) {
       const float lim = (float)(thr_bin + 1);
-      for (int i = tid; i < V; i += SMP_T) {
-        const float v = x[i] * invT;
+      walk([&](float raw, int i) {
+        const float v = raw * invT;
         if ((gmax - v) * bscale < lim) {
           const int slot = atomicAdd(&list_n, 1);
           if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = i; }
         }
-      }
+      });
       __syncthreads();
       const int ln = min(list_n, SMP_LIST);
       if (wv == 0) {  // one wave orders the list: round r picks the next entry in (value desc, index asc) order
@@ -314,7 +356,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       float pv = INFINITY;
       int pi = -1;
       for (;;) {
-        next_best(pv, pi, invT);
+        next_best(pv, pi, invT, false);
         const float v = bestv;
         const int i = besti;
         if (i == 0x7fffffff || v == -INFINITY) break;        // nothing (finite) left
@@ -439,9 +481,8 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->txt_mod /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
                              a->bad_id_flag, dt, a->h16, a->part, np_in, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
-  const int group = nq / nkv;
-  const int KS = 16 / group >= 1 ? 16 / group : 1;  // key splits per query head: up to 16 waves per workgroup
-  const size_t lds = ((size_t)group * a->kv_lmax + (size_t)group * KS * 66) * sizeof(float);
+  const int KS = std::min(16, (a->kv_lmax + 63) / 64);  // key splits (waves) per query head: one 64-key round each up to 1024 keys
+  const size_t lds = ((size_t)a->kv_lmax + (size_t)KS * 66) * sizeof(float);
   TCAVT_CHECK_ARG(lds <= 64 * 1024, "llama_decode_step: kv_lmax = %d too long for the decode attention's score buffer", a->kv_lmax);
   for (int li = 0; li < a->n_layers; ++li) {
     const tcavt_llama_layer& w = a->layers[li];
@@ -467,10 +508,10 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     bf16_t* vc = static_cast<bf16_t*>(a->v_cache) + li * per_layer;
     // (the new token's k / v rows are appended to the cache by attn_decode_kernel itself)
     if (dt == TCAVT_F16)
-      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nkv), dim3(group * KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
                          kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
     else
-      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nkv), dim3(group * KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
+      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
                          kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
     TCAVT_CHECK_LAUNCH("attn_decode");
     {
