@@ -585,6 +585,28 @@ typedef struct tcavt_tstack_args {
 
 int tcavt_tlayer_stack_forward(const tcavt_tstack_args* args, tcavt_stream_t stream);
 
+/* Backward of tcavt_tlayer_stack_forward for fp32 ENCODER layers (dtype16 == 0, no cross-attention): the lane-polygon
+ * encoder's layers in the training step (scripts/train.py:352-383 under loss.backward(), :1168-1183).  `fwd` is the forward
+ * call's argument block with every layer's activations still in place (a forward that feeds a backward gives each layer its
+ * own buffers); parameter gradients are fp32 and ADDED to (zero them first).  The 16-bit stacks (Q-Former, only trainable
+ * in modify_scripts/modify_train.py) are composed by the caller from the kernel-level entry points. */
+typedef struct tcavt_tlayer_grads {
+  float *g_w_in, *g_b_in, *g_w_out, *g_b_out, *g_w1, *g_b1, *g_w2, *g_b2, *g_n1_w, *g_n1_b, *g_n2_w, *g_n2_b;
+} tcavt_tlayer_grads;
+
+typedef struct tcavt_tstack_bwd_args {
+  const tcavt_tstack_args* fwd;
+  const tcavt_tlayer_grads* grads; /* HOST array, fwd->n_layers entries */
+  const float* g_out;              /* [M][E]: dL/d (stack output), M = B*L */
+  float* g_x;                      /* [M][E]: dL/d (stack input) (out) */
+  /* workspaces, shared by the layers */
+  float *g_tmp, *g_y2, *g_y2d, *g_x1, *g_y, *g_yd, *g_att; /* [M][E] each (g_y2d / g_yd: train mode only) */
+  float* g_f;                      /* [M][FF] */
+  float* g_qkv;                    /* [M][3E] */
+} tcavt_tstack_bwd_args;
+
+int tcavt_tlayer_stack_backward(const tcavt_tstack_bwd_args* args, tcavt_stream_t stream);
+
 /* The trajectory head's cross-attention over the LLM's final hidden states (scripts/train.py:795-798) in absorbed form, one
  * call: q'_h = q_h W_k[h], scores = q' F^T / sqrt(dh), P = dropout(softmax), ctx = P F, att_h = ctx_h W_v[h]^T + b_v[h]
  * (identical to nn.MultiheadAttention in exact arithmetic: b_k is softmax-invariant, rows of P sum to 1).  fp16 storage. */

@@ -49,7 +49,8 @@ def _struct_fields(name):
                                           ("tcavt_tlayer", "TLayer"), ("tcavt_tstack_args", "TStackArgs"),
                                           ("tcavt_cross_attn_args", "CrossAttnArgs"), ("tcavt_ltsf_args", "LtsfArgs"),
                                           ("tcavt_cross_attn_bwd_args", "CrossAttnBwdArgs"),
-                                          ("tcavt_ltsf_bwd_args", "LtsfBwdArgs")])
+                                          ("tcavt_ltsf_bwd_args", "LtsfBwdArgs"),
+                                          ("tcavt_tlayer_grads", "TLayerGrads"), ("tcavt_tstack_bwd_args", "TStackBwdArgs")])
 def test_struct_mirrors_match_header_layout(cname, mirror, tmp_path):
     """Field order of each ctypes mirror follows the C struct, and -- compiled with the host C compiler against the real
     header -- so do sizeof and every field offset."""

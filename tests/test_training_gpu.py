@@ -554,9 +554,9 @@ def test_cross_attn_backward_stage_matches_python_composition(gpu, train, monkey
 
 @pytest.mark.parametrize("train", [False, True])
 def test_ltsf_backward_stage_matches_python_composition(gpu, train, monkeypatch):
-    """tcavt_ltsf_backward (SURVEY 8b ltsf_backward: one C call per phase, single stream) against the per-launch Python
-    composition on leaf streams (TCAVT_PY_TLAYERS=1): every gradient of the trainable set, the lane-polygon encoder's
-    included (it consumes the stage's g_poly)."""
+    """tcavt_ltsf_backward (SURVEY 8b ltsf_backward: one C call per phase, single stream) and tcavt_tlayer_stack_backward
+    (the lane-polygon encoder's layers) against the per-launch Python composition on leaf streams (TCAVT_PY_TLAYERS=1): every
+    gradient of the trainable set."""
     from tcavt_amd import backward, model, training
 
     dev = gpu["device"]
@@ -565,9 +565,17 @@ def test_ltsf_backward_stage_matches_python_composition(gpu, train, monkeypatch)
     g = {k: v.to(dev) for k, v in t.items()}
     args = (g["traj_emb"], g["vision_emb"], g["lane_polygon"], g["lane_polygon_len"], g["target_traj"], g["norm_stat"],
             g["input_ids"], g["attention_mask"], g["labels"])
-    used = []
+    used, used_poly = [], []
     orig = backward.Backward._ltsf_stage
     monkeypatch.setattr(backward.Backward, "_ltsf_stage", lambda self, *a, **k: (used.append(1), orig(self, *a, **k))[1])
+    orig_p = backward.Backward._polygon_stage
+
+    def poly_stage(self, *a, **k):
+        r = orig_p(self, *a, **k)
+        used_poly.append(bool(r))
+        return r
+
+    monkeypatch.setattr(backward.Backward, "_polygon_stage", poly_stage)
 
     def run(py):
         if py:
@@ -583,9 +591,9 @@ def test_ltsf_backward_stage_matches_python_composition(gpu, train, monkeypatch)
         return {k: v.clone() for k, v in tr.book.g.items()}
 
     ga = run(False)
-    assert used == [1]  # the stage ran
+    assert used == [1] and used_poly == [True]  # both stages ran (tcavt_ltsf_backward, tcavt_tlayer_stack_backward)
     gb = run(True)
-    assert used == [1]  # ... and the Python composition did not go through it
+    assert used == [1] and used_poly == [True, False]  # ... and the Python composition did not go through them
     assert len(ga) > 40
     for k in ga:  # same kernels on the same operands; the atomically accumulated reductions (LayerNorm / bias sums) differ in order
         assert rel_err(ga[k].cpu(), gb[k].cpu()) < 1e-4, k

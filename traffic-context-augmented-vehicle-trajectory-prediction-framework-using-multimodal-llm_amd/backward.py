@@ -653,6 +653,11 @@ class Backward:
         dh = D // nh
         g_x = self._buf("po.g_x", (M, D))
         ops.masked_mean_bwd(g_emb, sv.lens, g_x, B, P, D)
+        if self._polygon_stage(g_x, sv, B, P, D, nh):  # the layer loop as one C call (tcavt_tlayer_stack_backward)
+            gpos = G[pp + "pos_embedding"]
+            ops.poly_embed_bwd(self._buf("po.g_x0", (M, D)), sv.polygon, G[pp + "input_proj.weight"], G[pp + "input_proj.bias"],
+                               gpos.view(-1, D)[:P], B, P, D)
+            return
         for i in reversed(range(len(sv.layers))):
             s, lyr = sv.layers[i], enc.encoder.layers[i]
             pre = f"{pp}encoder.layers.{i}."
@@ -687,6 +692,64 @@ class Backward:
         gpos = G[pp + "pos_embedding"]
         ops.poly_embed_bwd(g_x, sv.polygon, G[pp + "input_proj.weight"], G[pp + "input_proj.bias"],
                            gpos.view(-1, D)[:P], B, P, D)
+
+    def _polygon_stage(self, g_out, sv, B, P, D, nh):
+        """Backward.polygon's layer loop as tcavt_tlayer_stack_backward (fp32 encoder layers; csrc/tlayers.hip): the gradient
+        of the stack input lands in the buffer "po.g_x0".  False -> the caller runs the Python composition (TCAVT_PY_TLAYERS=1,
+        or dropout sites that are not the stage's numbering)."""
+        if os.environ.get("TCAVT_PY_TLAYERS", "0") == "1":
+            return False
+        from . import capi
+
+        enc, G, pp = self.m.lane_polygon_encoder, self.book.g, self.pp
+        n, M = len(sv.layers), B * P
+        specs = [s.get("drop") or [None] * 4 for s in sv.layers]
+        flat = [x for sp in specs for x in sp[:4]]
+        if all(x is None for x in flat):
+            p, seed, s0 = 0.0, 0, 0
+        elif any(x is None for x in flat):
+            return False
+        else:
+            p, seed, s0 = flat[0]
+            if any(x[0] != p or x[1] != seed for x in flat) or [x[2] for x in flat] != list(range(s0, s0 + 4 * n)):
+                return False
+        keep = []
+
+        def put(obj, **kw):
+            for k_, t_ in kw.items():
+                setattr(obj, k_, t_.data_ptr())
+                keep.append(t_)
+
+        arr, grads = (capi.TLayer * n)(), (capi.TLayerGrads * n)()
+        ff = enc.encoder.layers[0].linear1.weight.shape[0]
+        for i, (s, lyr) in enumerate(zip(sv.layers, enc.encoder.layers)):
+            sa, pre = lyr.self_attn, f"{pp}encoder.layers.{i}."
+            put(arr[i], w_in=sa.in_proj_weight.detach(), w_out=sa.out_proj.weight.detach(), w1=lyr.linear1.weight.detach(),
+                w2=lyr.linear2.weight.detach(), n1_w=lyr.norm1.weight.detach(), n2_w=lyr.norm2.weight.detach(), qkv=s["qkv"],
+                att=s["att"], y=s["y"], x1=s["x1"], ffh=s["f"], y2=s["y2"])
+            if i > 0:
+                put(arr[i - 1], out=s["x"])  # a layer's input is its predecessor's output
+            put(grads[i], g_w_in=G[pre + "self_attn.in_proj_weight"], g_b_in=G[pre + "self_attn.in_proj_bias"],
+                g_w_out=G[pre + "self_attn.out_proj.weight"], g_b_out=G[pre + "self_attn.out_proj.bias"],
+                g_w1=G[pre + "linear1.weight"], g_b1=G[pre + "linear1.bias"], g_w2=G[pre + "linear2.weight"],
+                g_b2=G[pre + "linear2.bias"], g_n1_w=G[pre + "norm1.weight"], g_n1_b=G[pre + "norm1.bias"],
+                g_n2_w=G[pre + "norm2.weight"], g_n2_b=G[pre + "norm2.bias"])
+        f = capi.TStackArgs()
+        f.layers, f.n_layers = arr, n
+        put(f, x=sv.layers[0]["x"], key_len=sv.lens)
+        f.B, f.L, f.E, f.FF, f.nhead, f.dtype16 = B, P, D, ff, nh, 0
+        f.dropout_p, f.dropout_seed, f.first_site = p, seed & 0xFFFFFFFFFFFFFFFF, s0
+        a = capi.TStackBwdArgs()
+        a.fwd, a.grads = ctypes.pointer(f), grads
+        b = self._buf
+        put(a, g_out=g_out, g_x=b("po.g_x0", (M, D)), g_tmp=b("po.g_tmp", (M, D)), g_y2=b("po.g_y2", (M, D)),
+            g_x1=b("po.g_x1", (M, D)), g_y=b("po.g_y", (M, D)), g_att=b("po.g_att", (M, D)), g_f=b("po.g_f", (M, ff)),
+            g_qkv=b("po.g_qkv", (M, 3 * D)))
+        if p > 0.0:
+            put(a, g_y2d=b("po.g_y2d", (M, D)), g_yd=b("po.g_yd", (M, D)))
+        ops.tlayer_stack_backward(a)
+        del keep
+        return True
 
     # ---- entry ------------------------------------------------------------------------------
     def run(self, decoded, y, norm_stat, x_in, poly_emb, fh_b, L, after_ltsf=None):

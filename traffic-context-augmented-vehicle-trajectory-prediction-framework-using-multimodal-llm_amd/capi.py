@@ -97,6 +97,20 @@ class CrossAttnArgs(ctypes.Structure):
         ("dropout_seed", ctypes.c_uint64)]
 
 
+class TLayerGrads(ctypes.Structure):
+    """Mirror of ``tcavt_tlayer_grads`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("g_w_in", "g_b_in", "g_w_out", "g_b_out", "g_w1", "g_b1", "g_w2", "g_b2", "g_n1_w", "g_n1_b",
+                                        "g_n2_w", "g_n2_b")]
+
+
+class TStackBwdArgs(ctypes.Structure):
+    """Mirror of ``tcavt_tstack_bwd_args`` (include/tcavt.h)."""
+
+    _fields_ = [("fwd", ctypes.POINTER(TStackArgs)), ("grads", ctypes.POINTER(TLayerGrads))] + [(n, c_void_p) for n in (
+        "g_out", "g_x", "g_tmp", "g_y2", "g_y2d", "g_x1", "g_y", "g_yd", "g_att", "g_f", "g_qkv")]
+
+
 class CrossAttnBwdArgs(ctypes.Structure):
     """Mirror of ``tcavt_cross_attn_bwd_args`` (include/tcavt.h)."""
 
@@ -252,6 +266,7 @@ _SIGNATURES = {
     "tcavt_ltsf_forward": [ctypes.POINTER(LtsfArgs), c_int, c_void_p],
     "tcavt_cross_attn_backward": [ctypes.POINTER(CrossAttnBwdArgs), c_void_p],
     "tcavt_ltsf_backward": [ctypes.POINTER(LtsfBwdArgs), c_int, c_void_p],
+    "tcavt_tlayer_stack_backward": [ctypes.POINTER(TStackBwdArgs), c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],

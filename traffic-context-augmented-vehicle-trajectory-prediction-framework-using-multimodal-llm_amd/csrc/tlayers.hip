@@ -104,6 +104,76 @@ extern "C" int tcavt_tlayer_stack_forward(const tcavt_tstack_args* a, tcavt_stre
 }
 
 // ---------------------------------------------------------------------------
+// Backward of the fp32 encoder-layer stack (the lane-polygon encoder's layers, scripts/train.py:352-383, in the training
+// step): the launch sequence of tcavt_amd.backward.Backward.polygon's layer loop on one stream.  Per layer, last first:
+//   out = LN2(y2), y2 = x1 + drop(linear2(drop(relu(linear1(x1)))));  x1 = LN1(y), y = x + drop(out_proj(MHA(in_proj(x))))
+// Dropout sites as the forward numbered them: first_site + 4 * layer + {0: attention weights, 1: after out_proj, 2: after
+// the ReLU, 3: after linear2}.
+// ---------------------------------------------------------------------------
+extern "C" int tcavt_tlayer_stack_backward(const tcavt_tstack_bwd_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->fwd && a->grads && a->g_out && a->g_x && a->g_tmp && a->g_y2 && a->g_x1 && a->g_y && a->g_att && a->g_f &&
+                      a->g_qkv,
+                  "tlayer_stack_backward: null pointer");
+  const tcavt_tstack_args& f = *a->fwd;
+  TCAVT_CHECK_ARG(f.layers && f.n_layers > 0 && f.x && f.B > 0 && f.L > 0 && f.E > 0 && f.FF > 0 && f.nhead > 0 && f.E % f.nhead == 0,
+                  "tlayer_stack_backward: bad forward args");
+  TCAVT_CHECK_ARG(f.dtype16 == 0, "tlayer_stack_backward: fp32 layers only (the 16-bit stacks' backward is composed by the caller)");
+  TCAVT_CHECK_ARG(f.dropout_p >= 0.f && f.dropout_p < 1.f && (f.dropout_p == 0.f || (a->g_y2d && a->g_yd)),
+                  "tlayer_stack_backward: dropout_p in [0, 1); train mode needs g_y2d / g_yd");
+  const int E = f.E, FF = f.FF, nh = f.nhead, dh = E / nh, M = f.B * f.L;
+  const float p = f.dropout_p;
+  const float scale = (float)(1.0 / sqrt((double)dh));
+  auto lin32 = [&](const float* x, const float* W, const float* gy, float* gW, float* gb, float* gx, int Mr, int N, int K) -> int {
+    TCAVT_TRY(tcavt_gemm_f32_strided(gy, 1, N, x, 1, K, nullptr, nullptr, 0, gW, K, N, K, Mr, TCAVT_EPI_ACCUM, stream));
+    TCAVT_TRY(tcavt_colsum(gy, N, TCAVT_F32, gb, Mr, N, 1, stream));
+    return tcavt_gemm_f32_strided(gy, N, 1, W, 1, K, nullptr, nullptr, 0, gx, K, Mr, K, N, 0, stream);
+  };
+  const float* g_in = a->g_out;
+  for (int li = f.n_layers - 1; li >= 0; --li) {
+    const tcavt_tlayer& l = f.layers[li];
+    const tcavt_tlayer_grads& g = a->grads[li];
+    TCAVT_CHECK_ARG(!l.w_q, "tlayer_stack_backward: layer %d is a decoder layer (encoder layers only)", li);
+    TCAVT_CHECK_ARG(l.w_in && l.w_out && l.w1 && l.w2 && l.n1_w && l.n2_w && l.qkv && l.att && l.y && l.x1 && l.ffh && l.y2 &&
+                        (li == 0 || f.layers[li - 1].out) && g.g_w_in && g.g_b_in && g.g_w_out && g.g_b_out && g.g_w1 && g.g_b1 &&
+                        g.g_w2 && g.g_b2 && g.g_n1_w && g.g_n1_b && g.g_n2_w && g.g_n2_b,
+                    "tlayer_stack_backward: layer %d: null weight / activation / gradient", li);
+    const float* x_in = li == 0 ? f.x : f.layers[li - 1].out;
+    const uint32_t s = f.first_site + 4u * (uint32_t)li;
+    float* g_xin = (li & 1) ? a->g_tmp : a->g_x;  // alternate, so that layer 0 writes the caller's g_x
+    auto drop = [&](const float* gi, float* go, int64_t n, uint32_t site) {
+      return tcavt_dropout(gi, go, n, TCAVT_F32, p, f.dropout_seed, site, nullptr, stream);
+    };
+    // feed-forward block
+    TCAVT_TRY(tcavt_layernorm_bwd(l.y2, l.n2_w, g_in, 1e-5f, a->g_y2, g.g_n2_w, g.g_n2_b, M, E, stream));
+    const float* g_y2d = a->g_y2;
+    if (p > 0.f) {
+      TCAVT_TRY(drop(a->g_y2, a->g_y2d, (int64_t)M * E, s + 3));
+      g_y2d = a->g_y2d;
+    }
+    const float* ffh = static_cast<const float*>(l.ffh);
+    TCAVT_TRY(lin32(ffh, static_cast<const float*>(l.w2), g_y2d, g.g_w2, g.g_b2, a->g_f, M, E, FF));
+    if (p > 0.f) TCAVT_TRY(drop(a->g_f, a->g_f, (int64_t)M * FF, s + 2));
+    TCAVT_TRY(tcavt_relu_bwd(a->g_f, ffh, TCAVT_F32, (int64_t)M * FF, stream));
+    TCAVT_TRY(lin32(l.x1, static_cast<const float*>(l.w1), a->g_f, g.g_w1, g.g_b1, a->g_x1, M, FF, E));
+    TCAVT_TRY(tcavt_add_inplace(a->g_x1, a->g_y2, (int64_t)M * E, stream));
+    // self-attention block
+    TCAVT_TRY(tcavt_layernorm_bwd(l.y, l.n1_w, a->g_x1, 1e-5f, a->g_y, g.g_n1_w, g.g_n1_b, M, E, stream));
+    const float* g_yd = a->g_y;
+    if (p > 0.f) {
+      TCAVT_TRY(drop(a->g_y, a->g_yd, (int64_t)M * E, s + 1));
+      g_yd = a->g_yd;
+    }
+    TCAVT_TRY(lin32(static_cast<const float*>(l.att), static_cast<const float*>(l.w_out), g_yd, g.g_w_out, g.g_b_out, a->g_att, M, E, E));
+    TCAVT_TRY(tcavt_mha_bwd(l.qkv, 3 * E, l.qkv + E, 3 * E, l.qkv + 2 * E, 3 * E, a->g_att, E, a->g_qkv, a->g_qkv + E, a->g_qkv + 2 * E,
+                            3 * E, f.key_len, f.B, f.L, f.L, nh, dh, scale, p, f.dropout_seed, p > 0.f ? s : 0u, stream));
+    TCAVT_TRY(lin32(x_in, static_cast<const float*>(l.w_in), a->g_qkv, g.g_w_in, g.g_b_in, g_xin, M, 3 * E, E));
+    TCAVT_TRY(tcavt_add_inplace(g_xin, a->g_y, (int64_t)M * E, stream));
+    g_in = g_xin;
+  }
+  return TCAVT_OK;
+}
+
+// ---------------------------------------------------------------------------
 // The trajectory head's cross-attention over the LLM's final hidden states (nn.MultiheadAttention with query = the To
 // decoder tokens of a sample, key = value = its L hidden states; scripts/train.py:795-798) in ABSORBED form, one call
 // (SURVEY.md 8b "cross_attn_forward").  Per head h with F = the sample's hidden states:

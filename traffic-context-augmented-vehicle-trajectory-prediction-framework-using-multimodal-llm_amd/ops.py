@@ -820,6 +820,11 @@ def ltsf_forward(args, phase):
     check(lib().tcavt_ltsf_forward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_forward")
 
 
+def tlayer_stack_backward(args):
+    """args: capi.TStackBwdArgs filled by backward.Backward.polygon (fp32 encoder layers)."""
+    check(lib().tcavt_tlayer_stack_backward(ctypes.byref(args), stream_ptr()), "tcavt_tlayer_stack_backward")
+
+
 def ltsf_backward(args, phase):
     """args: capi.LtsfBwdArgs filled by backward.Backward._ltsf_stage; phase 1 (head .. g_poly) / 2 (the rest) / 3."""
     check(lib().tcavt_ltsf_backward(ctypes.byref(args), int(phase), stream_ptr()), "tcavt_ltsf_backward")
