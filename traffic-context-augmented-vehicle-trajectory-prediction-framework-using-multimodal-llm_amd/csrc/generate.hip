@@ -170,6 +170,7 @@ constexpr int SMP_T = 1024;   // threads
 constexpr int SMP_CAP = 256;  // candidate list capacity (top_k + ties)
 constexpr int SMP_BINS = 2048;  // histogram of (max - score) * 64: covers 32 units below the maximum
 constexpr int SMP_LIST = 1024;  // pre-selected scores (everything down to the threshold bin)
+static_assert(SMP_LIST <= SMP_T && (SMP_BINS / 64 & (SMP_BINS / 64 - 1)) == 0, "one thread per list entry; bins per lane a power of two");
 
 __device__ __forceinline__ bool after(float v, int i, float pv, int pi) {  // (v, i) comes after (pv, pi) in (value desc, index asc) order
   return v < pv || (v == pv && i > pi);
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   __shared__ int hist_bins[SMP_BINS];
   __shared__ float list_v[SMP_LIST];
   __shared__ int list_i[SMP_LIST];
-  __shared__ int list_n, thr_bin;
+  __shared__ int list_n, thr_bin, keep_n;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* x = logits + (long)b * V;
   long* hist = history + (long)b * hist_cap;
@@ -201,10 +202,20 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   const int step = *step_p;
   // ---- repetition penalty: once per distinct token of the history (scatter semantics of the reference processor)
   if (sp.rep_penalty != 1.f) {
+    // (the history is staged in LDS when it fits: thread i compares its token with all earlier ones)
+    const bool in_lds = hl <= SMP_LIST;
+    if (in_lds) {
+      for (int i = tid; i < hl; i += SMP_T) list_i[i] = (int)min(max(hist[i], -1L), 0x7fffffffL);  // (ids >= 2^31 - 1 are out of range anyway)
+      __syncthreads();
+    }
     for (int i = tid; i < hl; i += SMP_T) {
       const long t = hist[i];
       bool first = t >= 0 && t < V;
-      for (int j = 0; j < i && first; ++j) first = hist[j] != t;
+      if (in_lds) {
+        for (int j = 0; j < i && first; ++j) first = list_i[j] != (int)t;
+      } else {
+        for (int j = 0; j < i && first; ++j) first = hist[j] != t;
+      }
       if (first) {
         const float s = x[t];
         x[t] = s < 0.f ? s * sp.rep_penalty : s / sp.rep_penalty;
@@ -293,20 +304,38 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     __syncthreads();
     const int k = min(max(sp.top_k, 1), SMP_CAP);
     for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
-    if (tid == 0) list_n = 0;
+    if (tid == 0) { list_n = 0; keep_n = 0; }
     __syncthreads();
     walk([&](float raw, int) {
       const float d = (gmax - raw * invT) * bscale;
       if (d < (float)SMP_BINS) atomicAdd(&hist_bins[(int)d], 1);  // (-inf scores: d = +inf, skipped)
     });
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, tb = SMP_BINS - 1;
-      for (int i = 0; i < SMP_BINS; ++i) {
-        cum += hist_bins[i];
-        if (cum >= k) { tb = i; break; }
+    if (wv == 0) {
+      // first bin at which the running count reaches k: every lane adds up its SMP_BINS / 64 consecutive bins, a wave scan
+      // finds the lane in whose range the count crosses k, and only that lane walks its bins (one thread walking all 2048
+      // bins was a chain of up to 2048 dependent LDS reads)
+      constexpr int PER = SMP_BINS / 64;
+      int loc = 0;
+#pragma unroll 8
+      for (int t_ = 0; t_ < PER; ++t_) loc += hist_bins[lane * PER + ((t_ + lane) & (PER - 1))];  // (rotated: 2-way instead of 64-way bank conflicts)
+      int pre = loc;  // inclusive prefix over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += up;
       }
-      thr_bin = (cum >= k && cum <= SMP_LIST) ? tb : -1;  // -1: too few scores in range or too many in the bin -> exact fallback
+      const bool hit = pre >= k && pre - loc < k;
+      if (__builtin_amdgcn_ballot_w64(hit) == 0ull) {
+        if (lane == 0) thr_bin = -1;  // fewer than k scores in range -> exact fallback
+      } else if (hit) {
+        int cum = pre - loc, tb = lane * PER;
+        for (int t_ = 0; t_ < PER; ++t_) {
+          cum += hist_bins[lane * PER + t_];
+          if (cum >= k) { tb = lane * PER + t_; break; }
+        }
+        thr_bin = cum <= SMP_LIST ? tb : -1;  // -1: too many scores in the threshold bin -> exact fallback
+      }
     }
     __syncthreads();
     int n = 0;
@@ -321,37 +350,24 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       });
       __syncthreads();
       const int ln = min(list_n, SMP_LIST);
-      if (wv == 0) {  // one wave orders the list: round r picks the next entry in (value desc, index asc) order
-        float pv = INFINITY;
-        int pi = -1;
-        for (;;) {
-          float bv = -INFINITY;
-          int bi = 0x7fffffff;
-          for (int j = lane; j < ln; j += 64) {
-            const float v = list_v[j];
-            const int i = list_i[j];
-            if (after(v, i, pv, pi) && better(v, i, bv, bi)) { bv = v; bi = i; }
-          }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-          }
-          if (bi == 0x7fffffff) break;
-          if (n >= k && !(bv == cv[k - 1])) break;  // beyond top-k and not a tie with the k-th value
-          if (n >= SMP_CAP) break;
-          if (lane == 0) { cv[n] = bv; ci[n] = bi; }
-          ++n;
-          pv = bv;
-          pi = bi;
-          __builtin_amdgcn_s_waitcnt(0);
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) list_n = n;
+      // order the list by RANK: entry t precedes rank(t) others in (value desc, index asc) order -- indices are distinct, so
+      // the ranks are a permutation -- and goes to slot rank(t).  Every thread reads the same list entry at a time (LDS
+      // broadcast).  Kept: the first k and every tie with the k-th value (as `scores < topk[-1]` keeps them), capped at
+      // SMP_CAP.  (The first version picked the next entry by a wave-wide arg-max, one round per candidate.)
+      float mv = 0.f;
+      int mi = 0, rank = 0x7fffffff;
+      if (tid < ln) {
+        mv = list_v[tid];
+        mi = list_i[tid];
+        rank = 0;
+        for (int j = 0; j < ln; ++j) rank += better(list_v[j], list_i[j], mv, mi) ? 1 : 0;
+        if (rank < SMP_CAP) { cv[rank] = mv; ci[rank] = mi; }
       }
       __syncthreads();
-      n = list_n;
+      const int kk = min(k, ln);
+      if (tid < ln && kk > 0 && (rank < kk || mv == cv[kk - 1])) atomicAdd(&keep_n, 1);
+      __syncthreads();
+      n = min(keep_n, SMP_CAP);
     } else {  // exact fallback: one pass over the vocabulary per candidate
       float pv = INFINITY;
       int pi = -1;
