@@ -33,6 +33,67 @@ import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
+RATED_SCLK_MHZ = 2400.0  # MI355X_MICROARCH.md "Max clock"
+
+
+class CardTelemetry:
+    """Shader clock and socket power of THIS process's card, polled from its hwmon files in sysfs by a background thread
+    (the host has several cards: matched by PCI address).  Used outside the timed region only: the dominant GEMM runs at the
+    power cap on real data and the chip lowers its clock (MI355X_MICROARCH.md "DVFS give-back"), so the roofline fraction is
+    also quoted against the MFMA peak at the clock the chip actually sustained.  Unreadable files -> no figures (None)."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+
+        self.rows, self._stop, self._thr, self.files = [], False, None, None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+                if os.path.basename(os.path.realpath(card)) != want:
+                    continue
+                hw = sorted(glob.glob(card + "/hwmon/hwmon*"))
+                if hw and os.path.exists(hw[0] + "/freq1_input"):
+                    pw = hw[0] + ("/power1_input" if os.path.exists(hw[0] + "/power1_input") else "/power1_average")
+                    self.files = (hw[0] + "/freq1_input", pw, hw[0] + "/power1_cap")
+        except Exception:
+            self.files = None
+        self._threading = threading
+
+    @staticmethod
+    def _num(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.rows.append((self._num(self.files[0]), self._num(self.files[1])))
+            time.sleep(0.01)
+
+    def start(self):
+        if self.files:
+            self._stop, self.rows = False, []
+            self._thr = self._threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        if not self._thr:
+            return None
+        self._stop = True
+        self._thr.join()
+        rows = self.rows[len(self.rows) // 4:]  # (skip the ramp)
+        ck = [r[0] / 1e6 for r in rows if r[0]]
+        pw = [r[1] / 1e6 for r in rows if r[1]]
+        cap = self._num(self.files[2])
+        if not ck:
+            return None
+        return {"sclk_mhz": round(sum(ck) / len(ck), 0), "rated_sclk_mhz": RATED_SCLK_MHZ,
+                "power_w": round(sum(pw) / len(pw), 0) if pw else None, "power_cap_w": round(cap / 1e6, 0) if cap else None,
+                "samples": len(ck)}
 GFLOP_PER_SAMPLE = 509.8  # forward, L=256, 18->30 (SURVEY.md 8d)
 
 
@@ -405,6 +466,7 @@ def main():
         elapsed = time.perf_counter() - t_start
         log(f"host enqueue time {enqueue_s / args.steps * 1e3:.3f} ms/step")
         log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
+        loss_timed = float(last["loss"].item())  # (read here: the un-timed passes below keep training)
 
         # in-situ kernel timing: tcavt_llama_stack_forward records HIP events on the launching stream around the five big
         # kernels of every layer (ops.StackEvents); one pass = 16 launches of each, averaged over a few passes
@@ -422,6 +484,13 @@ def main():
         m.mllm.llama_wrapper.timer = None
         timer.close()
         ksum = {k: (c, t / c) for k, (c, t) in acc.items()}
+        # sustained clock / power of the same step loop (un-timed repeat, sampled from sysfs)
+        tele = CardTelemetry(local_dev)
+        tele.start()
+        for _ in range(max(20, min(args.steps, 60))):
+            run_step()
+        torch.cuda.synchronize()
+        clock = tele.stop()
 
     if trainer is not None:
         trainer.release_graph()
@@ -497,11 +566,15 @@ def main():
                 "frac": round(gu_tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "algorithmic_bytes": int(2 * (M * ll.hidden + 2 * ll.inter * ll.hidden + M * ll.inter)),
                 "launches_timed": ksum["gateup"][0], "avg_launch_us": round(gu_ms * 1e3, 1),
+                # the chip holds its clock down at the power cap on real data: clock and power of the step loop (sysfs,
+                # un-timed repeat of the same steps) and the fraction against the MFMA peak at THAT clock
+                "sustained_clock": (dict(clock, frac_at_sustained_clock=round(
+                    gu_tflops / (MFMA_BF16_PEAK_TFLOPS * clock["sclk_mhz"] / RATED_SCLK_MHZ), 4)) if clock else None),
             },
             "kernels": kernels,
             "setup_s": round(setup_s, 1),
             # the synthetic batch is the same every step: in train mode the loss must fall as the optimizer fits it
-            "loss_first_step": round(first_loss, 3), "loss_last_timed_step": round(float(last["loss"].item()), 3),
+            "loss_first_step": round(first_loss, 3), "loss_last_timed_step": round(loss_timed, 3),
             "peak_device_memory_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         }
         if not args.no_cpu_baseline and world >= 1:
