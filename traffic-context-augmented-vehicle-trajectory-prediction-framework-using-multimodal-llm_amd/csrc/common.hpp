@@ -92,6 +92,9 @@ static inline bool skinny_shape(int M, int K) { return M <= 32 && K % 256 == 0; 
 // the number of partials per row a consumer (TCAVT_EPI_ROWSCALE: rowscale_npart) has to add up
 // (32 columns per workgroup for M > 16, to halve the activation re-reads, made the B = 32 decode step slower: 2.05 vs 1.91 ms --
 // half as many workgroups streaming weights costs more than the activation bytes save)
+// (8 columns per workgroup for the N = 2048 projections, so that all 256 CUs get one: also slower, 1.37 vs 1.27 ms at B = 8 --
+// every workgroup pays the same load instructions, LDS reduction and barrier for half the columns, and the consumers add up
+// twice the partial sums)
 static inline int norm_out_npart(int M, int N, int K) { return skinny_shape(M, K) ? N / 16 : N / 64; }
 
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------
