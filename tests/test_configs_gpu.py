@@ -166,3 +166,42 @@ def test_config2_full_size_two_samples_against_oracle(gpu, full_model):
     # BASELINE.json's bar at the full model size, against the reference's fp32 arithmetic (fp16 operand storage)
     assert f_dec < 1e-3 and e_dec < 1e-3
     assert ade32 < 1e-3 and fde32 < 1e-3 and ade16 < 1e-3 and fde16 < 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_config2_full_size_decode_step_equals_prefill_of_the_extended_sequence(gpu, full_model):
+    """Text generation at the full model size through a size-independent round trip: after N greedy tokens from the KV cache
+    (tcavt_llama_decode_step: skinny GEMMs, decode attention, per-sample RoPE positions on ragged prompts, hipGraph replay),
+    the logits that selected token N must equal the logits a fresh PREFILL (tile GEMMs, the causal GQA kernel) computes for
+    the prompt extended by the first N - 1 generated tokens -- two disjoint kernel paths to the same quantity
+    (scripts/train.py:577-654 semantics as stated in DESIGN.md section 7)."""
+    cfg, W, m, t = full_model
+    dev = gpu["device"]
+    B, N = 4, 6
+    g = {k: t[k][:B].contiguous().to(dev) for k in ("vision_emb", "input_ids", "attention_mask")}
+    kw = dict(do_sample=False, repetition_penalty=1.0, no_repeat_ngram_size=0, use_graph=True)
+    out = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=N, input_ids=g["input_ids"],
+                                attention_mask=g["attention_mask"], **kw)
+    torch.cuda.synchronize()
+    V = cfg.llama.vocab
+    last = m.mllm._ws.get("gen.logits", (B, V), torch.float32, dev).clone()
+    assert out.shape == (B, N) and torch.isfinite(last).all()
+    # the prompt of every sample extended by its own first N - 1 generated tokens (right padding keeps the samples ragged)
+    Lt = g["input_ids"].shape[1]
+    ids = torch.zeros(B, Lt + N - 1, dtype=g["input_ids"].dtype, device=dev)
+    am = torch.zeros(B, Lt + N - 1, dtype=g["attention_mask"].dtype, device=dev)
+    for b in range(B):
+        n = int(g["attention_mask"][b].sum())
+        ids[b, :n] = g["input_ids"][b, :n]
+        ids[b, n:n + N - 1] = out[b, :N - 1]
+        am[b, :n + N - 1] = 1
+    out2 = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=1, input_ids=ids, attention_mask=am, **kw)
+    torch.cuda.synchronize()
+    first = m.mllm._ws.get("gen.logits", (B, V), torch.float32, dev)
+    errs = [rel_err(last[b].cpu(), first[b].cpu()) for b in range(B)]
+    print("[config 2 generation] decode-step logits vs prefill of the extended sequence:", [f"{e:.1e}" for e in errs])
+    assert max(errs) < 2e-3
+    for b in range(B):  # the same token, unless the two leading logits are closer than the paths agree
+        top2 = torch.topk(first[b], 2).values
+        if (top2[0] - top2[1]).item() > 4e-3 * first[b].abs().max().item():
+            assert int(out2[b, 0]) == int(out[b, N - 1]), b
