@@ -205,3 +205,44 @@ def test_config2_full_size_decode_step_equals_prefill_of_the_extended_sequence(g
         top2 = torch.topk(first[b], 2).values
         if (top2[0] - top2[1]).item() > 4e-3 * first[b].abs().max().item():
             assert int(out2[b, 0]) == int(out[b, N - 1]), b
+
+
+@pytest.mark.timeout(900)
+def test_config2_full_size_gradient_is_the_mean_of_per_sample_gradients(gpu, full_model):
+    """The training step's backward (scripts/train.py:1168-1183) at the full model size through a size-independent property:
+    the loss is a mean over the batch and the samples are independent, so the gradient of a two-sample batch is the mean of
+    the two one-sample gradients -- every trainable tensor, computed through different GEMM shapes (M = 512 vs 256 rows in
+    the decoder, 60 vs 30 rows in the head's contractions).  This is also what makes data-parallel averaging exact."""
+    from tcavt_amd import training
+
+    cfg, W, m, t = full_model
+    dev = gpu["device"]
+    keys = ("traj_emb", "vision_emb", "lane_polygon", "lane_polygon_len", "target_traj", "norm_stat", "input_ids",
+            "attention_mask", "labels")
+    flags = (m.pipeline_decoder, m.mllm.skip_f32_hidden)
+    tr = training.Trainer(m, lr=1e-4)
+    try:
+        def grads(rows):
+            g = {k: t[k][rows].contiguous().to(dev) for k in keys}
+            loss, _ = tr.forward_backward(*[g[k] for k in keys])
+            torch.cuda.synchronize()
+            return loss.item(), tr.book.grads.detach().clone()
+
+        l01, g01 = grads(slice(0, 2))
+        l0, g0 = grads(slice(0, 1))
+        l1, g1 = grads(slice(1, 2))
+        mean = 0.5 * (g0 + g1)
+        assert abs(0.5 * (l0 + l1) - l01) / l01 < 1e-4
+        flat = ((g01 - mean).double().norm() / mean.double().norm()).item()
+        worst = 0.0
+        for name in tr.book.names:
+            o, n, _ = tr.book.offsets[name]
+            a, b = g01[o:o + n], mean[o:o + n]
+            if b.abs().max() == 0:
+                assert a.abs().max() == 0, name
+                continue
+            worst = max(worst, rel_err(a.cpu(), b.cpu()))
+        print(f"[config 2 backward] two-sample gradient vs mean of one-sample gradients: flat {flat:.2e}, worst tensor {worst:.2e}")
+        assert torch.isfinite(g01).all() and flat < 1e-3 and worst < 1e-2
+    finally:
+        m.pipeline_decoder, m.mllm.skip_f32_hidden = flags
