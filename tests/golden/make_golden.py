@@ -329,6 +329,127 @@ def run_generation_case(ref):
           f"kept candidates per row {[int(np.isfinite(w).sum()) for w in warped]}")
 
 
+def builder_tracks():
+    """The 64 synthetic tracks of config 1 in the form the reference's `train.py` builder expects them (vision features as
+    torch tensors, train.py:187-193), with the edge cases its branches need: a track whose vision features end before its
+    trajectory does (zero-padded and empty vision windows, :189-192), a track without vision features (:194-195), a track
+    that names an A4 line (dropped by filter_context, :50), one without a lane (dropped, :142-144), one that jumps (dropped
+    by is_trajectory_abnormal), one too short for a window (:152-153)."""
+    tracks = synth.make_tracks(n_tracks=64, n_frames=400, seed=0)
+    for t in tracks:
+        t["vision_embeddings"] = torch.from_numpy(t["vision_embeddings"])
+    tracks[3]["vision_embeddings"] = tracks[3]["vision_embeddings"][:150]   # 30 frames after [::5]
+    del tracks[5]["vision_embeddings"]
+    tracks[7]["context_str"] += "\nA4: a line that excludes the track."
+    tracks[9]["context_str"] = "A1: no lane is named here."
+    tracks[11]["raw_trajectory"] = tracks[11]["raw_trajectory"].copy()
+    tracks[11]["raw_trajectory"][200:, 0] -= 400.0
+    tracks[13]["raw_trajectory"] = tracks[13]["raw_trajectory"][:200]
+    tracks[13]["vision_embeddings"] = tracks[13]["vision_embeddings"][:200]
+    return tracks
+
+
+def sanity_tracks():
+    """Inputs for check_data_sanity: NaN, Inf, a coordinate beyond 1e6, a missing trajectory, a list instead of an array."""
+    tracks = synth.make_tracks(n_tracks=12, n_frames=40, seed=3)
+    for t in tracks:
+        del t["vision_embeddings"]
+    tracks[1]["raw_trajectory"] = tracks[1]["raw_trajectory"].copy()
+    tracks[1]["raw_trajectory"][5, 1] = np.nan
+    tracks[4]["raw_trajectory"] = tracks[4]["raw_trajectory"].copy()
+    tracks[4]["raw_trajectory"][0, 0] = np.inf
+    tracks[6]["raw_trajectory"] = tracks[6]["raw_trajectory"] * 1e4
+    del tracks[8]["raw_trajectory"]
+    tracks[10]["raw_trajectory"] = tracks[10]["raw_trajectory"].tolist()
+    tracks[11]["raw_trajectory"] = tracks[11]["raw_trajectory"].astype(np.float64)
+    tracks[11]["raw_trajectory"][3, 0] = 1e6 + 0.01   # rounds to 1e6 in float32: kept (the reference compares float32 values)
+    return tracks
+
+
+def _reference_function(path, name, namespace):
+    """One top-level function of a reference script that cannot be imported whole (modify_train.py needs `peft`): its
+    definition is compiled from the file where it lies and executed in `namespace`; nothing is copied."""
+    import ast
+
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+    return namespace[name]
+
+
+def run_builder_case(ref):
+    """tests/golden/builder_64tracks.npz -- the `train.py` leg of the dataset builder (scripts/train.py:114-259,
+    264-347; here the byte-identical copy in scripts/ablation_study_without_lora.py:112-330): vision windows with
+    zero padding, prompt / answer tokenisation, labels = -100 on the prompt, truncation to max_length, collate.
+    The tokenizer is tcavt_amd.synth.SyntheticTokenizer (the real one is a network fetch).  Three max_length values:
+    512 (nothing truncated), 120 (prompt + answer cut), 40 (each segment cut, then the total).  Also check_data_sanity
+    (modify_scripts/modify_train.py:26-49) on tracks with NaN / Inf / extreme / missing trajectories, and the wall time
+    of the reference's builder on these tracks."""
+    import time
+
+    tok = synth.SyntheticTokenizer()
+    T, To = 18, 30
+    out = {}
+    ref_time = None
+    for ml in (512, 120, 40):
+        tracks = builder_tracks()
+        t0 = time.perf_counter()
+        ins, outs = ref.build_dataset_from_tracks_sliding(tracks, seq_len=T, out_len=To, stride=6, max_step=50.0,
+                                                          max_speed_diff=30.0, image_width=3840, image_height=2160,
+                                                          downsample=5, tokenizer=tok, max_length=ml)
+        dt = time.perf_counter() - t0
+        if ml == 512:
+            ref_time = dt
+        n = len(ins)
+        lens = np.array([len(s["input_ids"]) for s in ins], np.int64)
+        width = int(lens.max())
+        ids = np.zeros((n, width), np.int64)
+        msk = np.zeros((n, width), np.int64)
+        lab = np.full((n, width), -100, np.int64)
+        for k, s in enumerate(ins):
+            ids[k, :lens[k]], msk[k, :lens[k]], lab[k, :lens[k]] = s["input_ids"], s["attention_mask"], s["labels"]
+        out[f"ml{ml}_len"], out[f"ml{ml}_ids"], out[f"ml{ml}_mask"], out[f"ml{ml}_labels"] = lens, ids, msk, lab
+        if ml != 512:
+            continue
+        out["n_windows"] = np.array(n)
+        out["track_id"] = np.array([s["track_id"] for s in ins])
+        out["norm_stat"] = np.array([s["norm_stat"] for s in ins], np.float64)
+        out["traj_in"] = np.stack([s["trajectory_embeddings"].numpy() for s in ins])
+        out["traj_out"] = np.stack([o.numpy() for o in outs])
+        out["vision_shape"] = np.array([tuple(s["vision_embeddings"].shape) for s in ins], np.int64)
+        # vision windows: float64 sum and three probes per window for all of them, whole windows for a few
+        out["vision_sum"] = np.array([float(s["vision_embeddings"].double().sum()) for s in ins])
+        out["vision_probe"] = np.stack([s["vision_embeddings"].reshape(-1)[[0, 777 % s["vision_embeddings"].numel(), -1]].numpy()
+                                        for s in ins])
+        tids = list(out["track_id"])
+        full_idx = sorted({0, n - 1, tids.index("syn0003"), len(tids) - 1 - tids[::-1].index("syn0003")})
+        out["vision_full_idx"] = np.array(full_idx)
+        out["vision_full"] = np.stack([ins[i]["vision_embeddings"].numpy() for i in full_idx])
+        # dataset + collate on a ragged selection (different polygon lengths and text lengths)
+        ds = ref.MultiModalTrajectoryDataset(ins, outs, max_polygon_points=16)   # 16 < every polygon: the truncation branch
+        sel = list(range(0, n, max(1, n // 8)))[:8]
+        coll = ref.custom_collate_fn([ds[i] for i in sel])
+        out["coll_idx"] = np.array(sel)
+        for k in ("traj_emb", "target_traj", "lane_polygon", "input_ids", "attention_mask", "labels"):
+            out["coll_" + k] = coll[k].numpy()
+        out["coll_lane_polygon_len"] = np.array(coll["lane_polygon_len"])
+        out["coll_vision_sum"] = np.array(float(coll["vision_emb"].double().sum()))
+    # ---- check_data_sanity of the LoRA-trainable script
+    cds = _reference_function("/root/reference/modify_scripts/modify_train.py", "check_data_sanity", {"np": np})
+    st = sanity_tracks()
+    with redirect_stdout(io.StringIO()) as buf:
+        kept = cds(st, max_coord_threshold=1e6)
+    out["sanity_kept"] = np.array([next(i for i, t in enumerate(st) if t is d) for d in kept])
+    out["sanity_printed"] = np.array(buf.getvalue().strip())
+    out["ref_builder_seconds"] = np.array(ref_time)
+    np.savez_compressed(os.path.join(HERE, "builder_64tracks.npz"), **out)
+    print(f"[golden] builder_64tracks: windows={int(out['n_windows'])} text lengths {sorted(set(out['ml512_len'].tolist()))} / "
+          f"{sorted(set(out['ml120_len'].tolist()))} / {sorted(set(out['ml40_len'].tolist()))}; sanity kept "
+          f"{out['sanity_kept'].tolist()} ({out['sanity_printed']}); reference builder {ref_time:.3f} s")
+
+
+
 def run_cv_case():
     """Config 1 (baseline_cv.py): dataset builder + collate + CV predictor + evaluate_cv's printed
     minADE/minFDE/minRMSE on 64 synthetic tracks (pickle written to a temp dir)."""
@@ -394,6 +515,7 @@ def main():
     for case in CASES[:2]:  # the ragged LoRA case and the ragged no-LoRA (train.py) case
         run_train_case(ref, *case)
     run_generation_case(ref)
+    run_builder_case(ref)
     run_cv_case()
 
 

@@ -29,6 +29,25 @@ def split_all_data(all_data, train_ratio=0.7, val_ratio=0.2, test_ratio=0.1):
     return all_data[:a], all_data[a:b], all_data[b:]
 
 
+def check_data_sanity(all_data, max_coord_threshold=1e6, verbose=True):
+    """Tracks whose raw_trajectory is present, finite and within +-max_coord_threshold (as float32), in order
+    (modify_scripts/modify_train.py:26-49, called in front of the split at :1061)."""
+    clean = []
+    for d in all_data:
+        raw = d.get("raw_trajectory", None)
+        if raw is None:
+            continue
+        raw = np.array(raw, dtype=np.float32)
+        if not np.all(np.isfinite(raw)):
+            continue
+        if np.abs(raw).max() > max_coord_threshold:
+            continue
+        clean.append(d)
+    if verbose:
+        print(f"[check_data_sanity] clean_data: {len(clean)} / {len(all_data)}")
+    return clean
+
+
 def filter_context(context):
     """-> (kept A1..A3 lines, direction) or (None, None) when an A4..A6 line is present (train.py:44-65)."""
     if not context.strip():

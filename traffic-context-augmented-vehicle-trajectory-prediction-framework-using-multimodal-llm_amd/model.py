@@ -843,6 +843,16 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
 # --------------------------------------------------------------------------------------
 # LlamaMultiModal (train.py:459-575)
 # --------------------------------------------------------------------------------------
+GENERATION_CUTOFF_MARKER = "No right-following vehicle."
+
+
+def cut_generated_text(text, marker=GENERATION_CUTOFF_MARKER):
+    """Post-processing of generate_batch (scripts/train.py:645-653): everything after the first occurrence of the marker
+    sentence is dropped, the marker itself is kept."""
+    k = text.find(marker)
+    return text if k < 0 else text[:k + len(marker)]
+
+
 class LlamaMultiModal(nn.Module, _Prepared):
     def __init__(self, base_model_name="meta-llama/Llama-3.2-1B", use_lora=True, lora_r=8, lora_alpha=32,
                  lora_dropout=0.1, vision_dim=512, q_hidden_size=768, q_nhead=8, q_enc_layers=4, q_dec_layers=4,
@@ -1089,7 +1099,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
             finally:
                 LW.dctx, LW.save_for_backward = was_dctx, was_saving
         if self.tokenizer is not None:
-            return [self.tokenizer.decode(row, skip_special_tokens=True) for row in out.tolist()]
+            return [cut_generated_text(self.tokenizer.decode(row, skip_special_tokens=True)) for row in out.tolist()]
         return out
 
 

@@ -110,3 +110,59 @@ def make_batch(cfg: ModelConfig, batch: int, text_len: int = 240, seed: int = 0,
         "lane_polygon_len": poly_len, "norm_stat": norm_stat, "input_ids": ids, "attention_mask": mask,
         "labels": labels,
     }
+
+
+class SyntheticTokenizer:
+    """Deterministic stand-in for the HF tokenizer the reference fetches by name (scripts/train.py:1056; no network here).
+
+    Same call surface as the builder uses (train.py:214-229): ``tok(text, truncation=True, max_length=N,
+    return_tensors="pt", add_special_tokens=False)`` -> ``{"input_ids": (1,n) int64, "attention_mask": (1,n) int64}``,
+    plus ``decode(ids, skip_special_tokens=True)``, ``pad_token`` / ``eos_token`` and their ids.  Pieces are words,
+    digit runs and single punctuation marks; a piece's id is a CRC of its bytes folded into [2, vocab) (0 = pad, 1 = eos),
+    so ids are stable across processes and Python versions.  ``decode`` returns the pieces it has seen for the ids
+    (unknown ids print as ``<id>``): enough for the marker cut-off of ``generate_batch`` to be exercised end to end."""
+
+    pad_token, eos_token = "<pad>", "<eos>"
+    pad_token_id, eos_token_id = 0, 1
+
+    def __init__(self, vocab=128256):
+        import re
+
+        self.vocab = int(vocab)
+        self._split = re.compile(r"[A-Za-z_]+|[0-9]+|\s+|[^\sA-Za-z0-9_]")
+        self._seen = {}
+
+    def piece_id(self, piece):
+        import zlib
+
+        i = 2 + zlib.crc32(piece.encode("utf-8")) % (self.vocab - 2)
+        self._seen.setdefault(i, piece)
+        return i
+
+    def encode(self, text):
+        return [self.piece_id(p) for p in self._split.findall(text) if not p.isspace()]
+
+    def __call__(self, text, truncation=False, max_length=None, return_tensors=None, add_special_tokens=False, **kw):
+        import torch
+
+        ids = self.encode(text)
+        if truncation and max_length is not None:
+            ids = ids[:max_length]
+        t = torch.tensor([ids], dtype=torch.long).reshape(1, len(ids))
+        return {"input_ids": t, "attention_mask": torch.ones_like(t)}
+
+    def decode(self, ids, skip_special_tokens=True):
+        out = []
+        for i in (int(v) for v in ids):
+            if skip_special_tokens and i in (self.pad_token_id, self.eos_token_id):
+                continue
+            out.append(self._seen.get(i, f"<{i}>"))
+        # words are joined with blanks, punctuation attaches to the piece before it
+        text = ""
+        for p in out:
+            text += p if (not text or (len(p) == 1 and not p.isalnum())) else " " + p
+        return text
+
+    @classmethod
+    def from_pretrained(cls, name, **kw):
+        return cls()
