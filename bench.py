@@ -492,6 +492,52 @@ def main():
         torch.cuda.synchronize()
         clock = tele.stop()
 
+        # ---- data-parallel self-diagnosis (world > 1; un-timed repeats of the same steps): what the first multi-GPU run needs
+        # to check the overlap claims of DESIGN section 6 instead of arguing them -- (i) the same build's step time with the
+        # gradient exchange switched off (the N = 1 figure on this very card, all ranks running it at once), (ii) how long
+        # every bucket's all-reduce held its launching stream, (iii) busy / idle time of the MLLM stream per step, (iv) the
+        # number of HIP streams a rank uses (the five-stream budget)
+        dp_diag = None
+        if world > 1 and trainer is not None and graph is None:
+            n_diag = max(5, min(args.steps, 20))
+
+            def timed_loop(n):
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    run_step()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / n * 1e3
+
+            trainer.exchange = False
+            run_step()
+            ms_no_exchange = timed_loop(n_diag)
+            trainer.exchange = True
+            run_step()
+            trainer.enable_diagnostics(True)
+            m.pipe_trace = [] if m.pipeline_decoder else None
+            ms_diag = timed_loop(n_diag)
+            d = trainer.diagnostics()
+            trainer.enable_diagnostics(False)
+            ev, m.pipe_trace = m.pipe_trace, None
+            pipe = None
+            if ev:
+                busy = [a.elapsed_time(b_) for a, b_ in ev]
+                idle = [ev[i][1].elapsed_time(ev[i + 1][0]) for i in range(len(ev) - 1)] or [0.0]
+                pipe = {"mllm_pass_busy_ms": round(sum(busy) / len(busy), 3), "mllm_idle_between_passes_ms": round(sum(idle) / len(idle), 3),
+                        "mllm_idle_max_ms": round(max(idle), 3), "passes": len(busy)}
+            loc = torch.tensor([ms_no_exchange, ms_diag], dtype=torch.float64, device=dev)
+            dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+            dp_diag = dict(d, ms_per_step_exchange_off=round(loc[0].item(), 3), ms_per_step_with_event_timing=round(loc[1].item(), 3),
+                           steps=n_diag, mllm_stream=pipe, backend=args.backend,
+                           note="rank 0's buckets and stream trace; step times are MAX over ranks between barriers; "
+                                "exchange_off = the same build and card without the gradient all-reduce (the N = 1 step)")
+            log(f"dp diagnostics: {dp_diag}")
+
     if trainer is not None:
         trainer.release_graph()
     if world > 1:
@@ -577,6 +623,8 @@ def main():
             "loss_first_step": round(first_loss, 3), "loss_last_timed_step": round(loss_timed, 3),
             "peak_device_memory_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
         }
+        if dp_diag is not None:
+            out["dp_diagnostics"] = dp_diag
         if not args.no_cpu_baseline and world >= 1:
             out["cpu_baseline"] = cpu_baseline(cfg, args, gpu_decoded=parity_dec, W=W_cpu) if args.gpus == 1 or world == 1 else None
             if out["cpu_baseline"]:

@@ -34,7 +34,7 @@ extern "C" {
 
 typedef void* tcavt_stream_t; /* hipStream_t */
 
-#define TCAVT_ABI_VERSION 2
+#define TCAVT_ABI_VERSION 3
 
 #define TCAVT_OK 0
 #define TCAVT_ERR_ARG 1  /* shape / alignment / null-pointer contract violated */
@@ -156,6 +156,14 @@ typedef struct tcavt_gemm_args {
   /* TCAVT_EPI_ROPE, optional: int32 [M] device array, the position of row m (a decode step has one row per sample, each
    * at its own position; cos / sin tables then hold rope_L >= max position + 1 rows).  NULL: position = m % rope_L */
   const int32_t* rope_pos;
+  /* TCAVT_EPI_NORM_OUT, optional: device int32 word that receives `nonfinite_tag` (compare-and-swap from 0: the first
+   * launch that sees one wins) when a partial sum of squares of the rows it writes is not finite, or -- fp16 16-bit copy of
+   * an fp32 stream -- when a rounded element is +-inf.  This is how an fp16 overflow anywhere upstream (the stream itself,
+   * `act`, q|k|v, attention output) becomes observable: it reaches the next residual epilogue as inf / NaN.  Only ever
+   * SET by the kernels; the host reads and clears it (LlamaMultiModal.check_flags).  NULL: no check. */
+  int32_t* nonfinite_flag;
+  int32_t nonfinite_tag;
+  int32_t reserved2;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -532,6 +540,10 @@ typedef struct tcavt_llama_stack_args {
   float lora_dropout_p;            /* > 0: train mode; sites first_site + 2 l (q_proj), first_site + 2 l + 1 (v_proj) */
   uint32_t lora_first_site;
   uint64_t dropout_seed;
+  /* optional: device int32 word; a residual epilogue that produces a non-finite value stores 1 + 2 * layer (o_proj) or
+     2 + 2 * layer (down_proj) into it if it is still 0 (tcavt_gemm_args.nonfinite_flag): the first layer whose output left
+     the 16-bit range, or whose inputs already had */
+  int32_t* nonfinite_flag;
 } tcavt_llama_stack_args;
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
@@ -828,6 +840,7 @@ typedef struct tcavt_decode_args {
   int32_t* bad_id_flag;
   int32_t n_layers, B, H, I, nq, nkv, V, dtype16, kv_lmax, rope_L;
   float rms_eps, lora_scale;
+  int32_t* nonfinite_flag;         /* optional, as tcavt_llama_stack_args.nonfinite_flag */
 } tcavt_decode_args;
 
 int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);

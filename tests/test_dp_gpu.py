@@ -53,7 +53,22 @@ def _worker(rank, world, port, case, outdir):
         torch.cuda.set_device(0)
         tr, grads, params, loss = _step(case, slice(rank, rank + 1), torch.device("cuda", 0))
         assert tr.world == world
-        torch.save({"grads": grads, "params": params, "loss": loss}, os.path.join(outdir, f"rank{rank}.pt"))
+        # self-diagnosis of a data-parallel rank (bench.py's dp_diagnostics): per-bucket all-reduce timings + stream budget
+        cfg, weights, fx = load_case(case)
+        g = {k: v[rank:rank + 1].contiguous().to("cuda:0") for k, v in batch_tensors(fx).items()}
+        tr.enable_diagnostics(True)
+        tr.forward_backward(*[g[k] for k in ARGS])
+        torch.cuda.synchronize()
+        d = tr.diagnostics()
+        tr.enable_diagnostics(False)
+        assert sum(b["bytes"] for b in d["buckets"]) == 4 * tr.book.total and all(b["launches"] == 1 and b["mean_ms"] >= 0 for b in d["buckets"])
+        assert d["hip_streams_in_use"] <= 5, d  # the five-stream budget of the pipelined step
+        tr.exchange = False  # the same-build single-rank comparison leg: gradients stay local
+        tr.forward_backward(*[g[k] for k in ARGS])
+        torch.cuda.synchronize()
+        local = tr.book.grads.detach().clone().cpu()
+        tr.exchange = True
+        torch.save({"grads": grads, "params": params, "loss": loss, "diag": d, "local": local}, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -69,6 +84,8 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(gpu, case, tmp_pa
     assert torch.equal(r0["grads"], r1["grads"])
     assert torch.equal(r0["params"], r1["params"])
     assert r0["loss"] != r1["loss"]  # (they did see different samples)
+    assert not torch.equal(r0["local"], r1["local"])  # exchange switched off: every rank keeps its own gradient
+    assert [b["bytes"] for b in r0["diag"]["buckets"]] == [b["bytes"] for b in r1["diag"]["buckets"]]
     # ... and that is what one process computes on both samples (the loss is a mean over the batch: MEAN of the ranks' gradients)
     tr, g_full, p_full, loss_full = _step(case, slice(0, world), gpu["device"])
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - loss_full) / loss_full < 1e-4

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import GOLDEN, batch_tensors, load_case, rel_err
+from tests.util import GOLDEN, load_generation_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -16,9 +16,7 @@ pytestmark = pytest.mark.gpu
 def _setup(dev):
     from tcavt_amd import model
 
-    fx = dict(np.load(os.path.join(GOLDEN, "tiny_generation.npz"), allow_pickle=False))
-    cfg, weights, case = load_case(str(fx["case"]))
-    t = batch_tensors(case)
+    fx, cfg, weights, t = load_generation_case()
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
     g = {k: v.to(dev) for k, v in t.items()}
     return fx, cfg, weights, t, g, m
@@ -34,7 +32,7 @@ def test_greedy_tokens_match_reference_model(gpu, use_graph):
     torch.cuda.synchronize()
     m.mllm.check_flags()
     assert out.dtype == torch.int64 and tuple(out.shape) == fx["greedy_tokens"].shape
-    assert np.array_equal(out.cpu().numpy(), fx["greedy_tokens"])  # plain arg-max (margins >= 1.5 in the fixture)
+    assert np.array_equal(out.cpu().numpy(), fx["greedy_tokens"])  # plain arg-max: >= 7 distinct tokens per sample, margins >= 0.1
     # the reference's processors in greedy mode: repetition penalty 1.2 + no-repeat-3-gram (train.py:639-640)
     out2 = m.mllm.generate_batch(g["vision_emb"], None, max_new_tokens=N, input_ids=g["input_ids"],
                                  attention_mask=g["attention_mask"], do_sample=False, repetition_penalty=1.2,

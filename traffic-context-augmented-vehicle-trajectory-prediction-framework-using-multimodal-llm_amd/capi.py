@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtcavt_hip.so")
 if os.environ.get("TCAVT_LIB") == "exp":  # tools/ only: the -DTCAVT_EXPERIMENTS build (python -m tcavt_amd.build --experiments)
     LIB_PATH = os.path.join(_HERE, "libtcavt_hip_exp.so")
 
-ABI_VERSION = 2  # TCAVT_ABI_VERSION of include/tcavt.h
+ABI_VERSION = 3  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_NORM_OUT, EPI_ROWSCALE = 128, 256
@@ -55,6 +55,7 @@ class GemmArgs(ctypes.Structure):
         ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
         ("reserved1", ctypes.c_int32),
         ("rope_pos", c_void_p),
+        ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
 
 
@@ -158,6 +159,7 @@ class LlamaStackArgs(ctypes.Structure):
         ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32), ("npart_in", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
         ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
+        ("nonfinite_flag", c_void_p),
     ]
 
 
@@ -176,7 +178,7 @@ class DecodeArgs(ctypes.Structure):
         "gamma_final", "rope_cos", "rope_sin", "table", "txt_mod", "cur_tok", "pos", "h", "h16", "part", "qkv", "att", "act",
         "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
-        ("rms_eps", c_float), ("lora_scale", c_float)]
+        ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)

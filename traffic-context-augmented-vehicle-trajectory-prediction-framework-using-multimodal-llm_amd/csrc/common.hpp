@@ -84,6 +84,11 @@ __device__ __forceinline__ float from16_lo(unsigned int w) { return from16<F16>(
 template <bool F16>
 __device__ __forceinline__ float from16_hi(unsigned int w) { return from16<F16>(static_cast<bf16_t>(w >> 16)); }
 
+// nonzero when either half of a packed fp16 pair is +-inf or NaN (exponent field all ones)
+__device__ __forceinline__ unsigned int half_is_inf2(unsigned int w) {
+  return (unsigned)((w & 0x7C00u) == 0x7C00u) | (unsigned)((w & 0x7C000000u) == 0x7C000000u);
+}
+
 static inline bool is16(int dtype) { return dtype == TCAVT_BF16 || dtype == TCAVT_F16; }
 
 // tcavt_gemm_bf16 runs its skinny form (csrc/gemm_bf16.hip) for these shapes when no tile is forced ...

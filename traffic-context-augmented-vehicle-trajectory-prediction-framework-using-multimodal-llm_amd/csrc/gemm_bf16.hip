@@ -58,7 +58,14 @@ struct GemmP {
   int rs_npart;
   float rs_eps, rs_inv_h;
   const int* rope_pos;    // ROPE: position of row m (decode step: one row per sample); NULL: m % rope_L
+  int* nf_flag;           // NORM_OUT: receives nf_tag (CAS from 0) when a partial sum / rounded element is not finite
+  int nf_tag;
 };
+
+// a non-finite partial sum of squares (inf: a rounded element overflowed; NaN: inf / NaN came in from upstream)
+__device__ __forceinline__ void flag_nonfinite(const GemmP& p, float ss) {
+  if (p.nf_flag && !(ss <= 3.0e38f)) atomicCAS(p.nf_flag, 0, p.nf_tag);
+}
 
 // 1 / rms of row m from its partial sums of squares, added in index order (bit-reproducible; rs_npart % 4 == 0)
 __device__ __forceinline__ float row_rscale(const GemmP& p, long m) {
@@ -214,7 +221,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           }
           ss += __shfl_xor(ss, 16, 64);
           ss += __shfl_xor(ss, 32, 64);
-          if (lane < 16 && rowok && colok) p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+          if (lane < 16 && rowok && colok) {
+            p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+            flag_nonfinite(p, ss);
+          }
         }
       }
       return;
@@ -241,6 +251,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         const long mm = rowok ? m : 0;  // (rows beyond M read row 0 and store nothing: the shuffles below need every lane)
         float* crow = reinterpret_cast<float*>(p.C) + mm * p.ldc + n_base + nq;
         bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
+        unsigned ovf = 0u;
 #pragma unroll
         for (int g = 0; g < TN / 4; ++g) {
           const bool colok = WHOLE_ONLY || n_base + g * 64 < p.N;  // (N % 64 == 0: a group is inside or outside)
@@ -248,10 +259,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
 #pragma unroll
           for (int i = g * 4; i < g * 4 + 4; ++i) {
             const f32x4 v = acc[i][j] + rv[j][i];
+            const u32x2 w = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
             if (rowok && colok) {
               *reinterpret_cast<f32x4*>(crow + i * 16) = v;
-              *reinterpret_cast<u32x2*>(hrow + i * 16) = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(hrow + i * 16) = w;
             }
+            if constexpr (F16) ovf |= half_is_inf2(w[0]) | half_is_inf2(w[1]);  // the fp32 value may be fine, its fp16 copy not
             ss += v[0] * v[0];
             ss += v[1] * v[1];
             ss += v[2] * v[2];
@@ -259,8 +272,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           }
           ss += __shfl_xor(ss, 16, 64);
           ss += __shfl_xor(ss, 32, 64);
-          if (lane < 16 && rowok && colok) p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+          if (lane < 16 && rowok && colok) {
+            p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+            flag_nonfinite(p, ss);
+          }
         }
+        if (F16 && ovf && rowok && p.nf_flag) atomicCAS(p.nf_flag, 0, p.nf_tag);
       }
       return;
     }
@@ -1614,7 +1631,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     }
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
-    if (lane < 16 && rowok) p.norm_part[(long)m * gridDim.x + blockIdx.x] = ss;
+    if (lane < 16 && rowok) {
+      p.norm_part[(long)m * gridDim.x + blockIdx.x] = ss;
+      flag_nonfinite(p, ss);
+    }
   } else if constexpr (EPI == EPI_SILU) {
     static_assert(EPI != EPI_SILU || NCB == 2, "gate block + up block");
     if (!rowok) return;
@@ -1736,6 +1756,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.xcd_gx = 8;
   p.norm_h16 = nullptr;
   p.norm_part = nullptr;
+  p.nf_flag = (epi & TCAVT_EPI_NORM_OUT) ? a->nonfinite_flag : nullptr;
+  p.nf_tag = a->nonfinite_tag;
   p.rs_part = nullptr;
   p.rope_pos = (epi & TCAVT_EPI_ROPE) ? a->rope_pos : nullptr;
   p.rs_npart = 0;

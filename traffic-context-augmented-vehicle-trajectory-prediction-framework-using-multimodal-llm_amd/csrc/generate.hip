@@ -536,6 +536,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.M = B; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {
@@ -552,6 +553,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.M = B; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
   }

@@ -199,6 +199,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.M = M; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;  // (stream16: C = residual = NULL)
       g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       ev.rec(4);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
       ev.rec(5);
@@ -222,6 +223,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.M = M; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.residual = h_mid; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       ev.rec(8);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
       ev.rec(9);

@@ -719,7 +719,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         """Partials per row the first fused norm of a pass over M rows reads (what embed_fuse / rownorm_prep must write)."""
         return ops.norm_npart(M, self.shape.hidden, self.shape.inter)
 
-    def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None, kv_cache=None):
+    def decoder_stack(self, h, kv_len, B, L, out_f32=None, out_bf16=None, kv_cache=None, nonfinite_flag=None):
         """h: fp32 [B*L, H] residual stream (updated in place unless a tape is kept), or None with ``stream16`` (the stream
         is norm_inputs()[0]); norm_inputs() must have been filled; kv_len int32 [B].  One C call: tcavt_llama_stack_forward (csrc/stack.hip).  kv_cache = (k, v, lmax):
         16-bit [layers, B, lmax, nkv*64] tensors that receive the rotated keys / values (generation prefill)."""
@@ -786,6 +786,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         args.h = None if h is None else h.data_ptr()
         args.h16, args.part, args.kv_len = h16.data_ptr(), part.data_ptr(), kv_len.data_ptr()
         args.att, args.act = att.data_ptr(), act.data_ptr()
+        if nonfinite_flag is not None:  # int32 [1]: 1 + 2 * layer (o_proj) / 2 + 2 * layer (down_proj) of the first non-finite epilogue
+            if nonfinite_flag.dtype != torch.int32 or nonfinite_flag.numel() < 1:
+                raise capi.TcavtError("decoder_stack.nonfinite_flag: int32 [1] required")
+            args.nonfinite_flag = nonfinite_flag.data_ptr()
+            keep.append(nonfinite_flag)
         for t_, nm, n_ in ((out_f32, "out_f32", M * H), (out_bf16, "out_bf16", M * H), (kv_len, "kv_len", B), (h, "h", M * H)):
             if t_ is not None and t_.numel() < n_:
                 raise capi.TcavtError(f"decoder_stack.{nm}: buffer has {t_.numel()} elements, the stack needs {n_}")
@@ -949,7 +954,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         h = None if LW.stream16 else ws.get("mm.h", (B * L, H), torch.float32, dev)
         # error flags: the kernels only ever SET them, so they accumulate over forwards until check_flags() reads and
         # clears them (evaluate_model and Trainer.check_flags do; one host sync, off the hot path)
-        flags = ws.get("mm.flags", (2,), torch.int32, dev, zero=True)
+        flags = ws.get("mm.flags", (3,), torch.int32, dev, zero=True)
         h16, part = LW.norm_inputs(B * L, dev)
         ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part,
                        npart=LW.norm_npart(B * L))
@@ -965,10 +970,10 @@ class LlamaMultiModal(nn.Module, _Prepared):
             # the head reads the 16-bit copy only: skip the fp32 hidden_states[-1] (67 MB written by the final norm on the
             # decoder's critical path); the 16-bit tensor stands in for it (shape carrier)
             final = final_b[: B * L].view(B, L, H)
-            LW.decoder_stack(h, kv_len, B, L, out_bf16=final_b)
+            LW.decoder_stack(h, kv_len, B, L, out_bf16=final_b, nonfinite_flag=flags[2:3])
         else:
             final = torch.empty((B, L, H), dtype=torch.float32, device=dev)
-            LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b)
+            LW.decoder_stack(h, kv_len, B, L, out_f32=final.view(B * L, H), out_bf16=final_b, nonfinite_flag=flags[2:3])
         self._last_flags = flags
         if return_bf16:
             return final, Nq, final_b
@@ -984,6 +989,12 @@ class LlamaMultiModal(nn.Module, _Prepared):
             raise ValueError("input_ids contains ids outside [0, vocab)")
         if f[1]:
             raise ValueError("attention_mask must be right-padded (a prefix of ones per row)")
+        if len(f) > 2 and f[2]:
+            layer, site = (f[2] - 1) // 2, ("o_proj" if (f[2] - 1) % 2 == 0 else "down_proj")
+            raise FloatingPointError(
+                f"non-finite value in the decoder's residual stream, first seen in the {site} epilogue of layer {layer}: a 16-bit "
+                f"operand left the range of {self.storage} (|x| > {torch.finfo(self.storage).max:g}) at or before that layer, or the "
+                "inputs were not finite (DESIGN.md, precision contract)")
 
     def generate_batch(self, vision_embs_batch, context_str_list=None, max_new_tokens=50, input_ids=None,
                        attention_mask=None, do_sample=True, temperature=0.9, top_k=40, top_p=0.9, repetition_penalty=1.2,
@@ -1031,7 +1042,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 # ---- prefill: image tokens + prompt through the decoder, keys / values of every layer into the cache
                 img = self._image_tokens(vision_embs_batch)
                 h = None if LW.stream16 else ws.get("gen.h", (B * L, H), torch.float32, dev)
-                flags = ws.get("mm.flags", (2,), i32, dev, zero=True)
+                flags = ws.get("mm.flags", (3,), i32, dev, zero=True)
                 h16, part = LW.norm_inputs(B * L, dev)
                 ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part, npart=LW.norm_npart(B * L))
                 kv_len = ws.get("gen.kvlen", (B,), i32, dev)
@@ -1040,7 +1051,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 kc = ws.get("gen.kc", (ll.layers, B, Lmax, nkvw), st, dev)
                 vc = ws.get("gen.vc", (ll.layers, B, Lmax, nkvw), st, dev)
                 final16 = ws.get("gen.final16", (B * L, H), st, dev)
-                LW.decoder_stack(h, kv_len, B, L, out_bf16=final16, kv_cache=(kc, vc, Lmax))
+                LW.decoder_stack(h, kv_len, B, L, out_bf16=final16, kv_cache=(kc, vc, Lmax), nonfinite_flag=flags[2:3])
                 x16 = ws.get("gen.x16", (B, H), st, dev)
                 ops.gather_last(final16, kv_len, x16, B, L, H)
                 logits = ws.get("gen.logits", (B, ll.vocab), torch.float32, dev)
@@ -1076,6 +1087,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     a.cur_tok, a.pos = cur.data_ptr(), pos.data_ptr()
                     a.k_cache, a.v_cache, a.kv_lmax = kc.data_ptr(), vc.data_ptr(), Lmax
                     a.x16, a.logits, a.bad_id_flag = x16.data_ptr(), logits.data_ptr(), flags.data_ptr()
+                    a.nonfinite_flag = flags[2:3].data_ptr()
                     a.n_layers, a.B, a.H, a.I, a.nq, a.nkv, a.V = ll.layers, B, H, ll.inter, ll.n_q_heads, ll.n_kv_heads, ll.vocab
                     a.dtype16 = capi.F16 if st == torch.float16 else capi.BF16
                     a.rms_eps, a.lora_scale = ll.rms_eps, (LW.lora_alpha / LW.lora_r) if LW.use_lora else 0.0

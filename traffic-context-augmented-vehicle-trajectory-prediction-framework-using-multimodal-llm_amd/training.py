@@ -123,6 +123,8 @@ class Trainer:
             model._side = model.ltsf._kv_stream = model.mllm._pf_stream = None  # (re-drawn from the pool on next use)
             if self.world == 1:
                 self._fake_dp = torch.cuda.Stream(device=dev)
+        self.exchange = True   # False: skip the gradient exchange (bench.py's same-build single-rank comparison leg)
+        self.diag = None       # enable_diagnostics(): per-bucket all-reduce timings of the steps that follow
         self._ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # device-side step counters of the gated optimizer
         self._last_loss = None
         # hipGraph replay of the whole step (capture()): the optimizer's step count and the dropout epoch live on the device
@@ -151,9 +153,18 @@ class Trainer:
         """SUM all-reduce of grads[lo:hi], launched from the current stream (the one that completed the bucket); the mean is
         taken by the clip / AdamW kernels.  torch.distributed runs it on the process group's own RCCL stream, ordered after
         the current stream, and makes the current stream wait for it."""
-        if self.world == 1 and self._fake_dp is None:
+        if (self.world == 1 and self._fake_dp is None) or not self.exchange:
             return
         view = self.book.grads[lo:hi]
+        if self.diag is not None and self._fake_dp is None:
+            # events on the LAUNCHING stream around the collective: torch runs it on the process group's RCCL stream and makes
+            # this stream wait for it, so stop - start = how long the exchange held this stream (queueing included)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(view, group=self.pg)
+            e1.record()
+            self.diag.append((int(lo), int(hi), e0, e1))
+            return
         if self._fake_dp is not None:  # tools: the stream choreography of an RCCL collective, an in-place kernel in its place
             cur = torch.cuda.current_stream()
             self._fake_dp.wait_stream(cur)
@@ -318,6 +329,29 @@ class Trainer:
         """(applied, skipped) updates of the gated optimizer (one host sync)."""
         c = self._ctl.tolist()
         return (c[0], c[1]) if (self.skip_nonfinite or self.device_step) else (self.step_count, 0)
+
+    def enable_diagnostics(self, on=True):
+        """Data-parallel self-diagnosis (bench.py, world > 1): record HIP events around every bucket's all-reduce."""
+        self.diag = [] if on else None
+
+    def diagnostics(self):
+        """-> per-bucket {first element, bytes, launches, mean / max ms the exchange held the launching stream} of the steps run
+        since enable_diagnostics() (call after a device synchronisation), and the number of HIP streams this rank uses."""
+        from . import streams as S
+
+        buckets = {}
+        for lo, hi, e0, e1 in (self.diag or []):
+            b = buckets.setdefault((lo, hi), [])
+            b.append(e0.elapsed_time(e1))
+        m = self.model
+        n_streams = 1 + (S._ACTIVE or S.N_SLOTS) + (1 if getattr(m, "pipeline_decoder", False) else 0) + (1 if self.world > 1 else 0)
+        return {
+            "buckets": [{"first_element": lo, "bytes": 4 * (hi - lo), "launches": len(v), "mean_ms": round(sum(v) / len(v), 4),
+                         "max_ms": round(max(v), 4)} for (lo, hi), v in sorted(buckets.items())],
+            "hip_streams_in_use": n_streams,
+            "hip_streams_note": "caller's stream + side-channel pool" + (" + MLLM stream" if getattr(m, "pipeline_decoder", False) else "")
+                                + (" + the process group's RCCL stream" if self.world > 1 else ""),
+        }
 
     def check_flags(self):
         """Raise if any forward since the last check saw input_ids outside the vocabulary or a mask that is not a
