@@ -253,7 +253,7 @@ def test_config2_full_size_gradient_is_the_mean_of_per_sample_gradients(gpu, ful
     tr = training.Trainer(m, lr=1e-4)
     try:
         flat, worst = _gradient_linearity(tr, t, gpu["device"], "train.py set")
-        assert flat < 1e-3 and worst < 1e-2
+        assert flat < 6e-4 and worst < 5e-3  # 3 x the measured 1.9e-4 / 1.7e-3
     finally:
         m.pipeline_decoder, m.mllm.skip_f32_hidden = flags
 
@@ -272,6 +272,6 @@ def test_config2_full_size_lora_gradient_is_the_mean_of_per_sample_gradients(gpu
     m2.load_weights(W).eval()
     tr = training.Trainer(m2, lr=1e-4, lora_trainable=True, train_mllm_front=True)
     flat, worst = _gradient_linearity(tr, t, dev, "modify_train.py set")
-    assert flat < 5e-3 and worst < 5e-2  # (bf16 tapes: the two batch shapes round differently)
+    assert flat < 5e-3 and worst < 1.8e-2  # 3 x the measured 1.8e-3 / 6.0e-3 (16-bit tapes: the two batch shapes round differently)
     del tr, m2
     torch.cuda.empty_cache()
