@@ -116,7 +116,9 @@ typedef struct tcavt_gemm_args {
   int32_t tile;                  /* 0 = auto (recommended).  Forcing a kernel form (all forms give bit-identical results):
                                     64 / 128 = small-launch kernels (4-stage pipeline), 256 = 8-wave 256x256,
                                     257 = 4-wave 256x256 (whole tiles only), 271 = 4-wave 256x192 (N % 192 == 0),
-                                    272 = 4-wave two-barrier deep-prefetch form (long K).  Any other code is refused by
+                                    272 = 4-wave two-barrier deep-prefetch form (long K).  The 4-wave forms write their SILU_MUL / ROPE /
+                                    in-place NORM_OUT results with 16-byte accesses: 16-bit output of the operand type and
+                                    ldc % 8 == 0 (refused otherwise; auto picks the 8-wave form).  Any other code is refused by
                                     the product library (measured-and-rejected variants and timing experiments live in
                                     the -DTCAVT_EXPERIMENTS build that tools/ makes for itself) */
   float acc_scale;               /* accumulator is multiplied by this first; 0 means 1 */

@@ -54,6 +54,11 @@ def test_gemm_w4_matches_8wave(gpu, K):
         for dt in (torch.float32, torch.bfloat16):
             r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
             for code in (257, 271, 272):  # 256x256 (2x2 waves), 256x192 (4x1 waves; N = 768 = 4 x 192), two-barrier deep-prefetch form
+                if kw.get("silu_mul") and dt == torch.float32:
+                    # the 4-wave kernel's SiLU epilogue exists for the 16-bit operand type only (16-byte stores): refused
+                    with pytest.raises(Exception):
+                        ops.gemm_bf16(a, w, out_dtype=dt, tile=code, **kw)
+                    continue
                 r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=code, **kw)
                 assert torch.equal(r8, r4), (code, sorted(kw), dt)
     # fused q|k|v form: RoPE epilogue (bf16 out) with and without the LoRA second K source

@@ -15,13 +15,15 @@ pytestmark = pytest.mark.gpu
 CASE = "tiny_6_12_lora_ragged"
 
 
-def _model(dev, scale_key=None, scale=1.0):
+def _model(dev, scales=None):
     from tcavt_amd import model
 
     cfg, weights, fx = load_case(CASE)
-    if scale_key is not None:
+    if scales:
         weights = dict(weights)
-        weights[scale_key] = weights[scale_key] * np.float32(scale)
+        for k, sc in scales.items():
+            weights[k] = weights[k] * np.float32(sc)
+            assert np.abs(weights[k]).max() < 65504 / 4  # the WEIGHTS stay well inside the range
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
     g = {k: v.to(dev) for k, v in batch_tensors(fx).items()}
     return cfg, m, g
@@ -48,14 +50,21 @@ def test_clean_model_raises_nothing_and_reports_its_range(gpu):
     assert h16.float().abs().max().item() < 65504 / 16
 
 
+def _overflow_scales(layer, site):
+    """Both operands of the projection stay finite in fp16 (weights |w| < 16 376 asserted in _model; `act` ~ 3e2 and the
+    attention output ~ 3e1), its OUTPUT -- a sum of 128 ... 256 such products added to the stream -- leaves the range."""
+    from tcavt_amd.weights import LLAMA_PREFIX
+
+    L = f"{LLAMA_PREFIX}layers.{layer}."
+    if site == "down_proj":
+        return {L + "mlp.down_proj.weight": 2e4, L + "mlp.up_proj.weight": 1e3}
+    return {L + "self_attn.o_proj.weight": 2e4, L + "self_attn.v_proj.weight": 1e2}
+
+
 @pytest.mark.parametrize("layer,site", [(0, "down_proj"), (1, "o_proj"), (1, "down_proj")])
 @pytest.mark.parametrize("with_loss", [True, False])
 def test_overflowing_layer_is_named(gpu, layer, site, with_loss):
-    from tcavt_amd.weights import LLAMA_PREFIX
-
-    key = f"{LLAMA_PREFIX}layers.{layer}." + ("mlp.down_proj.weight" if site == "down_proj" else "self_attn.o_proj.weight")
-    # weights stay finite in fp16 (|w| ~ 0.06 * 3e5 < 65504); the projection's OUTPUT leaves the range
-    cfg, m, g = _model(gpu["device"], key, 3e5)
+    cfg, m, g = _model(gpu["device"], _overflow_scales(layer, site))
     with torch.no_grad():
         out = _fwd(m, g, with_loss)
         torch.cuda.synchronize()
@@ -79,8 +88,7 @@ def test_evaluate_model_checks_the_flag(gpu):
     """evaluate_model ends with check_flags(): an overflow in ANY batch of the loop is reported (no loss to go non-finite on
     the y=None branch it runs)."""
     from tcavt_amd import evaluate
-    from tcavt_amd.weights import LLAMA_PREFIX
 
-    cfg, m, g = _model(gpu["device"], f"{LLAMA_PREFIX}layers.0.mlp.down_proj.weight", 3e5)
+    cfg, m, g = _model(gpu["device"], _overflow_scales(0, "down_proj"))
     with pytest.raises(FloatingPointError):
         evaluate.evaluate_model(m, [g], num_candidates=1)

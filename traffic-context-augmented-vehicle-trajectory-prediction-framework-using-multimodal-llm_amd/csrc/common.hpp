@@ -60,7 +60,10 @@ __device__ __forceinline__ float f16_to_f32(bf16_t v) {
   return static_cast<float>(__builtin_bit_cast(_Float16, v));
 }
 __device__ __forceinline__ unsigned int pack_f16x2(float lo, float hi) {
-  return static_cast<unsigned int>(f32_to_f16(lo)) | (static_cast<unsigned int>(f32_to_f16(hi)) << 16);
+  // one v_cvt_pk_f16_f32 (round-to-nearest-even, overflow -> inf): two scalar casts + shift/or were 3 instructions per pair
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f2_t{lo, hi}, h2_t));
 }
 // 16-bit storage type chosen at compile time: F16 = IEEE half, otherwise bf16 (raw storage is `bf16_t` = uint16 either way)
 template <bool F16>
@@ -88,6 +91,10 @@ __device__ __forceinline__ float from16_hi(unsigned int w) { return from16<F16>(
 __device__ __forceinline__ unsigned int half_is_inf2(unsigned int w) {
   return (unsigned)((w & 0x7C00u) == 0x7C00u) | (unsigned)((w & 0x7C000000u) == 0x7C000000u);
 }
+
+// ReLU as torch computes it: NaN stays NaN (fmaxf(NaN, 0) = 0 would turn an upstream overflow into finite garbage -- the
+// LTSF head's fusion layer is LN -> Linear -> ReLU -> Linear, so a NaN from the decoder would come out as a finite trajectory)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
 
 static inline bool is16(int dtype) { return dtype == TCAVT_BF16 || dtype == TCAVT_F16; }
 

@@ -71,12 +71,22 @@ __device__ __forceinline__ void flag_nonfinite(const GemmP& p, float ss) {
 __device__ __forceinline__ float row_rscale(const GemmP& p, long m) {
   const f32x4* q = reinterpret_cast<const f32x4*>(p.rs_part + m * p.rs_npart);
   float ss = 0.f;
-  for (int i = 0; i < (p.rs_npart >> 2); ++i) {
-    const f32x4 v = q[i];
-    ss += v[0];
-    ss += v[1];
-    ss += v[2];
-    ss += v[3];
+  const int nq = p.rs_npart >> 2;
+  // eight quads (H = 2048: all of them) in flight together -- one load per step, each waited for, was eight dependent
+  // L2 round trips per output tile of the persistent kernel
+  for (int i0 = 0; i0 < nq; i0 += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = q[min(i0 + i, nq - 1)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i0 + i < nq) {
+        ss += v[i][0];
+        ss += v[i][1];
+        ss += v[i][2];
+        ss += v[i][3];
+      }
+    }
   }
   return rsqrtf(ss * p.rs_inv_h + p.rs_eps);
 }
@@ -119,13 +129,62 @@ __device__ __forceinline__ float silu_mul(float g, float u) {
   return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * u;
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// silu(g) * u for the lane's four consecutive features, written on natural register pairs so that the products are
+// v_pk_mul_f32 (two outputs per issue slot; left to itself the vectoriser paired (0,2),(1,3) and paid for it in v_mov and
+// re-interleaving instructions: ~50 instructions per quad, this is ~24).  Same arithmetic, same order as silu_mul.
+template <bool F16>
+__device__ __forceinline__ u32x2 silu_mul_quad(const f32x4& g, const f32x4& u) {
+  const f32x2 g0 = {g[0], g[1]}, g1 = {g[2], g[3]}, u0 = {u[0], u[1]}, u1 = {u[2], u[3]};
+  const f32x2 t0 = g0 * -1.44269504088896340736f, t1 = g1 * -1.44269504088896340736f;  // __expf(-g) = exp2(-g log2 e)
+  const f32x2 d0 = f32x2{__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + 1.f;
+  const f32x2 d1 = f32x2{__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + 1.f;
+  const f32x2 r0 = {__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1])};
+  const f32x2 r1 = {__builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+  const f32x2 o0 = g0 * r0 * u0, o1 = g1 * r1 * u1;
+  return u32x2{pack16x2<F16>(o0[0], o0[1]), pack16x2<F16>(o1[0], o1[1])};
+}
+
+// ---- 16-byte epilogue accesses -------------------------------------------------------------------------------------------
+// A lane holds four consecutive features (8 bytes as 16-bit values) of one token per 16x16 MFMA tile; the lane 16 further on
+// holds the next four.  v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) applied to the
+// packed quads of two column-adjacent tiles a, b leaves EIGHT consecutive features in every lane -- even rows: tile a,
+// features 4q .. 4q+7; odd rows: tile b, features 4(q-1) .. 4(q-1)+7 -- i.e. one global_store_dwordx4 instead of two
+// dwordx2 (the store tail of these epilogues is issue-bound: half the instructions, same bytes, same addresses).  The swap is
+// an involution, so a 16-byte LOAD from the same address followed by the same swap returns the two quads.
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+// element offset of this lane's 16 bytes relative to column 0 of tile a (tile b follows at column 16)
+__device__ __forceinline__ int pair16_off(int lane) {
+  const int q = lane >> 4;
+  return (q & 1) ? 16 + 4 * (q - 1) : 4 * q;
+}
+__device__ __forceinline__ void store_pair16(bf16_t* row_pair, int off, const u32x2& a, const u32x2& b) {
+  unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+  swap16(a0, b0);
+  swap16(a1, b1);
+  *reinterpret_cast<u32x4*>(row_pair + off) = u32x4{a0, a1, b0, b1};
+}
+__device__ __forceinline__ void unswap_pair16(const u32x4& v, u32x2& a, u32x2& b) {
+  unsigned a0 = v[0], a1 = v[1], b0 = v[2], b1 = v[3];
+  swap16(a0, b0);
+  swap16(a1, b1);
+  a = u32x2{a0, a1};
+  b = u32x2{b0, b1};
+}
+
 // WHOLE_ONLY: the caller guarantees whole tiles (the 4-wave kernel); the bounds-checked paths are compiled out where
 // a fast path covers the form.
 // F16: the operands' 16-bit type; the fast paths below write 16-bit outputs of that same type (OUT16).
 // rs_lds (ROWSCALE, optional): the row scales of this wave's rows already in LDS (rs_lds[16 j + (lane & 15)] for m-tile j;
 // the 4-wave kernel computes them once per output tile while the first operands are in flight); otherwise they are
 // summed here from the partials, all TM rows' loads in flight together.
-template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false>
+// LEGACY (experiments build only, A/B): 1 = the 8-byte-access epilogues of rounds 1-2
+template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false, int LEGACY = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane,
                                               const float* rs_lds = nullptr) {
   constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
@@ -181,6 +240,61 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       // 16-bit residual stream (eval / frozen-decoder passes): norm_h16 IS the stream -- read, added to and rewritten in
       // place by the lane that owns the element; the partial sums are of the rounded values, i.e. of what the consumer
       // multiplies.  4 bytes per element instead of 10.
+      if constexpr (WHOLE_ONLY && LEGACY == 0) {
+        {  // (the 4-wave kernel is dispatched for ldc % 8 == 0 only: launch_w4)
+          // 16-byte form (pair16 helpers above): the residual pieces are requested DW rows ahead of their use (TN / 2 loads
+          // of 16 bytes per row: half the instructions of the 8-byte form for the same lines), the stores are 16 bytes as well
+          constexpr int DW = TM > 5 ? 5 : TM;
+          const int off16 = pair16_off(lane);
+          u32x4 oldw[TM][TN / 2];
+          auto fetchw = [&](int j) {
+            const bf16_t* hrow = p.norm_h16 + (long)(m_base + j * 16 + ml) * p.ldc + n_base + off16;
+#pragma unroll
+            for (int k = 0; k < TN / 2; ++k)
+              oldw[j][k] = res ? *reinterpret_cast<const u32x4*>(hrow + k * 32) : u32x4{0u, 0u, 0u, 0u};
+          };
+#pragma unroll
+          for (int j = 0; j < DW; ++j) fetchw(j);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            if (j + DW < TM) fetchw(j + DW < TM ? j + DW : 0);
+            const long m = m_base + j * 16 + ml;
+            bf16_t* hrow = p.norm_h16 + m * p.ldc + n_base;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (see the SiLU epilogue: no hoisted accumulator reads)
+#pragma unroll
+            for (int g = 0; g < TN / 4; ++g) {
+              float ss = 0.f;
+#pragma unroll
+              for (int k = g * 2; k < g * 2 + 2; ++k) {
+                u32x2 o[2], w[2];
+                unswap_pair16(oldw[j][k], o[0], o[1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  f32x4 v = acc[2 * k + h][j];
+                  v += f32x4{from16_lo<F16>(o[h][0]), from16_hi<F16>(o[h][0]), from16_lo<F16>(o[h][1]), from16_hi<F16>(o[h][1])};
+                  w[h] = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+                  const float r0 = from16_lo<F16>(w[h][0]), r1 = from16_hi<F16>(w[h][0]), r2 = from16_lo<F16>(w[h][1]),
+                              r3 = from16_hi<F16>(w[h][1]);
+                  ss += r0 * r0;
+                  ss += r1 * r1;
+                  ss += r2 * r2;
+                  ss += r3 * r3;
+                }
+                store_pair16(hrow + k * 32, off16, w[0], w[1]);
+              }
+              ss += __shfl_xor(ss, 16, 64);
+              ss += __shfl_xor(ss, 32, 64);
+              if (lane < 16) {
+                p.norm_part[m * npart + ((n_base >> 6) + g)] = ss;
+                flag_nonfinite(p, ss);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          return;
+        }
+      }
       constexpr int D = WHOLE_ONLY ? (TM > 4 ? 4 : TM) : 1;
       u32x2 old[TM][TN];
       auto fetch = [&](int j) {
@@ -317,6 +431,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       return;
     }
   }
+  if constexpr ((EPI == EPI_SILU || EPI == EPI_SILU_SAVE) && TN % 4 == 0) {
+    // (the 4-wave kernel is dispatched for this form only -- silu16_ok() on the host -- so that its general path, and
+    // the registers it costs around the persistent loop, compile away)
+    if ((WHOLE_ONLY && LEGACY == 0) || (whole && p.out_kind == OUT16 && (p.ldc & 7) == 0 && LEGACY == 0)) {
+      // two gate|up tile pairs -> two adjacent 16-column output tiles -> one 16-byte store per lane
+      const int off16 = pair16_off(lane);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const long m = m_base + j * 16 + ml;
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + (n_base >> 1);
+        const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
+        if constexpr (WHOLE_ONLY) {
+          // (4-wave kernel: the accumulators live in AGPRs; re-pinning this row's here keeps their v_accvgpr_reads from
+          // being hoisted over the rows before it -- 150 hoisted reads cost spills that were reloaded behind the stores)
+#pragma unroll
+          for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));
+        }
+#pragma unroll
+        for (int i = 0; i < TN; i += 4) {
+          u32x2 o[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 g = acc[i + 2 * h][j] * rs, u = acc[i + 2 * h + 1][j] * rs;
+            if constexpr (EPI == EPI_SILU_SAVE) {
+              bf16_t* arow = p.aux + m * p.ldaux + n_base + (i + 2 * h) * 16 + nq;
+              *reinterpret_cast<u32x2*>(arow) = u32x2{pack16x2<F16>(g[0], g[1]), pack16x2<F16>(g[2], g[3])};
+              *reinterpret_cast<u32x2*>(arow + 16) = u32x2{pack16x2<F16>(u[0], u[1]), pack16x2<F16>(u[2], u[3])};
+            }
+            o[h] = silu_mul_quad<F16>(g, u);
+          }
+          store_pair16(crow + (i >> 1) * 16, off16, o[0], o[1]);
+        }
+        // (one row of MFMA tiles at a time: left free, the scheduler hoists the accumulator reads of later rows over this
+        // one's arithmetic, runs out of registers and spills -- and a scratch reload waits for every store issued so far)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
+  }
   if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE) {
     if (whole && p.out_kind == OUT16) {
 #pragma unroll
@@ -336,6 +489,60 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
               u32x2{pack16x2<F16>(silu_mul(g[0], u[0]), silu_mul(g[1], u[1])),
                     pack16x2<F16>(silu_mul(g[2], u[2]), silu_mul(g[3], u[3]))};
         }
+      }
+      return;
+    }
+  }
+  if constexpr (EPI == EPI_ROPE && WHOLE_ONLY) {
+    if constexpr (LEGACY == 0) {
+      // 4-wave kernel (dispatched for 16-bit outputs with ldc % 8 == 0): 16-byte stores (pair16 helpers above); the cos / sin
+      // rows of one row of MFMA tiles are loaded one row ahead
+      const int off16 = pair16_off(lane);
+      f32x4 cs[2][2], sn[2][2];
+      auto fetch = [&](int j, int slot) {
+        const int m = m_base + j * 16 + ml;
+        const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_L;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          cs[slot][i] = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + nq + i * 16);
+          sn[slot][i] = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + nq + i * 16);
+        }
+      };
+      fetch(0, 0);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        if (j + 1 < TM) fetch(j + 1 < TM ? j + 1 : 0, (j + 1) & 1);
+        const int m = m_base + j * 16 + ml;
+        bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base;
+        const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (see the SiLU epilogue: no hoisted accumulator reads)
+#pragma unroll
+        for (int hh = 0; hh < TN / 4; ++hh) {
+          const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
+          u32x2 o[4];
+          if (rot) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const f32x4 lo = acc[hh * 4 + i][j] * rs, hi = acc[hh * 4 + i + 2][j] * rs;
+              const f32x4 c = cs[j & 1][i];
+              const f32x4 s = sn[j & 1][i];
+              const f32x4 l2 = lo * c - hi * s;
+              const f32x4 h2 = hi * c + lo * s;
+              o[i] = u32x2{pack16x2<F16>(l2[0], l2[1]), pack16x2<F16>(l2[2], l2[3])};
+              o[i + 2] = u32x2{pack16x2<F16>(h2[0], h2[1]), pack16x2<F16>(h2[2], h2[3])};
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const f32x4 v = acc[hh * 4 + i][j] * rs;
+              o[i] = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
+            }
+          }
+          store_pair16(crow + hh * 64, off16, o[0], o[1]);
+          store_pair16(crow + hh * 64 + 32, off16, o[2], o[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       return;
     }
@@ -444,8 +651,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           v[0] += bm[j]; v[1] += bm[j]; v[2] += bm[j]; v[3] += bm[j];
         }
         if (p.flags & TCAVT_EPI_RELU) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]);
+          v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]);
         }
         if constexpr (EPI == EPI_DROP) {
           float sc[4];
@@ -980,11 +1187,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   const int wm = wave / WN_, wn = wave % WN_;
   // fused RMSNorm (TCAVT_EPI_ROWSCALE): the 256 row scales of the output tile, behind the two tile buffers
   constexpr bool RS = EPI == EPI_SILU || EPI == EPI_SILU_SAVE || EPI == EPI_ROPE;
-  float* rs_tile = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+  // (two sets, used alternately by consecutive output tiles of the persistent form: the next tile's scales are written
+  // BEFORE this tile's epilogue, so that nothing has to be loaded, waited for or published behind the epilogue's stores)
+  float* const rs_base = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+  int rs_sel = 0;  // (uniform) the set the current output tile reads
   // Persistent form (p.pers_tiles > 0): this workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... as ONE stream of
   // K-tiles -- the look-ahead of the pipeline (fragments of the next K-tile, DMA of the next two) simply continues into
   // the next output tile, so its first operands arrive while this tile's epilogue runs (no per-tile prologue).
-  constexpr bool PERS_OK = !BUF && !DEEP && EPI != EPI_ROPE;  // (the RoPE instantiation fell apart into scratch with it)
+  constexpr bool PERS_OK = !BUF && !DEEP && EPI != EPI_ROPE;  // (the RoPE instantiation falls apart into scratch with it: 1.7 KB)
   const bool pers = PERS_OK && p.pers_tiles > 0;
   const int total_tiles = pers ? p.pers_tiles : (int)gridDim.x;
   int vb = blockIdx.x;
@@ -1100,7 +1310,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
 
   // ---- prologue: tile 0 (burst), publish, first pieces of tile 1, fragments F0(0)
   if constexpr (RS) {  // (the partial-sum loads are in flight together with tile 0's DMA; written before the barrier below)
-    if (p.rs_part) rs_tile[threadIdx.x] = row_rscale(p, m0 + threadIdx.x);
+    if (p.rs_part) rs_base[threadIdx.x] = row_rscale(p, m0 + threadIdx.x);
   }
   {
     const Src s0 = tsrc(0);
@@ -1246,24 +1456,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) asm volatile("" : "+a"(acc[i][j]));
-    gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, m0 + wm * TM * 16, n0 + wn * TN * 16, lane,
-                                          (RS && p.rs_part) ? rs_tile + wm * TM * 16 : nullptr);
-    if (!PERS_OK || !has_next) break;  // (uniform) non-persistent launches leave here
-    // ---- next output tile: F0 already holds its first fragments, its second K-tile is in flight
-    vb += gridDim.x;
-    if constexpr (RS) {
-      if (p.rs_part && nm0 != m0) {  // the next tile's rows differ: its scales replace this tile's once every wave has read them
-        asm volatile("s_barrier" ::: "memory");
-        rs_tile[threadIdx.x] = row_rscale(p, nm0 + threadIdx.x);  // (published by the first K-tile barrier of the next tile)
+    // ---- everything of the NEXT output tile that reads memory comes BEFORE this tile's stores: vmcnt counts loads and
+    // stores in one queue, so a load waited for after the epilogue (the next tile's row scales; any register the allocator
+    // chose to spill around the K loop) would first wait for the whole store tail to drain -- per output tile.
+    const int em0 = m0, en0 = n0;
+    const bool cont = PERS_OK && has_next;  // (uniform) non-persistent launches leave after the epilogue
+    if (cont) {  // F0 already holds the next tile's first fragments, its second K-tile is in flight
+      vb += gridDim.x;
+      if constexpr (RS) {
+        // the next tile's row scales, into the set this tile does not read (last read in the previous tile's epilogue:
+        // K-tile barriers have passed since; published by the next tile's K-tile barriers)
+        if (p.rs_part) rs_base[(rs_sel ^ 1) * 256 + threadIdx.x] = row_rscale(p, nm0 + threadIdx.x);
       }
+      m0 = nm0;
+      n0 = nn0;
+      srcA = nxtA;
+      srcW = nxtW;
+      locate_k2();
+      has_next = vb + (int)gridDim.x < total_tiles;
+      locate_next();
     }
-    m0 = nm0;
-    n0 = nn0;
-    srcA = nxtA;
-    srcW = nxtW;
-    locate_k2();
-    has_next = vb + (int)gridDim.x < total_tiles;
-    locate_next();
+    __builtin_amdgcn_sched_barrier(0);
+    gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, em0 + wm * TM * 16, en0 + wn * TN * 16, lane,
+                                          (RS && p.rs_part) ? rs_base + rs_sel * 256 + wm * TM * 16 : nullptr);
+    if (!cont) break;
+    rs_sel ^= 1;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -1276,8 +1493,32 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
 #endif
 }
 
+// the forms of the SiLU*up epilogue the 4-wave kernel is built for (16-byte stores of the 16-bit operand type)
+template <bool F16>
+static bool silu16_ok(const GemmP& p) {
+  return p.out_kind == (F16 ? TCAVT_F16 : TCAVT_BF16) && (p.ldc & 7) == 0;
+}
+
 template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256, bool F16 = false>
 static int launch_w4(const GemmP& p0, hipStream_t stream) {
+  if constexpr (EPI == EPI_SILU || EPI == EPI_SILU_SAVE) {
+    if (!silu16_ok<F16>(p0)) {
+      set_error("gemm_bf16(w4): the SiLU epilogue of the 4-wave kernel writes the 16-bit operand type with ldc %% 8 == 0");
+      return TCAVT_ERR_ARG;
+    }
+  }
+  if constexpr (EPI == EPI_ROPE) {
+    if (p0.ldc & 7) {
+      set_error("gemm_bf16(w4): the RoPE epilogue of the 4-wave kernel needs ldc %% 8 == 0");
+      return TCAVT_ERR_ARG;
+    }
+  }
+  if constexpr (EPI == EPI_NORM16) {
+    if (p0.ldc & 7) {
+      set_error("gemm_bf16(w4): the in-place 16-bit residual epilogue of the 4-wave kernel needs ldc %% 8 == 0");
+      return TCAVT_ERR_ARG;
+    }
+  }
   if (BUF && ((long)256 * p0.lda * 2 + (long)p0.K * 2 >= (1L << 31) || (long)256 * p0.ldw * 2 + (long)p0.K * 2 >= (1L << 31))) {
     set_error("gemm_bf16(w4, buffer loads): a 256-row operand panel must span < 2 GiB");
     return TCAVT_ERR_ARG;
@@ -1286,7 +1527,7 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
   p.xcd_gx = choose_xcd_partition(p);
-  constexpr int lds = 2 * (256 + BN) * 128 + 1024;  // two tile buffers + 256 row scales (TCAVT_EPI_ROWSCALE)
+  constexpr int lds = 2 * (256 + BN) * 128 + 2048;  // two tile buffers + two sets of 256 row scales (TCAVT_EPI_ROWSCALE)
   auto kfn = gemm_bf16_w4_kernel<EPI, B2R, DBG, BUF, BN, F16>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1815,7 +2056,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     tile = (t256 >= 256 && (double)t256 / (double)(waves * 256) >= 0.75) ? 256 : 0;  // 0: dispatch_tile picks 128 / 64
     // whole 256x256 tiles, one K source, bf16, no RoPE: the 4-wave kernel (gate|up 406 vs 434 us, down 204 vs 218,
     // o 57.5 vs 60 on the 8-wave kernel)
-    if (tile == 256 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 &&
+    const bool silu_ok = (!(epi & TCAVT_EPI_SILU_MUL) || (a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) && a->ldc % 8 == 0)) &&
+                         (!(stream16 || (epi & TCAVT_EPI_ROPE)) || a->ldc % 8 == 0);  // (16-byte epilogue accesses of the 4-wave kernel)
+    if (tile == 256 && batch == 1 && a->M % 256 == 0 && a->N % 256 == 0 && silu_ok &&
         ((epi & TCAVT_EPI_ROPE) ? a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) : K2 == 0)) {
       tile = 257;
       // 256 x 192 tiles where they fill whole waves of 256 CUs and 256 x 256 tiles do not (q|k|v: N = 3072)

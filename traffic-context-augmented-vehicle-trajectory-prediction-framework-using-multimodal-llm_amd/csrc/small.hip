@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         if (flags & TCAVT_EPI_ACCUM) v += C[(long)m * ldc + n];
         if (flags & TCAVT_EPI_BIAS) v += bias[n];
-        if (flags & TCAVT_EPI_RELU) v = fmaxf(v, 0.f);
+        if (flags & TCAVT_EPI_RELU) v = relu_nan(v);
         if (drop.p > 0.f) v *= dropout_one(drop, (unsigned long long)m * (unsigned long long)N + (unsigned long long)n);
         if (flags & TCAVT_EPI_RESIDUAL) v += res[(long)m * ldr + n];
         C[(long)m * ldc + n] = v;
