@@ -385,16 +385,24 @@ int tcavt_relu_bwd(float* g, const void* y, int y_dtype, int64_t n, tcavt_stream
 int tcavt_add_inplace(float* a, const float* b, int64_t n, tcavt_stream_t stream);
 /* ---- decoder-layer backward for the LoRA-trainable variant (modify_scripts/modify_train.py:512-528) ---- */
 /* d(silu(gate) * up): gu [M, 2I] bf16 in the interleaved TCAVT_EPI_SILU_MUL layout, g_act [M, I] bf16 -> g_gu [M, 2I] bf16 */
-int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
+int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I, int dtype16,
                        tcavt_stream_t stream);
-/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32 (H % 8 == 0); gy (+ gy2, optional) bf16 [M, H];
-   gx = or += (accumulate); gx_bf16 (optional): a bf16 copy of the updated gx, the next dgrad GEMM's operand */
+/* The 16-bit tensors of this group (names say _bf16 for history) are of the type `dtype16` names: TCAVT_BF16, or TCAVT_F16 --
+   the forward's storage contract; the gradients among them then carry the power-of-two scale of tcavt_grad_scale_pick. */
+/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32 (H % 8 == 0); gy (+ gy2, optional) 16-bit [M, H] of gy_dtype,
+   multiplied by *gy_scale when gy_scale != NULL (device scalar: where the backward enters its scale);
+   gx = or += (accumulate); gx_bf16 (optional): a 16-bit copy (out_dtype) of the updated gx, the next dgrad GEMM's operand */
 int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
-                      float* gx, void* gx_bf16, int accumulate, int M, int H, tcavt_stream_t stream);
+                      float* gx, void* gx_bf16, int accumulate, int M, int H, int gy_dtype, int out_dtype,
+                      const float* gy_scale, tcavt_stream_t stream);
+/* scale[0] = S = 2^k with max|g_a, g_b| * S in [target / 2, target], scale[1] = 1 / S, decided on the device (S = 1 for
+   all-zero or non-finite input); g_a, g_b (optional) 16-bit [n] of dtype16; scratch: one uint32, zero-initialised once */
+int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n, int dtype16, float target, float* scale,
+                          uint32_t* scratch, tcavt_stream_t stream);
 /* fp32 gradient of the rotated q|k|v [M, ncols] -> bf16 gradient of the projection outputs: transposed RoPE rotation on
    the first rope_cols columns (heads of 64), plain conversion on the rest; tables as for TCAVT_EPI_ROPE ([L, 32]) */
 int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
-                        int ncols, int rope_cols, int L, tcavt_stream_t stream);
+                        int ncols, int rope_cols, int L, int dtype16, tcavt_stream_t stream);
 /* backward of tcavt_attn_causal_gqa (head_dim 64, T <= 280): qkv = the forward's rotated q|k|v [B*T, (nq+2nkv)*64] bf16,
    dO [B*T, nq*64] bf16; g32 [B*T, (nq+2nkv)*64] fp32 in the same layout, ZEROED by the caller (k/v parts are accumulated
    with float atomics) */
@@ -418,12 +426,12 @@ int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf1
    scaled scores, 1 / row sum, sum(P dP), 0 -- the input of tcavt_attn_bwd_dkv */
 int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
                           float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp, int nq,
-                          int nkv, int head_dim, float scale, tcavt_stream_t stream);
+                          int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream);
 /* dK, dV of the attention backward, key-major on the matrix cores (one workgroup per sample, key/value head and 64 keys;
    P^T, dS^T rebuilt from `stats`, the query heads of the group summed in registers): writes the k and v columns of
    g32 [B*T, (nq+2nkv)*64] fp32 (every row; no zero-initialisation needed) */
 int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* stats, float* g32, const int32_t* kv_len,
-                       int B, int T, int Tp, int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream);
+                       int B, int T, int Tp, int nq, int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream);
 /* G3 fp32 [M, 3*nq*64] = dQ | dK per query head | dV per query head -> bf16 [M, (nq+2nkv)*64]: group sums + RoPE^T */
 int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
                             int nq, int nkv, int head_dim, int L, tcavt_stream_t stream);
@@ -431,9 +439,10 @@ int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_c
  *   C[i][h] += sum_m G[m][g_col0 + i] * X[m][h]     i < n (16, 32, 48 or 64), h < H, contraction over the M tokens
  * G bf16 [M][ldg] (a gradient), X 16-bit [M][ldx] of x_dtype (an fp16 forward activation is converted to bf16 on the way),
  * C fp32, ACCUMULATED into with float atomics (zero it or let it hold an earlier contribution): [n][ldc], or, with
- * trans_out != 0, the transpose [H][ldc]. */
+ * trans_out != 0, the transpose [H][ldc].
+ * g_dtype: 0 / TCAVT_BF16 (as described), or TCAVT_F16 together with an fp16 X: both operands as they are on the f16 MFMA. */
 int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
-                   int64_t ldc, int M, int H, int trans_out, tcavt_stream_t stream);
+                   int64_t ldc, int M, int H, int trans_out, int g_dtype, tcavt_stream_t stream);
 
 /* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192):
      g *= grad_scale;  g *= min(1, max_norm / (||g|| + 1e-6))

@@ -126,7 +126,8 @@ def _lora_keys(weights):
 @pytest.mark.parametrize("ragged,lora_drop", [(False, False), (True, False), (True, True)])
 def test_decoder_backward_lora_grads_match_autograd(gpu, ragged, lora_drop):
     """Stage-level: identical decoder input and an arbitrary gradient of the final hidden states; the adapter gradients of
-    LoraBackward vs torch autograd through the oracle's decoder (bf16 contract, straight-through casts)."""
+    LoraBackward vs torch autograd through the oracle's decoder (fp16 contract, straight-through casts).  The HIP walk is
+    IEEE half throughout -- tapes and, under the device-chosen power-of-two scale, gradients."""
     from oracle import forward as O
     from tcavt_amd import model, training
     from tests.util import load_case
@@ -151,7 +152,7 @@ def test_decoder_backward_lora_grads_match_autograd(gpu, ragged, lora_drop):
     # train mode: LoRA dropout with the HIP path's Philox masks (block 2 of the model's site numbering, one site per layer)
     seed = 0xD0C
     drop = O.DropTape(seed, cfg.lora_dropout, first_site=(2 << 16) + 1) if lora_drop else O._ident
-    out = O.llama_decoder(W, cfg, embeds, mask, O._rounder("bf16"), drop=drop)
+    out = O.llama_decoder(W, cfg, embeds, mask, O._rounder("fp16"), drop=drop)  # (the model's default storage contract)
     (out * G.float()).sum().backward()
 
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
@@ -161,7 +162,7 @@ def test_decoder_backward_lora_grads_match_autograd(gpu, ragged, lora_drop):
         lw.dctx = model.DropoutCtx(seed).sub(2) if lora_drop else None
         res = lw(embeds.to(dev), mask.to(dev)).last_hidden_state
         lw.dctx = None
-        assert rel_err(res.cpu(), out.detach()) < 2e-2
+        assert m.storage == torch.float16 and rel_err(res.cpu(), out.detach()) < 2e-3
         assert (lw.tape.layers[0].dspec is not None) == lora_drop
         tr.lbw.run(G.reshape(B * L, H).contiguous().to(dev))
     torch.cuda.synchronize()
@@ -172,7 +173,7 @@ def test_decoder_backward_lora_grads_match_autograd(gpu, ragged, lora_drop):
         assert ref.abs().max() > 0, k
         e = rel_err(got, ref)
         worst = max(worst, e)
-        assert e < 3e-2, (k, e)  # bf16 gradient chain through the layers vs fp32 autograd of the bf16-contract graph
+        assert e < 7.5e-3, (k, e)  # fp16 gradient chain through the layers vs fp32 autograd of the fp16-contract graph: 3 x the measured 2.4e-3 (bf16 chain: 1.2e-2)
     print(f"[lora grads ragged={ragged} lora_dropout={lora_drop}] worst relative error {worst:.2e}")
 
 
@@ -193,11 +194,12 @@ def test_lora_trainable_step(gpu):
         W[k].requires_grad_(True)
     loss, _ = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
                               t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
-                              contract="bf16")
+                              contract="fp16")
     loss.backward()
 
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(weights, device=dev).eval()
     tr = training.Trainer(m, lora_trainable=True, max_grad_norm=1.0)
+    assert m.storage == torch.float16
     assert set(tr.book.g) == set(keys) | set(trainable_keys(W))
     gq = {k: v.to(dev) for k, v in t.items()}
     args = (gq["traj_emb"], gq["vision_emb"], gq["lane_polygon"], gq["lane_polygon_len"], gq["target_traj"], gq["norm_stat"],
@@ -209,8 +211,8 @@ def test_lora_trainable_step(gpu):
     assert torch.isfinite(flat_got).all() and flat_ref.norm() > 0
     rel = ((flat_got - flat_ref).norm() / flat_ref.norm()).item()
     cos = (flat_got @ flat_ref / (flat_got.norm() * flat_ref.norm())).item()
-    print(f"[lora step] flat adapter gradient vs bf16-contract autograd: rel {rel:.2e}, cosine {cos:.5f}")
-    assert rel < 0.15 and cos > 0.99  # end to end on a tiny case: same conditioning caveat as test_gradients_match_autograd
+    print(f"[lora step] flat adapter gradient vs fp16-contract autograd: rel {rel:.2e}, cosine {cos:.5f}")
+    assert rel < 1e-2 and cos > 0.9999  # end to end on a tiny case; 3 x the measured 3.0e-3
     before = {k: tr.book.g[k].clone() for k in keys[:2]}
     a0 = m.mllm.llama_wrapper.llama_model.model.layers[0].self_attn.q_proj.lora_A.weight.detach().clone()
     gn = torch.linalg.vector_norm(tr.book.grads).item()
@@ -220,23 +222,24 @@ def test_lora_trainable_step(gpu):
         assert abs(torch.linalg.vector_norm(tr.book.grads).item() - 1.0) < 1e-3
     a1 = m.mllm.llama_wrapper.llama_model.model.layers[0].self_attn.q_proj.lora_A.weight.detach()
     assert (a1 - a0).abs().max().item() > 0
-    # the packed bf16 operands (and their transposes for the dgrad GEMMs) follow the updated parameters, every layer
+    # the packed 16-bit operands (and their transposes for the dgrad GEMMs) follow the updated parameters, every layer
     lw, r = m.mllm.llama_wrapper, cfg.lora_r
+    st = m.storage
     from tcavt_amd.model import LORA_V as LV
     nqh, nkvh = cfg.llama.n_q_heads * 64, cfg.llama.n_kv_heads * 64
     for li, lyr in enumerate(lw.llama_model.model.layers):
         d, dT, sa = lw._prepared().layers[li], lw.prepared_T()[li], lyr.self_attn
         # the forward's packed adapters carry the folded RMSNorm gain (A * input_layernorm.weight, rounded once) ...
         g1 = lyr.input_layernorm.weight.detach()[None, :]
-        assert torch.equal(d.a_cat[:r], (sa.q_proj.lora_A.weight.detach() * g1).to(torch.bfloat16))
-        assert torch.equal(d.a_cat[LV:LV + r], (sa.v_proj.lora_A.weight.detach() * g1).to(torch.bfloat16))
-        assert torch.equal(d.b_ext[:nqh, :r], sa.q_proj.lora_B.weight.detach().to(torch.bfloat16))
-        assert torch.equal(d.b_ext[nqh + nkvh:, LV:LV + r], sa.v_proj.lora_B.weight.detach().to(torch.bfloat16))
+        assert torch.equal(d.a_cat[:r], (sa.q_proj.lora_A.weight.detach() * g1).to(st))
+        assert torch.equal(d.a_cat[LV:LV + r], (sa.v_proj.lora_A.weight.detach() * g1).to(st))
+        assert torch.equal(d.b_ext[:nqh, :r], sa.q_proj.lora_B.weight.detach().to(st))
+        assert torch.equal(d.b_ext[nqh + nkvh:, LV:LV + r], sa.v_proj.lora_B.weight.detach().to(st))
         assert d.a_cat[r:LV].abs().max().item() == 0 and d.a_cat[LV + r:].abs().max().item() == 0
         assert d.b_ext[nqh:nqh + nkvh].abs().max().item() == 0
         # ... the backward's copies are the plain matrices
-        assert torch.equal(dT.a_plain[:r], sa.q_proj.lora_A.weight.detach().to(torch.bfloat16))
-        assert torch.equal(dT.a_plain[LV:LV + r], sa.v_proj.lora_A.weight.detach().to(torch.bfloat16))
+        assert torch.equal(dT.a_plain[:r], sa.q_proj.lora_A.weight.detach().to(st))
+        assert torch.equal(dT.a_plain[LV:LV + r], sa.v_proj.lora_A.weight.detach().to(st))
         assert torch.equal(dT.a_q[:, :LV], dT.a_plain[:LV].t()) and dT.a_q[:, LV:].abs().max().item() == 0
         assert torch.equal(dT.a_v[:, LV:], dT.a_plain[LV:].t()) and dT.a_v[:, :LV].abs().max().item() == 0
         assert torch.equal(dT.a_cat, dT.a_plain.t()) and torch.equal(dT.b_ext, d.b_ext.t())
@@ -454,7 +457,7 @@ def _front_keys(weights):
 def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
     """Trainer(lora_trainable=True, train_mllm_front=True) = the whole trainable set of modify_scripts/modify_train.py
     (:523-528 freeze only the non-LoRA Llama weights): gradients of the Q-Former, mllm.q_proj and the modality embeddings
-    against torch autograd through the oracle graph (bf16 contract), in eval arithmetic and in train mode with the same
+    against torch autograd through the oracle graph (fp16 contract), in eval arithmetic and in train mode with the same
     Philox masks; an optimizer step then moves them and the next forward."""
     from oracle import forward as O
     from tcavt_amd import model, training
@@ -476,7 +479,7 @@ def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
     assert set(tr.book.g) == set(lora) | set(front) | set(trainable_keys(W))
     loss, _ = O.model_forward(W, cfg, t["traj_emb"], t["vision_emb"], t["lane_polygon"], t["lane_polygon_len"],
                               t["input_ids"], t["attention_mask"], y=t["target_traj"], norm_stat=t["norm_stat"],
-                              contract="bf16", dropout_seed=m.dropout_seed if train_mode else None)
+                              contract="fp16", dropout_seed=m.dropout_seed if train_mode else None)
     loss.backward()
     gq = {k: v.to(dev) for k, v in t.items()}
     args = (gq["traj_emb"], gq["vision_emb"], gq["lane_polygon"], gq["lane_polygon_len"], gq["target_traj"], gq["norm_stat"],
@@ -495,8 +498,9 @@ def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
         rel = ((got - ref).norm() / ref.norm()).item()
         cos = (got @ ref / (got.norm() * ref.norm())).item()
         print(f"[modify_train set, train_mode={train_mode}] {name}: rel {rel:.2e}, cosine {cos:.5f}")
-        # bf16 gradient chain through 16 decoder layers + 8 Q-Former layers vs fp32 autograd of the bf16-contract graph
-        assert rel < 0.15 and cos > 0.99, (name, rel, cos)
+        # fp16 (scaled) gradient chain through the decoder layers, bf16 through the Q-Former layers, vs fp32 autograd of the
+        # fp16-contract graph: 3 x the measured 9.6e-3 (eval arithmetic) / 3.1e-2 (train mode, same masks)
+        assert rel < (0.1 if train_mode else 3e-2) and cos > 0.999, (name, rel, cos)
     w0 = m.mllm.qformer.query_tokens.detach().clone()
     tr.optimizer_step()
     l1, _ = tr.forward_backward(*args)

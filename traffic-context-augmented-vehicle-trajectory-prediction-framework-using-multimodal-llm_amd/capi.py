@@ -221,9 +221,11 @@ _SIGNATURES = {
     "tcavt_colsum": [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_relu_bwd": [c_void_p, c_void_p, c_int, c_int64, c_void_p],
     "tcavt_add_inplace": [c_void_p, c_void_p, c_int64, c_void_p],
-    "tcavt_silu_mul_bwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
-    "tcavt_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tcavt_silu_mul_bwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
+    "tcavt_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                          c_void_p, c_void_p],
+    "tcavt_grad_scale_pick": [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_attn_causal_gqa_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_void_p],
     "tcavt_causal_softmax_bwd_rows": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
@@ -231,11 +233,12 @@ _SIGNATURES = {
     "tcavt_causal_softmax_bwd_tiles": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_float, c_void_p],
     "tcavt_attn_bwd_scores": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
-                              c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                           c_void_p],
+                           c_int, c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
-    "tcavt_wgrad_tn": [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
+    "tcavt_wgrad_tn": [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                       c_void_p],
     "tcavt_clip_grad_norm": [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

@@ -12,8 +12,19 @@ namespace tcavt {
 
 __device__ __forceinline__ float sigmoid_f(float g) { return __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
 
+// one MFMA step on raw 16-byte fragments of the 16-bit type the backward runs in (F16: IEEE half = the forward's storage
+// contract, gradients carried under a power-of-two scale, tcavt_grad_scale_pick; otherwise bf16, round 1's contract)
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16b(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ float half16(unsigned int w, int k) { return k ? from16_hi<F16>(w) : from16_lo<F16>(w); }
+
 // gu: [M, 2I] bf16 in the interleaved layout of TCAVT_EPI_SILU_MUL (blocks of 16 gate columns, then the 16 up columns
 // of the same features); g_act: [M, I] bf16 = dL/d(silu(gate) * up).  g_gu gets dL/dgate, dL/dup in the same layout.
+template <bool F16>
 __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ g_act,
                                                            bf16_t* __restrict__ g_gu, long M, int I) {
   // one thread per block of 16 features: 32 B of gate, 32 B of up (adjacent), 32 B of g_act
@@ -31,15 +42,13 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
       float r[2][2];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const float g = __uint_as_float(k ? (gv[h][e] & 0xffff0000u) : (gv[h][e] << 16));
-        const float u = __uint_as_float(k ? (uv[h][e] & 0xffff0000u) : (uv[h][e] << 16));
-        const float d = __uint_as_float(k ? (dv[h][e] & 0xffff0000u) : (dv[h][e] << 16));
+        const float g = half16<F16>(gv[h][e], k), u = half16<F16>(uv[h][e], k), d = half16<F16>(dv[h][e], k);
         const float sg = sigmoid_f(g);
         r[0][k] = d * u * sg * (1.f + g * (1.f - sg));
         r[1][k] = d * g * sg;
       }
-      og[h][e] = pack_bf16x2(r[0][0], r[0][1]);
-      ou[h][e] = pack_bf16x2(r[1][0], r[1][1]);
+      og[h][e] = pack16x2<F16>(r[0][0], r[0][1]);
+      ou[h][e] = pack16x2<F16>(r[1][0], r[1][1]);
     }
   u32x4* dst = reinterpret_cast<u32x4*>(g_gu + blk * 32);
   dst[0] = og[0]; dst[1] = og[1]; dst[2] = ou[0]; dst[3] = ou[1];
@@ -48,10 +57,14 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
 // RMSNorm backward, one wave per row:  y = x * r * gamma,  r = rsqrt(mean(x^2) + eps)
 //   gx = r * (gy*gamma) - x * r^3 * mean(gy*gamma*x)
 // gy = gy_a (+ gy_b): the LoRA branch hands in its own gradient of the same normed row.  accumulate: gx += .
+// GF16 / OF16: 16-bit type of the incoming gradients / of the outgoing 16-bit copy.  gy_scale (optional, device scalar):
+// the incoming gradients are multiplied by it -- where the backward enters its power-of-two scale (tcavt_grad_scale_pick).
+template <bool GF16, bool OF16>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const bf16_t* __restrict__ gy_a, const bf16_t* __restrict__ gy_b,
                                                           float eps, float* __restrict__ gx, bf16_t* __restrict__ gx_bf16,
-                                                          int accumulate, int M, int H) {
+                                                          int accumulate, int M, int H, const float* __restrict__ gy_scale) {
+  const float gsc = gy_scale ? *gy_scale : 1.f;
   // H % 8 == 0: a lane handles 8 consecutive columns per step (2 x 16 B of x, 16 B of each gradient)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,18 +76,18 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     const u32x4 a = *reinterpret_cast<const u32x4*>(ga + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      g[2 * e] = __uint_as_float(a[e] << 16);
-      g[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+      g[2 * e] = from16_lo<GF16>(a[e]);
+      g[2 * e + 1] = from16_hi<GF16>(a[e]);
     }
     if (gb) {
       const u32x4 b = *reinterpret_cast<const u32x4*>(gb + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        g[2 * e] += __uint_as_float(b[e] << 16);
-        g[2 * e + 1] += __uint_as_float(b[e] & 0xffff0000u);
+        g[2 * e] += from16_lo<GF16>(b[e]);
+        g[2 * e + 1] += from16_hi<GF16>(b[e]);
       }
     }
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(gamma + c), w1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(gamma + c) * gsc, w1 = *reinterpret_cast<const f32x4*>(gamma + c + 4) * gsc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       g[e] *= w0[e];
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(o + c) = v0;
     *reinterpret_cast<f32x4*>(o + c + 4) = v1;
     if (gx_bf16) {
-      u32x4 b = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+      u32x4 b = {pack16x2<OF16>(v0[0], v0[1]), pack16x2<OF16>(v0[2], v0[3]), pack16x2<OF16>(v1[0], v1[1]), pack16x2<OF16>(v1[2], v1[3])};
       *reinterpret_cast<u32x4*>(gx_bf16 + (long)row * H + c) = b;
     }
   }
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 // fp32 [M, ncols] gradient of the rotated q | k | v  ->  bf16 gradient of the projections' outputs: the first
 // rope_cols columns (q and k heads, head_dim 64 each) get the transposed rotation
 //   g_t1 = g_o1 * cos + g_o2 * sin,   g_t2 = g_o2 * cos - g_o1 * sin      (forward: o1 = t1 cos - t2 sin, o2 = t2 cos + t1 sin)
+template <bool F16>
 __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const float* __restrict__ g32, bf16_t* __restrict__ out,
                                                             const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                             long M, int ncols, int rope_cols, int L) {
@@ -144,8 +158,8 @@ __global__ __launch_bounds__(256) void rope_bwd_pack_kernel(const float* __restr
     o1 = a * cs + b * sn;
     o2 = b * cs - a * sn;
   }
-  out[row * ncols + c1] = f32_to_bf16(o1);
-  out[row * ncols + c2] = f32_to_bf16(o2);
+  out[row * ncols + c1] = to16<F16>(o1);
+  out[row * ncols + c2] = to16<F16>(o2);
 }
 
 // ---------------------------------------------------------------------------
@@ -411,6 +425,7 @@ __global__ __launch_bounds__(256) void causal_softmax_bwd_tiles_kernel(const flo
 // and P^T, dS^T (as causal_softmax_bwd_tiles_kernel).  S and dP never exist in memory.
 // D[m][n] of the MFMA sits in lane l as m = 4 (l >> 4) + e, n = l & 15.
 // ---------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
                                                               bf16_t* __restrict__ dST, float* __restrict__ dQ, long ld_dq,
@@ -494,10 +509,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&ks[t * 16 + l15][kk * 32 + l4 * 8]);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, sacc, 0, 0, 0);
+        sacc = mfma16b<F16>(qf[kk], kf, sacc);
         if (want_d) {
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&vs[t * 16 + l15][kk * 32 + l4 * 8]);
-          dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[kk], vf, dacc, 0, 0, 0);
+          dacc = mfma16b<F16>(gf[kk], vf, dacc);
         }
       }
       sa[t] = sacc * scale;
@@ -583,8 +598,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
           dv = scale * pv * (da[t][e] - dot[e]);
         }
         const int r = wave * 16 + l4 * 4 + e;
-        tP[r][cl] = f32_to_bf16(pv);
-        tD[r][cl] = f32_to_bf16(dv);
+        tP[r][cl] = to16<F16>(pv);
+        tD[r][cl] = to16<F16>(dv);
       }
     }
     __syncthreads();
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&ksT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
-          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, dq[dt], 0, 0, 0);
+          dq[dt] = mfma16b<F16>(af, bfr, dq[dt]);
         }
       }
     }
@@ -644,6 +659,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
 // tile (accumulator layout -> A-fragment layout), and  dV += P^T dO,  dK += dS^T q  accumulate in registers over all of
 // it -- the group sum included.  Written once, fp32, into the k / v columns of the q|k|v-layout gradient.
 // ---------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ stats, float* __restrict__ g32,
                                                            const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
@@ -729,8 +745,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&qs[t * 16 + l15][kk * 32 + l4 * 8]);
         const bf16x8 gf = *reinterpret_cast<const bf16x8*>(&gs[t * 16 + l15][kk * 32 + l4 * 8]);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf, sacc, 0, 0, 0);
-        dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kk], gf, dacc, 0, 0, 0);
+        sacc = mfma16b<F16>(kf[kk], qf, sacc);
+        dacc = mfma16b<F16>(vf[kk], gf, dacc);
       }
       sT[t] = sacc;
       dT[t] = dacc;
@@ -749,8 +765,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
           pv = __expf(sacc[e] * scale - qm) * qinv;
           dsv = scale * pv * (dacc[e] - qdot);
         }
-        tP[wave * 16 + l4 * 4 + e][qi] = f32_to_bf16(pv);
-        tD[wave * 16 + l4 * 4 + e][qi] = f32_to_bf16(dsv);
+        tP[wave * 16 + l4 * 4 + e][qi] = to16<F16>(pv);
+        tD[wave * 16 + l4 * 4 + e][qi] = to16<F16>(dsv);
       }
     }
     __syncthreads();  // (the tile rows of a wave are private to it; the barrier only orders its own writes and reads)
@@ -762,8 +778,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
       for (int dt = 0; dt < 4; ++dt) {
         const bf16x8 gT = *reinterpret_cast<const bf16x8*>(&gsT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
         const bf16x8 qT = *reinterpret_cast<const bf16x8*>(&qsT[dt * 16 + l15][((kk * 4 + l4) ^ dt) * 8]);
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, gT, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, qT, dk[dt], 0, 0, 0);
+        dv[dt] = mfma16b<F16>(pf, gT, dv[dt]);
+        dk[dt] = mfma16b<F16>(df, qT, dk[dt]);
       }
     }
   }
@@ -870,7 +886,9 @@ static size_t attn_bwd_lds(int T) {
 // meet in C through fp32 atomics (C zeroed or holding an earlier contribution; same reproducibility class as the other
 // weight gradients: up to the float summation order).  trans_out: store C^T ([h][ldc] layout) instead.
 // ---------------------------------------------------------------------------
-template <bool XF16>
+// GF16: G (and then X as well) is IEEE half and the products run on the f16 MFMA; otherwise G is bf16 and an fp16 X
+// (XF16: a forward activation of the fp16 storage contract) is converted while it is staged
+template <bool XF16, bool GF16 = false>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ G, long ldg, int g0, int NB,
                                                        const bf16_t* __restrict__ X, long ldx, float* __restrict__ C,
                                                        long ldc, int M, int H, int m_per_wg, int trans_out) {
@@ -900,7 +918,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           bf16_t lo = static_cast<bf16_t>(v[e] & 0xffffu), hi = static_cast<bf16_t>(v[e] >> 16);
-          if constexpr (XF16) {  // forward activation in fp16, gradient operand in bf16: one type for the MFMA
+          if constexpr (XF16 && !GF16) {  // forward activation in fp16, gradient operand in bf16: one type for the MFMA
             lo = f32_to_bf16(f16_to_f32(lo));
             hi = f32_to_bf16(f16_to_f32(hi));
           }
@@ -930,7 +948,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
         const u32x4 af = *reinterpret_cast<const u32x4*>(&gt[(a * 16 + r16) * XS + kq * 8]);
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma16b<GF16>(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b]);
       }
     }
     __syncthreads();
@@ -953,16 +971,56 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// Power-of-two scale of the fp16 backward: S = 2^k with  max|g| * S  in [target / 2, target]  (g = the 16-bit gradient(s) the
+// backward starts from; bf16, so they cannot overflow themselves).  The backward is linear in g: every 16-bit gradient
+// tensor downstream carries the factor S, the fp32 weight gradients are multiplied by 1 / S at the end.  Decided on the
+// device (no host synchronisation): scale[0] = S, scale[1] = 1 / S.  All-zero or non-finite g: S = 1 (a non-finite
+// gradient then reaches the gated optimizer as it did before).
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void grad_amax_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long n8,
+                                                        unsigned int* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(a)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(from16_lo<F16>(v[e])), fabsf(from16_hi<F16>(v[e]))));
+    if (b) {
+      const u32x4 w = reinterpret_cast<const u32x4*>(b)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(fabsf(from16_lo<F16>(w[e])), fabsf(from16_hi<F16>(w[e]))));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));  // (non-negative floats order as their bits; NaN is dropped by fmaxf)
+}
+__global__ void grad_scale_set_kernel(unsigned int* __restrict__ amax_bits, float target, float* __restrict__ scale) {
+  const float m = __uint_as_float(*amax_bits);
+  float s = 1.f;
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(target / m, &e);       // target / m = f * 2^e, f in [0.5, 1)
+    e = max(-60, min(60, e - 1));       // 2^(e-1) <= target / m
+    s = ldexpf(1.f, e);
+  }
+  scale[0] = s;
+  scale[1] = 1.f / s;
+  *amax_bits = 0u;  // (re-armed for the next call)
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
 
-extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I,
+extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_bf16, int64_t M, int I, int dtype16,
                                   tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(is16(dtype16), "silu_mul_bwd: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(gu_bf16 && g_act_bf16 && g_gu_bf16 && M > 0 && I > 0 && I % 16 == 0, "silu_mul_bwd: bad args (I %% 16 == 0)");
   TCAVT_CHECK_ARG(aligned16(gu_bf16) && aligned16(g_act_bf16) && aligned16(g_gu_bf16), "silu_mul_bwd: 16-byte alignment required");
   const long n = (long)M * (I / 16);
-  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  auto kfn = dtype16 == TCAVT_F16 ? silu_mul_bwd_kernel<true> : silu_mul_bwd_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(gu_bf16), static_cast<const bf16_t*>(g_act_bf16),
                      static_cast<bf16_t*>(g_gu_bf16), (long)M, I);
   TCAVT_CHECK_LAUNCH("silu_mul_bwd");
@@ -970,23 +1028,30 @@ extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, v
 }
 
 extern "C" int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
-                                 float* gx, void* gx_bf16, int accumulate, int M, int H, tcavt_stream_t stream) {
+                                 float* gx, void* gx_bf16, int accumulate, int M, int H, int gy_dtype, int out_dtype,
+                                 const float* gy_scale, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(is16(gy_dtype) && (gx_bf16 == nullptr || is16(out_dtype)), "rmsnorm_bwd: gy_dtype / out_dtype must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(x && gamma && gy_bf16 && gx && M > 0 && H > 0 && H % 8 == 0, "rmsnorm_bwd: bad args (H %% 8 == 0)");
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(gy_bf16) && aligned16(gy2_bf16) && aligned16(gx) &&
                       aligned16(gx_bf16), "rmsnorm_bwd: 16-byte alignment required");
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
+  const bool gf = gy_dtype == TCAVT_F16, of = out_dtype == TCAVT_F16;
+  auto kfn = gf ? (of ? rmsnorm_bwd_kernel<true, true> : rmsnorm_bwd_kernel<true, false>)
+                : (of ? rmsnorm_bwd_kernel<false, true> : rmsnorm_bwd_kernel<false, false>);
+  hipLaunchKernelGGL(kfn, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
                      static_cast<const bf16_t*>(gy_bf16), static_cast<const bf16_t*>(gy2_bf16), eps, gx,
-                     static_cast<bf16_t*>(gx_bf16), accumulate, M, H);
+                     static_cast<bf16_t*>(gx_bf16), accumulate, M, H, gy_scale);
   TCAVT_CHECK_LAUNCH("rmsnorm_bwd");
   return TCAVT_OK;
 }
 
 extern "C" int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
-                                   int ncols, int rope_cols, int L, tcavt_stream_t stream) {
+                                   int ncols, int rope_cols, int L, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(is16(dtype16), "rope_bwd_pack: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(g32 && out_bf16 && rope_cos && rope_sin && M > 0 && L > 0, "rope_bwd_pack: bad args");
   TCAVT_CHECK_ARG(ncols % 64 == 0 && rope_cols % 64 == 0 && rope_cols <= ncols, "rope_bwd_pack: columns come in heads of 64");
   const long n = (long)M * (ncols / 2);
-  hipLaunchKernelGGL(rope_bwd_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  auto kfn = dtype16 == TCAVT_F16 ? rope_bwd_pack_kernel<true> : rope_bwd_pack_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      g32, static_cast<bf16_t*>(out_bf16), rope_cos, rope_sin, (long)M, ncols, rope_cols, L);
   TCAVT_CHECK_LAUNCH("rope_bwd_pack");
   return TCAVT_OK;
@@ -1055,8 +1120,8 @@ extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, v
 
 extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
                                      float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp,
-                                     int nq, int nkv, int head_dim, float scale, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && kv_len && B > 0 && T > 0, "attn_bwd_scores: bad args");
+                                     int nq, int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && kv_len && B > 0 && T > 0 && is16(dtype16), "attn_bwd_scores: bad args");
   TCAVT_CHECK_ARG((PT_bf16 != nullptr) == (dST_bf16 != nullptr), "attn_bwd_scores: PT and dST come together");
   TCAVT_CHECK_ARG(PT_bf16 || stats, "attn_bwd_scores: give PT/dST (GEMM form of dK, dV) or stats (tcavt_attn_bwd_dkv)");
   TCAVT_CHECK_ARG(aligned16(stats), "attn_bwd_scores: stats must be 16-byte aligned");
@@ -1065,7 +1130,8 @@ extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, 
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_scores: head_dim 64 and nq %% nkv == 0 required");
   TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_scores: Tp must be T rounded up to a multiple of 64");
   TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16), "attn_bwd_scores: 16-byte alignment required");
-  hipLaunchKernelGGL(attn_bwd_scores_kernel, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
+  auto kfn = dtype16 == TCAVT_F16 ? attn_bwd_scores_kernel<true> : attn_bwd_scores_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), dQ, (long)ld_dq,
                      stats, kv_len, T, Tp, nq, nkv, scale);
@@ -1075,12 +1141,13 @@ extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, 
 
 extern "C" int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, const float* stats, float* g32,
                                   const int32_t* kv_len, int B, int T, int Tp, int nq, int nkv, int head_dim, float scale,
-                                  tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && stats && g32 && kv_len && B > 0 && T > 0, "attn_bwd_dkv: bad args");
+                                  int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && stats && g32 && kv_len && B > 0 && T > 0 && is16(dtype16), "attn_bwd_dkv: bad args");
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_dkv: head_dim 64 and nq %% nkv == 0 required");
   TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_dkv: Tp must be T rounded up to a multiple of 64");
   TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16) && aligned16(stats), "attn_bwd_dkv: 16-byte alignment required");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((long)B * nkv * (Tp / 64))), dim3(256), 0,
+  auto kfn = dtype16 == TCAVT_F16 ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)((long)B * nkv * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      stats, g32, kv_len, T, Tp, nq, nkv, scale);
   TCAVT_CHECK_LAUNCH("attn_bwd_dkv");
@@ -1101,10 +1168,12 @@ extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float g
 }
 
 extern "C" int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
-                              int64_t ldc, int M, int H, int trans_out, tcavt_stream_t stream) {
+                              int64_t ldc, int M, int H, int trans_out, int g_dtype, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(G && X && C && M > 0 && H > 0 && n > 0 && n <= 64 && n % 16 == 0 && g_col0 >= 0 && g_col0 % 8 == 0 &&
                       ldg % 8 == 0 && ldx % 8 == 0 && H % 8 == 0 && is16(x_dtype),
                   "wgrad_tn: n in {16, 32, 48, 64}, g_col0 / ldg / ldx / H multiples of 8");
+  TCAVT_CHECK_ARG(g_dtype == 0 || g_dtype == TCAVT_BF16 || (g_dtype == TCAVT_F16 && x_dtype == TCAVT_F16),
+                  "wgrad_tn: G is bf16 (g_dtype 0 / TCAVT_BF16), or fp16 together with an fp16 X");
   TCAVT_CHECK_ARG(aligned16(G) && aligned16(X), "wgrad_tn: 16-byte alignment required");
   const int gx = (H + 255) / 256;
   int split = 256 / gx;  // ~one workgroup per CU
@@ -1112,12 +1181,30 @@ extern "C" int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, con
   int m_per_wg = ((M + split - 1) / split + 31) / 32 * 32;
   split = (M + m_per_wg - 1) / m_per_wg;
   const dim3 grid(gx, split), block(256);
-  if (x_dtype == TCAVT_F16)
+  if (g_dtype == TCAVT_F16)
+    hipLaunchKernelGGL((wgrad_tn_kernel<true, true>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+  else if (x_dtype == TCAVT_F16)
     hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
                        (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
   else
     hipLaunchKernelGGL(wgrad_tn_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
                        (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
   TCAVT_CHECK_LAUNCH("wgrad_tn");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n, int dtype16, float target, float* scale,
+                                     uint32_t* scratch, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(g_a && scale && scratch && n > 0 && n % 8 == 0 && is16(dtype16) && target > 0.f && aligned16(g_a) && aligned16(g_b),
+                  "grad_scale_pick: bad args (n %% 8 == 0, 16-byte alignment, scratch = one zero-initialised uint32)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  long blocks = (n / 8 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  auto kfn = dtype16 == TCAVT_F16 ? grad_amax_kernel<true> : grad_amax_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const bf16_t*>(g_a), static_cast<const bf16_t*>(g_b),
+                     (long)(n / 8), scratch);
+  hipLaunchKernelGGL(grad_scale_set_kernel, dim3(1), dim3(1), 0, st, scratch, target, scale);
+  TCAVT_CHECK_LAUNCH("grad_scale_pick");
   return TCAVT_OK;
 }

@@ -15,7 +15,7 @@ adapter gradients:
         q|k|v^T (dgrad GEMM)  ->  RMSNorm backward                                                    (attention half)
 
 The dgrad GEMMs are the forward's MFMA kernel on transposed copies of the frozen weights (prepared_T); the gate|up
-pre-activations come from the forward (its SiLU epilogue writes a bf16 copy in this mode: tcavt_gemm_args.silu_preact), the
+pre-activations come from the forward (its SiLU epilogue writes a 16-bit copy in this mode: tcavt_gemm_args.silu_preact), the
 normed rows feeding the adapters are recomputed.
 Layer 0's input gradient is not formed: nothing below it is trainable.
 """
@@ -62,7 +62,7 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     hd = 64
     Tp = _rup(T, 64)
     nqkv, grp, BH = (nq + 2 * nkv) * hd, nq // nkv, B * nq
-    f32, b16 = torch.float32, torch.bfloat16
+    f32, b16 = torch.float32, qkv.dtype
     if scores == "fused":
         # two MFMA kernels and the pack: query-major (row statistics, dQ), key-major (dK, dV; group sum in registers);
         # S, dP, P, dS never reach memory
@@ -112,12 +112,22 @@ class LoraBackward:
         self.ws = self.lw._ws
         self.input_grad = False  # True: also walk through layer 0's projections and return dL/d(inputs_embeds)
 
-    def _buf(self, name, shape, dtype=torch.bfloat16, zero=False):  # noqa: D401 (scratch from the decoder's workspace)
-        return self.ws.get("llbw." + name, shape, dtype, self.book.grads.device, zero=zero)
+    def _buf(self, name, shape, dtype=None, zero=False):  # noqa: D401 (scratch from the decoder's workspace)
+        """16-bit scratch is of the model's storage type (fp16: the forward's contract; gradients then run under the scale of
+        ops.grad_scale_pick) unless a type is given."""
+        dtype = self.lw.storage if dtype is None else dtype
+        return self.ws.get(f"llbw.{name}.{str(dtype)[6:]}", shape, dtype, self.book.grads.device, zero=zero)
 
     def run(self, g_final_a, g_final_b=None):
-        """g_final_a (+ g_final_b): bf16 [B*L, H] gradient of the post-final-norm hidden states.  Returns the fp32 gradient of
-        the decoder's input embeddings [B*L, H] when `input_grad` is set (qformer_backward.QFormerBackward continues from it)."""
+        """g_final_a (+ g_final_b): 16-bit [B*L, H] gradient of the post-final-norm hidden states (bf16 when the model's
+        storage is fp16: they are what the backward's scale is picked from and must not overflow themselves).  Returns the
+        fp32 gradient of the decoder's input embeddings [B*L, H] when `input_grad` is set (QFormerBackward continues from it).
+
+        fp16 storage (the default contract): every 16-bit tensor of the walk -- the forward's tapes AND the gradients -- is
+        IEEE half; the gradients carry one power-of-two factor S chosen on the device so that max |g_final| * S ~ 2^8
+        (tcavt_grad_scale_pick), the fp32 residual-gradient stream carries it too, and the adapters' fp32 weight gradients
+        (and the returned input gradient) are multiplied by 1 / S at the end.  A value that still leaves the half range
+        becomes inf, reaches the weight gradients and makes the gated optimizer skip the step (Trainer.skip_nonfinite)."""
         lw, G = self.lw, self.book.g
         tape = lw.tape
         if tape is None:
@@ -134,6 +144,16 @@ class LoraBackward:
         eps = ll.rms_eps
         pre = "mllm.llama_wrapper.llama_model.model.layers."
 
+        st = lw.storage
+        scaled = st == torch.float16
+        scale = self._buf("scale", (2,), torch.float32)       # [S, 1 / S]
+        if scaled:
+            if g_final_a.dtype != torch.bfloat16 or (g_final_b is not None and g_final_b.dtype != torch.bfloat16):
+                raise ValueError("LoraBackward.run: with fp16 storage the incoming gradient(s) must be bf16 (range)")
+            ops.grad_scale_pick(g_final_a, g_final_b, scale, self._buf("scale_scratch", (1,), torch.int32, zero=True))
+        elif g_final_a.dtype != st:
+            raise ValueError("LoraBackward.run: the incoming gradient must have the model's 16-bit storage type")
+        inv_s = scale[1:2]
         g_h = self._buf("g_h", (M, H), torch.float32)
         g_hb = self._buf("g_hb", (M, H))
         xn = self._buf("xn", (M, H))
@@ -156,7 +176,8 @@ class LoraBackward:
         dA = self._buf("dA", (64, H), torch.float32)
         dB = self._buf("dB", (nqkv, 64), torch.float32)
 
-        ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b, gx_bf16=g_hb)
+        ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b, gx_bf16=g_hb,
+                        gy_scale=scale[0:1] if scaled else None)
         for li in reversed(range(ll.layers)):
             d, dT, sv = P.layers[li], PT[li], tape.layers[li]
             # ---- MLP half: h_out = h_mid + (silu(gate) * up) W_d^T,  gate|up = rmsnorm(h_mid) W_gu^T
@@ -193,10 +214,16 @@ class LoraBackward:
                     ops.wgrad_tn(g_t, 0, 2 * LORA_V, xn, dA)
                 ops.wgrad_tn(t_re, 0, 2 * LORA_V, g_qkv, dB, trans_out=True)  # dB = g_qkv^T t, stored as [nqkv, 64]
                 p = f"{pre}{li}.self_attn."
-                G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
-                G[p + "v_proj.lora_A.weight"].copy_(dA[LORA_V:LORA_V + r])
-                G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
-                G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, LORA_V:LORA_V + r])
+                if scaled:  # out of the backward's scale (device scalar, no synchronisation)
+                    torch.mul(dA[:r], inv_s, out=G[p + "q_proj.lora_A.weight"])
+                    torch.mul(dA[LORA_V:LORA_V + r], inv_s, out=G[p + "v_proj.lora_A.weight"])
+                    torch.mul(dB[: nq * hd, :r], inv_s, out=G[p + "q_proj.lora_B.weight"])
+                    torch.mul(dB[(nq + nkv) * hd:, LORA_V:LORA_V + r], inv_s, out=G[p + "v_proj.lora_B.weight"])
+                else:
+                    G[p + "q_proj.lora_A.weight"].copy_(dA[:r])
+                    G[p + "v_proj.lora_A.weight"].copy_(dA[LORA_V:LORA_V + r])
+                    G[p + "q_proj.lora_B.weight"].copy_(dB[: nq * hd, :r])
+                    G[p + "v_proj.lora_B.weight"].copy_(dB[(nq + nkv) * hd:, LORA_V:LORA_V + r])
 
             if leaf is None:
                 adapter_grads()
@@ -221,4 +248,6 @@ class LoraBackward:
             ops.rmsnorm_bwd(sv.h_in, d.g1, g_xn, g_h, eps, gy2=g_xl, accumulate=True, gx_bf16=g_hb)
         if leaf is not None:
             torch.cuda.current_stream().wait_stream(leaf)
+        if self.input_grad and scaled:
+            g_h.mul_(inv_s)  # what continues below the decoder (Q-Former backward) runs unscaled
         return g_h if self.input_grad else None

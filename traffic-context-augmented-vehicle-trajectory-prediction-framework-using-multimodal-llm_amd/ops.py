@@ -497,12 +497,32 @@ def silu_mul_bwd(gu, g_act, g_gu):
     """d(silu(gate) * up) in the interleaved gate|up layout (layout.interleave_gate_up)."""
     M, I = g_act.shape
     for t, n, nm in ((gu, 2 * M * I, "gu"), (g_act, M * I, "g_act"), (g_gu, 2 * M * I, "g_gu")):
-        _req(t, torch.bfloat16, "silu_mul_bwd." + nm)
+        _req(t, gu.dtype, "silu_mul_bwd." + nm)  # one 16-bit type for all three (bf16, or fp16 with scaled gradients)
         _need(t, n, "silu_mul_bwd." + nm)
-    check(lib().tcavt_silu_mul_bwd(ptr(gu), ptr(g_act), ptr(g_gu), M, I, stream_ptr()), "tcavt_silu_mul_bwd")
+    check(lib().tcavt_silu_mul_bwd(ptr(gu), ptr(g_act), ptr(g_gu), M, I, _DT16(gu), stream_ptr()), "tcavt_silu_mul_bwd")
 
 
-def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None):
+def _DT16(t):
+    if t.dtype not in _H16:
+        raise capi.TcavtError(f"16-bit tensor (fp16 / bf16) required, got {t.dtype}")
+    return _DT[t.dtype]
+
+
+def grad_scale_pick(g_a, g_b, scale, scratch, target=256.0):
+    """scale[0] = 2^k with max|g_a, g_b| * 2^k in [target / 2, target], scale[1] = its inverse -- on the device
+    (tcavt_grad_scale_pick).  scratch: one zero-initialised int32."""
+    n = g_a.numel()
+    if g_b is not None and (g_b.dtype != g_a.dtype or g_b.numel() != n):
+        raise capi.TcavtError("grad_scale_pick: g_b must match g_a")
+    _req(scale, torch.float32, "grad_scale_pick.scale")
+    _need(scale, 2, "grad_scale_pick.scale")
+    if scratch.dtype != torch.int32 or scratch.numel() < 1:
+        raise capi.TcavtError("grad_scale_pick.scratch: int32 [1] required")
+    check(lib().tcavt_grad_scale_pick(ptr(g_a), ptr(g_b) if g_b is not None else None, n, _DT16(g_a), float(target), ptr(scale),
+                                      ptr(scratch), stream_ptr()), "tcavt_grad_scale_pick")
+
+
+def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None, gy_scale=None):
     M, H = x.shape
     _req(x, torch.float32, "rmsnorm_bwd.x")
     _req(gx, torch.float32, "rmsnorm_bwd.gx")
@@ -511,21 +531,26 @@ def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None)
     _need(gx, M * H, "rmsnorm_bwd.gx")
     for t, nm in ((gy, "gy"), (gy2, "gy2"), (gx_bf16, "gx_bf16")):
         if t is not None:
-            _req(t, torch.bfloat16, "rmsnorm_bwd." + nm)
+            _DT16(t)
             _need(t, M * H, "rmsnorm_bwd." + nm)
+    if gy2 is not None and gy2.dtype != gy.dtype:
+        raise capi.TcavtError("rmsnorm_bwd: gy and gy2 must have one 16-bit type")
+    if gy_scale is not None:
+        _req(gy_scale, torch.float32, "rmsnorm_bwd.gy_scale")
     check(lib().tcavt_rmsnorm_bwd(ptr(x), ptr(gamma), ptr(gy), ptr(gy2) if gy2 is not None else None, eps, ptr(gx),
-                                  ptr(gx_bf16) if gx_bf16 is not None else None, int(accumulate), M, H, stream_ptr()),
+                                  ptr(gx_bf16) if gx_bf16 is not None else None, int(accumulate), M, H, _DT16(gy),
+                                  _DT16(gx_bf16) if gx_bf16 is not None else 0,
+                                  ptr(gy_scale) if gy_scale is not None else None, stream_ptr()),
           "tcavt_rmsnorm_bwd")
 
 
 def rope_bwd_pack(g32, out, cos, sin, rope_cols, L):
     M, ncols = g32.shape
     _req(g32, torch.float32, "rope_bwd_pack.g32")
-    _req(out, torch.bfloat16, "rope_bwd_pack.out")
     _need(out, M * ncols, "rope_bwd_pack.out")
     _need(cos, L * 32, "rope_bwd_pack.cos")
     _need(sin, L * 32, "rope_bwd_pack.sin")
-    check(lib().tcavt_rope_bwd_pack(ptr(g32), ptr(out), ptr(cos), ptr(sin), M, ncols, rope_cols, L, stream_ptr()),
+    check(lib().tcavt_rope_bwd_pack(ptr(g32), ptr(out), ptr(cos), ptr(sin), M, ncols, rope_cols, L, _DT16(out), stream_ptr()),
           "tcavt_rope_bwd_pack")
 
 
@@ -570,13 +595,13 @@ def causal_softmax_bwd_tiles(S, dP, dS, PT, dST, kv_len, B, T, Tp, nq, scale):
 def attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale):
     """dK, dV of the causal GQA attention (key-major MFMA kernel) into the k / v columns of g32 (fp32, q|k|v layout)."""
     ncols = (nq + 2 * nkv) * 64
-    for t, dt, n, nm in ((qkv, torch.bfloat16, B * T * ncols, "qkv"), (dO, torch.bfloat16, B * T * nq * 64, "dO"),
+    for t, dt, n, nm in ((qkv, qkv.dtype, B * T * ncols, "qkv"), (dO, qkv.dtype, B * T * nq * 64, "dO"),
                          (stats, torch.float32, B * nq * T * 4, "stats"), (g32, torch.float32, B * T * ncols, "g32")):
         if t.dtype != dt or (not t.is_cuda and not _ALLOW_CPU) or _avail(t) < n:
             raise capi.TcavtError(f"attn_bwd_dkv.{nm}: {dt} GPU buffer with {n} elements required")
     _need(kv_len, B, "attn_bwd_dkv.kv_len")
     check(lib().tcavt_attn_bwd_dkv(ptr(qkv), ptr(dO), ptr(stats), ptr(g32), ptr(kv_len), B, T, Tp, nq, nkv, 64, scale,
-                                   stream_ptr()), "tcavt_attn_bwd_dkv")
+                                   _DT16(qkv), stream_ptr()), "tcavt_attn_bwd_dkv")
 
 
 def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None, stats=None):
@@ -590,8 +615,8 @@ def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=N
                      (PT, B * nq * Tp * Tp, "PT"), (dST, B * nq * Tp * Tp, "dST")):
         if t is None and ((nm == "dS" and dQ is not None) or (nm in ("PT", "dST") and stats is not None)):
             continue
-        if t.dtype != torch.bfloat16 or (not t.is_cuda and not _ALLOW_CPU):
-            raise capi.TcavtError(f"attn_bwd_scores.{nm}: bf16 GPU tensor required")
+        if t.dtype != qkv.dtype or t.dtype not in _H16 or (not t.is_cuda and not _ALLOW_CPU):
+            raise capi.TcavtError(f"attn_bwd_scores.{nm}: 16-bit GPU tensor of the type of qkv required")
         if _avail(t) < n:
             raise capi.TcavtError(f"attn_bwd_scores.{nm}: buffer too small")
     _need(kv_len, B, "attn_bwd_scores.kv_len")
@@ -601,7 +626,7 @@ def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=N
     opt = lambda t: ptr(t) if t is not None else None
     check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), opt(dS), opt(PT), opt(dST), opt(dQ),
                                       dQ.stride(0) if dQ is not None else 0, opt(stats), ptr(kv_len), B, T, Tp, nq, nkv, 64,
-                                      scale, stream_ptr()), "tcavt_attn_bwd_scores")
+                                      scale, _DT16(qkv), stream_ptr()), "tcavt_attn_bwd_scores")
 
 
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
@@ -697,8 +722,8 @@ def masked_mean_bwd(gemb, lens, genc, B, P, D):
 def wgrad_tn(g, g_col0, n, x, out, trans_out=False):
     """out[i, h] += sum_m g[m, g_col0 + i] * x[m, h] (i < n; trans_out: out[h, i]) -- skinny weight gradient without
     transposes (tcavt_wgrad_tn).  g bf16 [M, >= g_col0 + n], x fp16 / bf16 [M, H], out fp32, accumulated into."""
-    if g.dtype != torch.bfloat16 or x.dtype not in _H16 or out.dtype != torch.float32:
-        raise capi.TcavtError("wgrad_tn: g bf16, x fp16 / bf16, out fp32 required")
+    if g.dtype not in _H16 or x.dtype not in _H16 or out.dtype != torch.float32 or (g.dtype == torch.float16 and x.dtype != torch.float16):
+        raise capi.TcavtError("wgrad_tn: g bf16 with x fp16 / bf16, or g fp16 with x fp16; out fp32")
     M, H = x.shape
     if g.shape[0] < M or g.shape[1] < g_col0 + n or g.stride(1) != 1 or x.stride(1) != 1 or out.stride(1) != 1:
         raise capi.TcavtError("wgrad_tn: operand shapes / strides")
@@ -706,7 +731,7 @@ def wgrad_tn(g, g_col0, n, x, out, trans_out=False):
     if out.shape[0] < rows or out.shape[1] < cols:
         raise capi.TcavtError(f"wgrad_tn.out: needs at least ({rows}, {cols})")
     check(lib().tcavt_wgrad_tn(ptr(g), g.stride(0), int(g_col0), int(n), ptr(x), x.stride(0), _DT[x.dtype], ptr(out), out.stride(0),
-                               M, H, int(trans_out), stream_ptr()), "tcavt_wgrad_tn")
+                               M, H, int(trans_out), _DT[g.dtype], stream_ptr()), "tcavt_wgrad_tn")
 
 
 def clip_grad_norm(g, max_norm, scratch, grad_scale=1.0):

@@ -56,10 +56,9 @@ class Trainer:
         for p in model.mllm.parameters():  # train.py:1141-1142
             p.requires_grad_(False)
         self.lora_trainable = bool(lora_trainable)
-        if self.lora_trainable and model.storage != torch.bfloat16:
-            # the decoder backward's kernels (csrc/llm_backward.hip) read the forward's tapes as bf16 and exchange bf16
-            # gradients with them: this variant runs the whole model with bf16 storage (the round-1 contract)
-            model.set_storage(torch.bfloat16)
+        # (the LoRA-trainable variant runs on the model's storage type as well -- fp16 by default: the forward's tapes and,
+        # under a device-chosen power-of-two scale, the gradients of the decoder backward are IEEE half; set_storage(bfloat16)
+        # before constructing the Trainer keeps round 1's bf16 contract)
         self.max_grad_norm = max_grad_norm
         # modify_train.py:1190-1196 skips clip + step on a non-finite loss; train.py has no such test
         self.skip_nonfinite = self.lora_trainable if skip_nonfinite is None else bool(skip_nonfinite)
