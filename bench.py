@@ -124,7 +124,8 @@ def parse():
     ap.add_argument("--storage", choices=["fp16", "bf16"], default="fp16",
                     help="16-bit storage type of GEMM operands (weights copies and activations); fp32 accumulation either "
                          "way.  fp16 (default) keeps the whole model within 1e-3 of the fp32 reference; bf16 is round 1's "
-                         "contract (the LoRA-trainable variant always runs in bf16)")
+                         "contract (the LoRA-trainable variant follows the same switch: fp16 tapes and device-scaled fp16 "
+                         "gradients by default)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8,

@@ -98,6 +98,12 @@ int tcavt_init(int device, int* num_cus);
  *           index order (no atomics: bit-reproducible).  rowscale_npart % 4 == 0. */
 #define TCAVT_EPI_NORM_OUT 128
 #define TCAVT_EPI_ROWSCALE 256
+/* SILU_BWD (dgrad of down_proj in the LoRA-trainable variant's backward; the 4-wave kernel only: M, N % 256 == 0, 16-bit
+ *           output of the operand type, ldc and ld_preact % 8 == 0, no other flag): the accumulator is d = dL/d(silu(gate)*up)
+ *           [M][N]; with the forward's gate|up pre-activations `silu_preact` [M][2N] (interleaved layout of SILU_MUL) the
+ *           epilogue writes dL/dgate | dL/dup to C [M][2N] in the same layout -- tcavt_silu_mul_bwd without the round trip
+ *           of d through memory.  C may be `silu_preact` itself (in place: a lane reads its 16 bytes before it writes them). */
+#define TCAVT_EPI_SILU_BWD 512
 
 typedef struct tcavt_gemm_args {
   const void* A;   int64_t lda;  /* bf16 [M][K]  */
@@ -166,6 +172,10 @@ typedef struct tcavt_gemm_args {
   int32_t* nonfinite_flag;
   int32_t nonfinite_tag;
   int32_t reserved2;
+  /* TCAVT_EPI_NORM_OUT with C == NULL (16-bit residual stream), optional: the 16-bit residual is READ from here
+   * (leading dimension ldc) and the updated stream written to norm_h16 -- out of place, so that a caller can keep the
+   * stream of every layer (the LoRA-trainable variant's tape).  NULL: read from norm_h16 (in place). */
+  const void* norm_res16;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -389,12 +399,13 @@ int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, void* g_gu_b
                        tcavt_stream_t stream);
 /* The 16-bit tensors of this group (names say _bf16 for history) are of the type `dtype16` names: TCAVT_BF16, or TCAVT_F16 --
    the forward's storage contract; the gradients among them then carry the power-of-two scale of tcavt_grad_scale_pick. */
-/* LlamaRMSNorm backward w.r.t. its input x [M, H] fp32 (H % 8 == 0); gy (+ gy2, optional) 16-bit [M, H] of gy_dtype,
+/* LlamaRMSNorm backward w.r.t. its input x [M, H] (H % 8 == 0; x_dtype: TCAVT_F32, or a 16-bit type when the forward kept
+   the 16-bit residual stream itself); gy (+ gy2, optional) 16-bit [M, H] of gy_dtype,
    multiplied by *gy_scale when gy_scale != NULL (device scalar: where the backward enters its scale);
    gx = or += (accumulate); gx_bf16 (optional): a 16-bit copy (out_dtype) of the updated gx, the next dgrad GEMM's operand */
-int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
+int tcavt_rmsnorm_bwd(const void* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
                       float* gx, void* gx_bf16, int accumulate, int M, int H, int gy_dtype, int out_dtype,
-                      const float* gy_scale, tcavt_stream_t stream);
+                      const float* gy_scale, int x_dtype, tcavt_stream_t stream);
 /* scale[0] = S = 2^k with max|g_a, g_b| * S in [target / 2, target], scale[1] = 1 / S, decided on the device (S = 1 for
    all-zero or non-finite input); g_a, g_b (optional) 16-bit [n] of dtype16; scratch: one uint32, zero-initialised once */
 int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n, int dtype16, float target, float* scale,
@@ -504,8 +515,9 @@ typedef struct tcavt_llama_layer {
   const void* w_gu;   /* 16-bit [2 I][H], gate / up rows interleaved in blocks of 16 (TCAVT_EPI_SILU_MUL), post_attention_layernorm.weight folded in */
   const void* w_d;    /* 16-bit [H][I] */
   /* LoRA-trainable variant (optional, all NULL otherwise): per-layer buffers the backward reads (csrc/llm_backward.hip) */
-  float* tape_h_mid;  /* fp32 [M][H]: residual stream after the attention half (then h_in stays untouched) */
-  float* tape_h_out;  /* fp32 [M][H]: residual stream after the MLP half */
+  float* tape_h_mid;  /* [M][H]: residual stream after the attention half (then h_in stays untouched): fp32, or -- 16-bit
+                         residual stream, tcavt_llama_stack_args.h == NULL -- of the 16-bit storage type (cast the pointer) */
+  float* tape_h_out;  /* [M][H]: residual stream after the MLP half (same type) */
   void* tape_qkv;     /* 16-bit [M (+ pad)][(nq + 2 nkv) * 64]: rotated q|k|v of this layer */
   void* tape_gu;      /* 16-bit [M][2 I]: gate|up pre-activations (interleaved layout) */
   void* tape_t;       /* 16-bit [M][64]: LoRA down-projection */
@@ -558,6 +570,15 @@ typedef struct tcavt_llama_stack_args {
 } tcavt_llama_stack_args;
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
+
+/* Backward of tcavt_lora_down w.r.t. its input, both adapters and their masks in one pass (LoRA-trainable variant,
+ * modify_scripts/modify_train.py:512-528):
+ *   out[m][n] = mask_q[m][n] * sum_r g_t[m][r] A_q[r][n]  +  mask_v[m][n] * sum_r g_t[m][16 + r] A_v[r][n]
+ * g_t 16-bit [M][64] (columns 0-15: dL/dt of the q adapter, 16-31: of the v adapter), aqT / avT 16-bit [H][64]: the plain
+ * (no folded gain) A matrices transposed, rank r of the q adapter in column r / of the v adapter in column 16 + r, the other
+ * adapter's columns ZERO; out 16-bit [M][H].  Masks as in tcavt_lora_down (dropout_p == 0: none).  H % 128 == 0. */
+int tcavt_lora_dgrad(const void* g_t, const void* aqT, const void* avT, void* out, int M, int H, float dropout_p,
+                     uint64_t dropout_seed, uint32_t site_q, uint32_t site_v, int dtype16, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Post-LN nn.TransformerEncoderLayer / nn.TransformerDecoderLayer stacks as one call: the Q-Former's encoder and decoder

@@ -21,7 +21,7 @@ if os.environ.get("TCAVT_LIB") == "exp":  # tools/ only: the -DTCAVT_EXPERIMENTS
 ABI_VERSION = 3  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
-EPI_NORM_OUT, EPI_ROWSCALE = 128, 256
+EPI_NORM_OUT, EPI_ROWSCALE, EPI_SILU_BWD = 128, 256, 512
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -56,6 +56,7 @@ class GemmArgs(ctypes.Structure):
         ("reserved1", ctypes.c_int32),
         ("rope_pos", c_void_p),
         ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("norm_res16", c_void_p),
     ]
 
 
@@ -223,7 +224,9 @@ _SIGNATURES = {
     "tcavt_add_inplace": [c_void_p, c_void_p, c_int64, c_void_p],
     "tcavt_silu_mul_bwd": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     "tcavt_rmsnorm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                          c_void_p, c_void_p],
+                          c_void_p, c_int, c_void_p],
+    "tcavt_lora_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32,
+                         ctypes.c_uint32, c_int, c_void_p],
     "tcavt_grad_scale_pick": [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_attn_causal_gqa_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -58,6 +58,7 @@ struct GemmP {
   int rs_npart;
   float rs_eps, rs_inv_h;
   const int* rope_pos;    // ROPE: position of row m (decode step: one row per sample); NULL: m % rope_L
+  const bf16_t* res16;    // NORM16: where the 16-bit residual is read from (norm_h16 itself unless the caller keeps every layer's stream)
   int* nf_flag;           // NORM_OUT: receives nf_tag (CAS from 0) when a partial sum / rounded element is not finite
   int nf_tag;
 };
@@ -99,7 +100,8 @@ __device__ __forceinline__ float row_rscale(const GemmP& p, long m) {
 // instantiation as well -- inside EPI_GENERIC it pushed the 4-wave kernel's generic form into 460 bytes of scratch.
 // EPI_NORM16 = the same with C == NULL (16-bit residual stream, updated in place): again its own instantiation (both bodies in
 // one kernel spilled 150-500 bytes per lane in the 4-wave kernel).
-enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4, EPI_NORM = 5, EPI_NORM16 = 6 };
+// EPI_SILUBWD = TCAVT_EPI_SILU_BWD (4-wave kernel only).
+enum { EPI_GENERIC = 0, EPI_SILU = 1, EPI_ROPE = 2, EPI_DROP = 3, EPI_SILU_SAVE = 4, EPI_NORM = 5, EPI_NORM16 = 6, EPI_SILUBWD = 7 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
@@ -248,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           const int off16 = pair16_off(lane);
           u32x4 oldw[TM][TN / 2];
           auto fetchw = [&](int j) {
-            const bf16_t* hrow = p.norm_h16 + (long)(m_base + j * 16 + ml) * p.ldc + n_base + off16;
+            const bf16_t* hrow = p.res16 + (long)(m_base + j * 16 + ml) * p.ldc + n_base + off16;
 #pragma unroll
             for (int k = 0; k < TN / 2; ++k)
               oldw[j][k] = res ? *reinterpret_cast<const u32x4*>(hrow + k * 32) : u32x4{0u, 0u, 0u, 0u};
@@ -300,7 +302,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       auto fetch = [&](int j) {
         const long m = m_base + j * 16 + ml;
         const long mm = (WHOLE_ONLY || m < p.M) ? m : 0;
-        const bf16_t* hrow = p.norm_h16 + mm * p.ldc + n_base + nq;
+        const bf16_t* hrow = p.res16 + mm * p.ldc + n_base + nq;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const bool colok = WHOLE_ONLY || n_base + (i >> 2) * 64 < p.N;
@@ -430,6 +432,49 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       }
       return;
     }
+  }
+  if constexpr (EPI == EPI_SILUBWD) {
+    // d(silu(gate) * up) straight from the accumulator of down_proj's dgrad GEMM (include/tcavt.h: TCAVT_EPI_SILU_BWD): for
+    // the lane's four features of a 16-column tile, gate and up sit in two column-adjacent 16-column blocks of the
+    // interleaved pre-activation row, and so do dgate and dup in the output row -- one 16-byte load and one 16-byte store
+    // per tile (pair16 helpers above).  Same arithmetic as silu_mul_bwd_kernel, on the un-rounded d.
+    static_assert(WHOLE_ONLY, "the SiLU-backward epilogue exists in the 4-wave kernel only");
+    constexpr int DW = 2;  // rows of pre-activations requested ahead (TN x 16 bytes per lane and row)
+    const int off16 = pair16_off(lane);
+    u32x4 pre[TM][TN];
+    auto fetchp = [&](int j) {
+      const bf16_t* arow = p.aux + (long)(m_base + j * 16 + ml) * p.ldaux + 2 * n_base + off16;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) pre[j][i] = *reinterpret_cast<const u32x4*>(arow + i * 32);
+    };
+#pragma unroll
+    for (int j = 0; j < DW && j < TM; ++j) fetchp(j);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      if (j + DW < TM) fetchp(j + DW < TM ? j + DW : 0);
+      bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m_base + j * 16 + ml) * p.ldc + 2 * n_base;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (no hoisted accumulator reads: see the SiLU epilogue)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        u32x2 gq, uq;
+        unswap_pair16(pre[j][i], gq, uq);
+        const f32x4 d = acc[i][j];
+        float dg[4], du[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = (e & 1) ? from16_hi<F16>(gq[e >> 1]) : from16_lo<F16>(gq[e >> 1]);
+          const float u = (e & 1) ? from16_hi<F16>(uq[e >> 1]) : from16_lo<F16>(uq[e >> 1]);
+          const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-g));
+          dg[e] = d[e] * u * sg * (1.f + g * (1.f - sg));
+          du[e] = d[e] * g * sg;
+        }
+        store_pair16(crow + i * 32, off16, u32x2{pack16x2<F16>(dg[0], dg[1]), pack16x2<F16>(dg[2], dg[3])},
+                     u32x2{pack16x2<F16>(du[0], du[1]), pack16x2<F16>(du[2], du[3])});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
   }
   if constexpr ((EPI == EPI_SILU || EPI == EPI_SILU_SAVE) && TN % 4 == 0) {
     // (the 4-wave kernel is dispatched for this form only -- silu16_ok() on the host -- so that its general path, and
@@ -1507,6 +1552,13 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
       return TCAVT_ERR_ARG;
     }
   }
+  if constexpr (EPI == EPI_SILUBWD) {
+    if (p0.out_kind != (F16 ? TCAVT_F16 : TCAVT_BF16) || (p0.ldc & 7) || (p0.ldaux & 7) || p0.aux == nullptr || p0.ldc < 2 * p0.N ||
+        p0.ldaux < 2 * p0.N) {
+      set_error("gemm_bf16(w4): SILU_BWD needs silu_preact, 16-bit output of the operand type, ldc / ld_preact %% 8 == 0 and >= 2 N");
+      return TCAVT_ERR_ARG;
+    }
+  }
   if constexpr (EPI == EPI_ROPE) {
     if (p0.ldc & 7) {
       set_error("gemm_bf16(w4): the RoPE epilogue of the 4-wave kernel needs ldc %% 8 == 0");
@@ -1778,7 +1830,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       if constexpr (EPI == EPI_NORM16) {
         if (p.flags & TCAVT_EPI_RESIDUAL) {
 #pragma unroll
-          for (int c = 0; c < NCB; ++c) old16[c] = *reinterpret_cast<const u32x2*>(p.norm_h16 + pmm * p.ldc + n0 + c * 16 + 4 * kq);
+          for (int c = 0; c < NCB; ++c) old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + pmm * p.ldc + n0 + c * 16 + 4 * kq);
         }
       }
     }
@@ -1997,6 +2049,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.xcd_gx = 8;
   p.norm_h16 = nullptr;
   p.norm_part = nullptr;
+  p.res16 = nullptr;
   p.nf_flag = (epi & TCAVT_EPI_NORM_OUT) ? a->nonfinite_flag : nullptr;
   p.nf_tag = a->nonfinite_tag;
   p.rs_part = nullptr;
@@ -2012,6 +2065,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                     "gemm_bf16: NORM_OUT with C == NULL keeps the residual stream in norm_h16 (updated in place): residual must be NULL");
     p.norm_h16 = static_cast<bf16_t*>(a->norm_h16);
     p.norm_part = a->norm_part;
+    TCAVT_CHECK_ARG(a->norm_res16 == nullptr || (stream16 && aligned16(a->norm_res16)),
+                    "gemm_bf16: norm_res16 goes with the 16-bit residual stream (NORM_OUT, C == NULL) and needs 16-byte alignment");
+    p.res16 = a->norm_res16 ? static_cast<const bf16_t*>(a->norm_res16) : p.norm_h16;
   }
   if (epi & TCAVT_EPI_ROWSCALE) {
     TCAVT_CHECK_ARG((epi & (TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROPE)) && a->rowscale_part && aligned16(a->rowscale_part) &&
@@ -2046,6 +2102,15 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     }
     if (e0 == 0 && K2 == 0 && a->N % 16 == 0)
       return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
+  }
+  if (epi & TCAVT_EPI_SILU_BWD) {  // dgrad of down_proj with d(silu(gate) * up) in the epilogue: the 4-wave kernel only
+    TCAVT_CHECK_ARG(epi == TCAVT_EPI_SILU_BWD && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->K >= 128 &&
+                        a->silu_preact && aligned16(a->silu_preact) && a->dropout_p == 0.f && p.acc_scale == 1.f &&
+                        a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) && (a->tile == 0 || a->tile == 257),
+                    "gemm_bf16: SILU_BWD runs on whole 256x256 tiles with silu_preact, a 16-bit output of the operand type and no other flag");
+    p.aux = static_cast<bf16_t*>(a->silu_preact);
+    p.ldaux = a->ld_preact;
+    return f16 ? launch_w4<EPI_SILUBWD, 2, 0, false, 256, true>(p, s) : launch_w4<EPI_SILUBWD, 2, 0, false, 256, false>(p, s);
   }
   int tile = a->tile;
   if (tile == 0) {

@@ -59,8 +59,21 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16_t* __restr
 // gy = gy_a (+ gy_b): the LoRA branch hands in its own gradient of the same normed row.  accumulate: gx += .
 // GF16 / OF16: 16-bit type of the incoming gradients / of the outgoing 16-bit copy.  gy_scale (optional, device scalar):
 // the incoming gradients are multiplied by it -- where the backward enters its power-of-two scale (tcavt_grad_scale_pick).
-template <bool GF16, bool OF16>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// XT: type of x -- 0 fp32, 1 fp16, 2 bf16 (the forward's 16-bit residual stream, kept per layer by the tape)
+template <int XT>
+__device__ __forceinline__ void load_x8(const void* xr, int c, f32x4& x0, f32x4& x1) {
+  if constexpr (XT == 0) {
+    const float* f = static_cast<const float*>(xr);
+    x0 = *reinterpret_cast<const f32x4*>(f + c);
+    x1 = *reinterpret_cast<const f32x4*>(f + c + 4);
+  } else {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(xr) + c);
+    x0 = f32x4{from16_lo<XT == 1>(v[0]), from16_hi<XT == 1>(v[0]), from16_lo<XT == 1>(v[1]), from16_hi<XT == 1>(v[1])};
+    x1 = f32x4{from16_lo<XT == 1>(v[2]), from16_hi<XT == 1>(v[2]), from16_lo<XT == 1>(v[3]), from16_hi<XT == 1>(v[3])};
+  }
+}
+template <bool GF16, bool OF16, int XT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                           const bf16_t* __restrict__ gy_a, const bf16_t* __restrict__ gy_b,
                                                           float eps, float* __restrict__ gx, bf16_t* __restrict__ gx_bf16,
                                                           int accumulate, int M, int H, const float* __restrict__ gy_scale) {
@@ -69,7 +82,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float* xr = x + (long)row * H;
+  const void* xr = XT == 0 ? static_cast<const void*>(static_cast<const float*>(x) + (long)row * H)
+                           : static_cast<const void*>(static_cast<const bf16_t*>(x) + (long)row * H);
   const bf16_t* ga = gy_a + (long)row * H;
   const bf16_t* gb = gy_b ? gy_b + (long)row * H : nullptr;
   auto load_g = [&](int c, float (&g)[8]) {
@@ -98,7 +112,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   for (int c = lane * 8; c < H; c += 512) {
     float g[8];
     load_g(c, g);
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + c), x1 = *reinterpret_cast<const f32x4*>(xr + c + 4);
+    f32x4 x0, x1;
+    load_x8<XT>(xr, c, x0, x1);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       ss = fmaf(x0[e], x0[e], ss);
@@ -115,7 +130,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
   for (int c = lane * 8; c < H; c += 512) {
     float g[8];
     load_g(c, g);
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + c), x1 = *reinterpret_cast<const f32x4*>(xr + c + 4);
+    f32x4 x0, x1;
+    load_x8<XT>(xr, c, x0, x1);
     f32x4 v0, v1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1027,16 +1043,25 @@ extern "C" int tcavt_silu_mul_bwd(const void* gu_bf16, const void* g_act_bf16, v
   return TCAVT_OK;
 }
 
-extern "C" int tcavt_rmsnorm_bwd(const float* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
+extern "C" int tcavt_rmsnorm_bwd(const void* x, const float* gamma, const void* gy_bf16, const void* gy2_bf16, float eps,
                                  float* gx, void* gx_bf16, int accumulate, int M, int H, int gy_dtype, int out_dtype,
-                                 const float* gy_scale, tcavt_stream_t stream) {
+                                 const float* gy_scale, int x_dtype, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(is16(gy_dtype) && (gx_bf16 == nullptr || is16(out_dtype)), "rmsnorm_bwd: gy_dtype / out_dtype must be TCAVT_BF16 or TCAVT_F16");
+  TCAVT_CHECK_ARG(x_dtype == TCAVT_F32 || is16(x_dtype), "rmsnorm_bwd: x_dtype must be TCAVT_F32, TCAVT_F16 or TCAVT_BF16");
   TCAVT_CHECK_ARG(x && gamma && gy_bf16 && gx && M > 0 && H > 0 && H % 8 == 0, "rmsnorm_bwd: bad args (H %% 8 == 0)");
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(gy_bf16) && aligned16(gy2_bf16) && aligned16(gx) &&
                       aligned16(gx_bf16), "rmsnorm_bwd: 16-byte alignment required");
   const bool gf = gy_dtype == TCAVT_F16, of = out_dtype == TCAVT_F16;
-  auto kfn = gf ? (of ? rmsnorm_bwd_kernel<true, true> : rmsnorm_bwd_kernel<true, false>)
-                : (of ? rmsnorm_bwd_kernel<false, true> : rmsnorm_bwd_kernel<false, false>);
+  decltype(&rmsnorm_bwd_kernel<false, false, 0>) kfn;
+  if (x_dtype == TCAVT_F32)
+    kfn = gf ? (of ? rmsnorm_bwd_kernel<true, true, 0> : rmsnorm_bwd_kernel<true, false, 0>)
+             : (of ? rmsnorm_bwd_kernel<false, true, 0> : rmsnorm_bwd_kernel<false, false, 0>);
+  else if (x_dtype == TCAVT_F16)
+    kfn = gf ? (of ? rmsnorm_bwd_kernel<true, true, 1> : rmsnorm_bwd_kernel<true, false, 1>)
+             : (of ? rmsnorm_bwd_kernel<false, true, 1> : rmsnorm_bwd_kernel<false, false, 1>);
+  else
+    kfn = gf ? (of ? rmsnorm_bwd_kernel<true, true, 2> : rmsnorm_bwd_kernel<true, false, 2>)
+             : (of ? rmsnorm_bwd_kernel<false, true, 2> : rmsnorm_bwd_kernel<false, false, 2>);
   hipLaunchKernelGGL(kfn, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
                      static_cast<const bf16_t*>(gy_bf16), static_cast<const bf16_t*>(gy2_bf16), eps, gx,
                      static_cast<bf16_t*>(gx_bf16), accumulate, M, H, gy_scale);

@@ -106,6 +106,68 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// Backward of the adapters' down-projections w.r.t. their (dropped) input, both adapters in one pass:
+//     g_x[m][n] = mask_q[m][n] * (g_t[m][0:16] . A_q[:, n]) + mask_v[m][n] * (g_t[m][16:32] . A_v[:, n])
+// (g_t = dL/dt of tcavt_lora_down's output; one dropout site per adapted Linear, as in the forward).  Replaces two skinny
+// GEMMs, two mask kernels and their 32 MB round trips per layer.  A wave owns 16 tokens and walks the features in pairs of
+// 16-column tiles; per tile and adapter one MFMA (A operand = rows of A_q^T / A_v^T [H][64] with the other adapter's columns
+// zero, B operand = the tokens' g_t rows, K = 32), issued "swapped" so that a lane ends with four consecutive features of
+// its token; v_permlane16_swap pairs two tiles into eight consecutive features per lane = one mask octet = one generator
+// call per site, and one 16-byte store.
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void lora_dgrad_kernel(const bf16_t* __restrict__ g_t, const bf16_t* __restrict__ aqT,
+                                                         const bf16_t* __restrict__ avT, bf16_t* __restrict__ out, int M, int H,
+                                                         DropoutP dq, DropoutP dv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 16;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const long m = min(m0 + r16, M - 1);
+  const u32x4 gt = *reinterpret_cast<const u32x4*>(g_t + m * 64 + kq * 8);
+  const bool drop = dq.p > 0.f;
+  const int foff = (kq & 1) ? 16 + 4 * (kq - 1) : 4 * kq;  // this lane's eight features inside a pair of tiles (after the swap)
+  for (int n0 = wave * 32; n0 < H; n0 += 128) {
+    f32x4 cq[2], cv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long arow = (long)(n0 + 16 * h + r16) * 64 + kq * 8;
+      const u32x4 aq = *reinterpret_cast<const u32x4*>(aqT + arow), av = *reinterpret_cast<const u32x4*>(avT + arow);
+      cq[h] = mfma16s<F16>(aq, gt, f32x4{0.f, 0.f, 0.f, 0.f});
+      cv[h] = mfma16s<F16>(av, gt, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    float vq[8], vv[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (cq[0][e], cq[1][e]) -> elements e and 4 + e of the lane's eight consecutive features
+      unsigned int a = __float_as_uint(cq[0][e]), b = __float_as_uint(cq[1][e]);
+      auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+      vq[e] = __uint_as_float(r[0]);
+      vq[4 + e] = __uint_as_float(r[1]);
+      a = __float_as_uint(cv[0][e]);
+      b = __float_as_uint(cv[1][e]);
+      r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+      vv[e] = __uint_as_float(r[0]);
+      vv[4 + e] = __uint_as_float(r[1]);
+    }
+    const int f0 = n0 + foff;
+    float o[8];
+    if (drop) {
+      const unsigned long long oct = ((unsigned long long)m * (unsigned long long)H + (unsigned long long)f0) >> 3;
+      float sq[8], sv[8];
+      dropout_oct(dq, oct, sq);
+      dropout_oct(dv, oct, sv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = vq[k] * sq[k] + vv[k] * sv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = vq[k] + vv[k];
+    }
+    if (m0 + r16 < M)
+      *reinterpret_cast<u32x4*>(out + m * H + f0) = u32x4{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3]),
+                                                          pack16x2<F16>(o[4], o[5]), pack16x2<F16>(o[6], o[7])};
+  }
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -148,30 +210,34 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
   const float scale = 0.125f;  // 1 / sqrt(head_dim 64)
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* h = a->h;
+  const void* x16 = a->h16;  // the 16-bit stream (or 16-bit copy of the fp32 stream) the current layer reads
   for (int li = 0; li < a->n_layers; ++li) {
     const tcavt_llama_layer& w = a->layers[li];
     TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (w.a_cat == nullptr) == (w.b_ext == nullptr),
                     "llama_stack_forward: layer %d: null weight", li);
     const bool tape = w.tape_h_mid != nullptr;
-    TCAVT_CHECK_ARG(!(tape && stream16), "llama_stack_forward: a tape keeps fp32 residual streams: h must be given");
     if (tape) TCAVT_CHECK_ARG(w.tape_h_out && w.tape_qkv && w.tape_gu && (!w.a_cat || w.tape_t), "llama_stack_forward: layer %d: incomplete tape", li);
     void* qkv = tape ? w.tape_qkv : a->qkv;
     void* t = tape && w.a_cat ? w.tape_t : a->t;
-    float* h_mid = tape ? w.tape_h_mid : h;
+    float* h_mid = tape ? w.tape_h_mid : h;   // (stream16 + tape: these two name 16-bit buffers, see x_mid / x_out)
     float* h_out = tape ? w.tape_h_out : h;
+    // 16-bit residual stream: where this layer reads it (x16) and writes it -- in place without a tape, into the layer's own
+    // buffers with one (the backward then finds every layer's stream as the forward computed it)
+    void* x_mid = (stream16 && tape) ? static_cast<void*>(w.tape_h_mid) : a->h16;
+    void* x_out = (stream16 && tape) ? static_cast<void*>(w.tape_h_out) : a->h16;
     TCAVT_CHECK_ARG(qkv && (!w.a_cat || t), "llama_stack_forward: qkv / t workspace missing");
     const Ev ev{a->events, st, li};
     // ---- LoRA down-projection: t = (alpha / r) * dropout(x16) . (A * gamma)^T, un-normalised (the row scale is applied
     // to the whole q|k|v accumulator, the adapter update included); one fused kernel for both adapters and their masks
     if (w.a_cat) {
       const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
-      TCAVT_TRY(tcavt_lora_down(a->h16, w.a_cat, t, M, H, a->lora_scale, a->lora_dropout_p, a->dropout_seed, site, site + 1, dt,
+      TCAVT_TRY(tcavt_lora_down(x16, w.a_cat, t, M, H, a->lora_scale, a->lora_dropout_p, a->dropout_seed, site, site + 1, dt,
                                 stream));
     }
     // ---- q|k|v = rs * (x16 . (W_qkv * gamma1)^T + t . B_ext^T), RoPE on q and k
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = qkv; g.ldc = nqkv;
+      g.A = x16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = qkv; g.ldc = nqkv;
       g.M = M; g.N = nqkv; g.K = H; g.out_dtype = dt; g.in_dtype = dt; g.tile = a->gemm_tile;
       if (w.a_cat) { g.A2 = t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
@@ -198,7 +264,9 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = h_mid; g.ldc = H;
       g.M = M; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;  // (stream16: C = residual = NULL)
-      g.norm_h16 = a->h16; g.norm_part = a->part;
+      if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_mid; g.norm_res16 = x16; }
+      else g.norm_h16 = a->h16;
+      g.norm_part = a->part;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       ev.rec(4);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -207,7 +275,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     // ---- act = silu(rs * gate) * (rs * up),  gate|up = x16 . (W_gu * gamma2)^T
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
+      g.A = stream16 ? x_mid : a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
       g.M = M; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
       g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
@@ -222,16 +290,19 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = h_out; g.ldc = H;
       g.M = M; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.residual = h_mid; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
-      g.norm_h16 = a->h16; g.norm_part = a->part;
+      if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_out; g.norm_res16 = x_mid; }
+      else g.norm_h16 = a->h16;
+      g.norm_part = a->part;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       ev.rec(8);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
       ev.rec(9);
     }
     h = h_out;
+    x16 = x_out;
   }
   // final RMSNorm: its fp32 result is hidden_states[-1] (scripts/train.py:553), the 16-bit copy feeds the head's K / V projections
-  if (stream16) return tcavt_rmsnorm16(a->h16, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, dt, stream);
+  if (stream16) return tcavt_rmsnorm16(x16, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, dt, stream);
   return tcavt_rmsnorm(h, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, nullptr, 0.f, 0, 0, dt, stream);
 }
 
@@ -343,5 +414,19 @@ extern "C" int tcavt_event_elapsed_ms(void* start, void* stop, float* ms) {
     set_error("event_elapsed_ms: %s", hipGetErrorString(rc));
     return TCAVT_ERR_HIP;
   }
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_lora_dgrad(const void* g_t, const void* aqT, const void* avT, void* out, int M, int H, float dropout_p,
+                                uint64_t dropout_seed, uint32_t site_q, uint32_t site_v, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(g_t && aqT && avT && out && M > 0 && H > 0 && H % 128 == 0 && is16(dtype16) && dropout_p >= 0.f && dropout_p < 1.f,
+                  "lora_dgrad: bad args (H %% 128 == 0, 0 <= dropout_p < 1)");
+  TCAVT_CHECK_ARG(aligned16(g_t) && aligned16(aqT) && aligned16(avT) && aligned16(out), "lora_dgrad: 16-byte alignment required");
+  const DropoutP dq = make_dropout(dropout_p, dropout_seed, site_q), dv = make_dropout(dropout_p, dropout_seed, site_v);
+  const dim3 grid((unsigned)((M + 15) / 16)), block(256);
+  auto kfn = dtype16 == TCAVT_F16 ? lora_dgrad_kernel<true> : lora_dgrad_kernel<false>;
+  hipLaunchKernelGGL(kfn, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(g_t),
+                     static_cast<const bf16_t*>(aqT), static_cast<const bf16_t*>(avT), static_cast<bf16_t*>(out), M, H, dq, dv);
+  TCAVT_CHECK_LAUNCH("lora_dgrad");
   return TCAVT_OK;
 }

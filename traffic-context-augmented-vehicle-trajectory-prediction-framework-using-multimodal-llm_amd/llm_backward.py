@@ -163,7 +163,8 @@ class LoraBackward:
         g_xl2 = self._buf("g_xl2", (M, H))
         g_xn = self._buf("g_xn", (M, H))
         g_xl = self._buf("g_xl", (M, H))
-        g_act = self._buf("g_act", (M, I))
+        fuse_silu = ops.silu_bwd_fusable(M, I, H) and os.environ.get("TCAVT_NO_SILU_BWD_FUSION", "0") != "1"
+        g_act = None if fuse_silu else self._buf("g_act", (M, I))
         g_att = self._buf("g_att", (M, nq * hd))
         # the adapters' weight gradients are leaf work (nothing downstream reads them): they run on a side stream while the
         # main stream walks on to the next layer; what they read alternates between two buffers (layer parity), and a
@@ -181,9 +182,12 @@ class LoraBackward:
         for li in reversed(range(ll.layers)):
             d, dT, sv = P.layers[li], PT[li], tape.layers[li]
             # ---- MLP half: h_out = h_mid + (silu(gate) * up) W_d^T,  gate|up = rmsnorm(h_mid) W_gu^T
-            ops.gemm_bf16(g_hb, dT.w_d, out=g_act)  # g_hb: bf16 copy of g_h, written by the RMSNorm backward before
             gu = sv.gu  # gate|up pre-activations, saved by the forward's SiLU epilogue (silu_preact)
-            ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its block of gate / up before writing it
+            if fuse_silu:  # d(silu(gate) * up) in the dgrad GEMM's epilogue: dL/d(act) never reaches memory
+                ops.gemm_silu_bwd(g_hb, dT.w_d, gu)
+            else:
+                ops.gemm_bf16(g_hb, dT.w_d, out=g_act)  # g_hb: 16-bit copy of g_h, written by the RMSNorm backward before
+                ops.silu_mul_bwd(gu, g_act, gu)  # in place: every thread reads its block of gate / up before writing it
             ops.gemm_bf16(gu, dT.w_gu, out=g_xn)
             ops.rmsnorm_bwd(sv.h_mid, d.g2, g_xn, g_h, eps, accumulate=True, gx_bf16=g_hb)
             # ---- attention half: h_mid = h_in + att W_o^T
@@ -203,13 +207,20 @@ class LoraBackward:
                 dA.zero_()
                 dB.zero_()
                 if sv.dspec is not None:  # ... with the forward's two masks
-                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
+                    if sv.h_in.dtype == torch.float32:
+                        ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
+                    else:  # 16-bit residual stream on the tape
+                        ops.rmsnorm16(sv.h_in, d.g1, eps, out16=xn)
+                        ops.dropout(xn, xl, *sv.dspec[0])
                     ops.dropout(xn, xl2, *sv.dspec[1])
                     ops.lora_down(xn, dT.a_plain, t_re, s, dropout=sv.dspec[0], site_v=sv.dspec[1][2])
                     ops.wgrad_tn(g_t, 0, LORA_V, xl, dA)               # dA_q = g_tq^T drop_q(xn): token-major operands as they are
                     ops.wgrad_tn(g_t, LORA_V, LORA_V, xl2, dA[LORA_V:])
                 else:
-                    ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
+                    if sv.h_in.dtype == torch.float32:
+                        ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn)
+                    else:
+                        ops.rmsnorm16(sv.h_in, d.g1, eps, out16=xn)
                     ops.lora_down(xn, dT.a_plain, t_re, s)
                     ops.wgrad_tn(g_t, 0, 2 * LORA_V, xn, dA)
                 ops.wgrad_tn(t_re, 0, 2 * LORA_V, g_qkv, dB, trans_out=True)  # dB = g_qkv^T t, stored as [nqkv, 64]
@@ -237,9 +248,12 @@ class LoraBackward:
                     leaf_done[par].record(leaf)
             if li == 0 and not self.input_grad:
                 break
-            if sv.dspec is None:
+            if H % 128 == 0:  # both adapters' input gradients under their own masks, summed: one kernel
+                ops.lora_dgrad(g_t, dT.a_q, dT.a_v, g_xl, dropout=None if sv.dspec is None else sv.dspec[0],
+                               site_v=None if sv.dspec is None else sv.dspec[1][2])
+            elif sv.dspec is None:
                 ops.gemm_bf16(g_t, dT.a_cat, out=g_xl)
-            else:  # each adapter's input gradient under its own mask, summed
+            else:
                 ops.gemm_bf16(g_t, dT.a_q, out=g_xl2)
                 ops.dropout_(g_xl2, sv.dspec[0])
                 ops.gemm_bf16(g_t, dT.a_v, out=g_xl)

@@ -710,10 +710,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
 
     @property
     def stream16(self):
-        """16-bit residual stream (fp16 storage, no tape): the stream lives in norm_inputs()[0] only -- the residual
-        epilogues add to it in place, no fp32 copy exists (tcavt_llama_stack_args.h == NULL).  The LoRA-trainable variant
-        (bf16 storage, a tape for the backward) keeps fp32 streams."""
-        return self.storage == torch.float16 and not self.save_for_backward
+        """16-bit residual stream (fp16 storage): no fp32 copy exists (tcavt_llama_stack_args.h == NULL).  Without a tape the
+        stream lives in norm_inputs()[0] only and the residual epilogues add to it in place; with one (the LoRA-trainable
+        variant) every epilogue writes the updated stream to its layer's own 16-bit buffer, which the backward reads --
+        the forward arithmetic is the frozen path's either way.  bf16 storage (round 1's contract) keeps fp32 streams."""
+        return self.storage == torch.float16
 
     def norm_npart(self, M):
         """Partials per row the first fused norm of a pass over M rows reads (what embed_fuse / rownorm_prep must write)."""
@@ -747,7 +748,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         if self.save_for_backward:
             tape = self.tape = SimpleNamespace(layers=[], kv_len=kv_len, B=B, L=L, h_last=None)
             carr = (capi.LlamaLayer * ll.layers)()
-            h_in = h
+            st_stream = self.storage if self.stream16 else torch.float32  # type of the per-layer residual streams
+            h_in = h16 if self.stream16 else h  # (layer 0 reads the fused embeddings: the workspace's 16-bit stream / h)
             for li, d in enumerate(P.layers):
                 # per-layer buffers instead of the shared ones: the residual stream is written to a new buffer by each
                 # residual epilogue (no copies), q|k|v and the LoRA down-projection stay where the backward finds them
@@ -755,8 +757,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 if dq is not None:
                     dspec = ((dq[0], dq[1], dq[2] + 2 * li), (dq[0], dq[1], dq[2] + 2 * li + 1))
                 sv = SimpleNamespace(h_in=h_in, dspec=dspec,
-                                     h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), torch.float32, dev),
-                                     h_out=ws.get(f"ll.sv.hout{li}", (M, H), torch.float32, dev),
+                                     h_mid=ws.get(f"ll.sv.hmid{li}", (M, H), st_stream, dev),
+                                     h_out=ws.get(f"ll.sv.hout{li}", (M, H), st_stream, dev),
                                      qkv_padded=ws.get(f"ll.sv.qkv{li}", (M + 64, nqkv), self.storage, dev, zero=True),
                                      gu=ws.get(f"ll.sv.gu{li}", (M, 2 * ll.inter), self.storage, dev),
                                      t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev, zero=True) if self.use_lora else None)

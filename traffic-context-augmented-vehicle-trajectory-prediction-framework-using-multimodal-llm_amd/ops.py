@@ -134,6 +134,35 @@ def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual
     return out
 
 
+def silu_bwd_fusable(M, I, H):
+    """Shapes for which gemm_silu_bwd exists (whole 256 x 256 tiles of the 4-wave kernel)."""
+    return M % 256 == 0 and I % 256 == 0 and H % 64 == 0 and H >= 128
+
+
+def gemm_silu_bwd(g, w_t, gu, out=None):
+    """d(gate|up) = silu_mul_bwd(gu, g @ w_t.T) with the activation gradient never leaving the GEMM (TCAVT_EPI_SILU_BWD):
+    g 16-bit [M, H] = dL/d(down_proj output), w_t [I, H] = down_proj.weight^T, gu [M, 2I] the forward's gate|up
+    pre-activations (interleaved layout); out [M, 2I] (default: gu itself, in place)."""
+    _req16(g, "gemm_silu_bwd.g", rows_ok=True)
+    _req16(w_t, "gemm_silu_bwd.w_t", like=g, rows_ok=True)
+    _req16(gu, "gemm_silu_bwd.gu", like=g, rows_ok=True)
+    M, H = g.shape
+    I = w_t.shape[0]
+    out = gu if out is None else out
+    _req16(out, "gemm_silu_bwd.out", like=g, rows_ok=True)
+    if w_t.shape[1] != H or gu.shape[0] < M or gu.shape[1] < 2 * I or out.shape[0] < M or out.shape[1] < 2 * I or not silu_bwd_fusable(M, I, H):
+        raise capi.TcavtError("gemm_silu_bwd: shapes (g [M,H], w_t [I,H], gu / out [M,2I]; M, I multiples of 256)")
+    args = capi.GemmArgs()
+    args.A, args.lda, args.W, args.ldw = g.data_ptr(), g.stride(0), w_t.data_ptr(), w_t.stride(0)
+    args.C, args.ldc = out.data_ptr(), out.stride(0)
+    args.silu_preact, args.ld_preact = gu.data_ptr(), gu.stride(0)
+    args.M, args.N, args.K = M, I, H
+    args.out_dtype = args.in_dtype = _DT[g.dtype]
+    args.epilogue = capi.EPI_SILU_BWD
+    check(lib().tcavt_gemm_bf16(ctypes.byref(args), stream_ptr()), "tcavt_gemm_bf16(SILU_BWD)")
+    return out
+
+
 def _avail(t):
     """Elements addressable from t.data_ptr() to the end of its storage."""
     return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
@@ -524,7 +553,9 @@ def grad_scale_pick(g_a, g_b, scale, scratch, target=256.0):
 
 def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None, gy_scale=None):
     M, H = x.shape
-    _req(x, torch.float32, "rmsnorm_bwd.x")
+    if x.dtype not in (torch.float32,) + _H16:
+        raise capi.TcavtError("rmsnorm_bwd.x: fp32 or a 16-bit residual stream required")
+    _need(x, M * H, "rmsnorm_bwd.x")
     _req(gx, torch.float32, "rmsnorm_bwd.gx")
     _req(gamma, torch.float32, "rmsnorm_bwd.gamma")
     _need(gamma, H, "rmsnorm_bwd.gamma")
@@ -540,7 +571,7 @@ def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None,
     check(lib().tcavt_rmsnorm_bwd(ptr(x), ptr(gamma), ptr(gy), ptr(gy2) if gy2 is not None else None, eps, ptr(gx),
                                   ptr(gx_bf16) if gx_bf16 is not None else None, int(accumulate), M, H, _DT16(gy),
                                   _DT16(gx_bf16) if gx_bf16 is not None else 0,
-                                  ptr(gy_scale) if gy_scale is not None else None, stream_ptr()),
+                                  ptr(gy_scale) if gy_scale is not None else None, _DT[x.dtype], stream_ptr()),
           "tcavt_rmsnorm_bwd")
 
 
@@ -792,6 +823,21 @@ def lora_down(x16, a_cat, t, scale, dropout=None, site_v=None):
     p, seed, site = _drop(dropout)
     check(lib().tcavt_lora_down(ptr(x16), ptr(a_cat), ptr(t), M, H, float(scale), p, seed, site,
                                 (site + 1) if site_v is None else int(site_v), _DT[x16.dtype], stream_ptr()), "tcavt_lora_down")
+
+
+def lora_dgrad(g_t, a_qT, a_vT, out, dropout=None, site_v=None):
+    """out = mask_q * (g_t[:, :16] . A_q) + mask_v * (g_t[:, 16:32] . A_v) in one pass (tcavt_lora_dgrad); a_qT / a_vT [H, 64]
+    with the other adapter's columns zero; dropout = (p, seed, site_q), site_v = site_q + 1 unless given."""
+    _req16(g_t, "lora_dgrad.g_t")
+    for t, nm in ((a_qT, "a_qT"), (a_vT, "a_vT"), (out, "out")):
+        _req16(t, "lora_dgrad." + nm, like=g_t)
+    M, H = out.shape
+    _need(g_t, M * 64, "lora_dgrad.g_t")
+    _need(a_qT, H * 64, "lora_dgrad.a_qT")
+    _need(a_vT, H * 64, "lora_dgrad.a_vT")
+    p, seed, site = _drop(dropout)
+    check(lib().tcavt_lora_dgrad(ptr(g_t), ptr(a_qT), ptr(a_vT), ptr(out), M, H, p, seed, site,
+                                 (site + 1) if site_v is None else int(site_v), _DT[g_t.dtype], stream_ptr()), "tcavt_lora_dgrad")
 
 
 def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finished, out_tokens, advance_pos):
