@@ -57,12 +57,24 @@ __device__ __forceinline__ unsigned int bf16pair_to_f16pair(unsigned int k0_bits
 // lane -- with the 1024-thread bound (groups up to 8) the kernel is held to 128 and spills.
 // F16: q|k|v and the output are fp16 (the forward path's default storage): S^T = K . Q^T runs on the f16 MFMA and V needs
 // no conversion while it is transposed into LDS.
-template <int MAXT, bool F16>
+// STAMP (experiments build, tools/attn_stamps.py): s_memtime at the phase boundaries of every wave, written to `stamps`
+// ([workgroup][wave][16] uint64) -- a buffer nothing else reads; the product instantiation has no such code.
+template <int MAXT, bool F16, bool STAMP = false>
 __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __restrict__ qkv,
                                                               bf16_t* __restrict__ out,
                                                               const int* __restrict__ kv_len_p,
                                                               int L, int Lp, int nq, int nkv,
-                                                              float scale_log2e) {
+                                                              float scale_log2e, int ot_bytes,
+                                                              unsigned long long* __restrict__ stamps = nullptr) {
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if constexpr (STAMP) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if ((threadIdx.x & 63) == 0 && n_stamp < 16) stamps[((long)blockIdx.x * (MAXT / 64) + (threadIdx.x >> 6)) * 16 + n_stamp] = t;
+      ++n_stamp;
+    }
+  };
+  stamp();  // 0: entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int group = nq / nkv;
   const int b = blockIdx.x / nkv, kvh = blockIdx.x % nkv;
@@ -73,22 +85,56 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
   const int vstride = Lp + 4;  // elements
   char* Ks = smem;
   bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + Lp * 128);
+  const int ot_off = (Lp * 128 + 64 * (Lp + 4) * 2 + 15) & ~15;  // output tiles of the waves (ot_bytes > 0), behind K and V^T
   const bf16_t* base = qkv + (long)b * L * ld;
 
-  // ---- stage K (swizzled rows) and V^T
-  const int nthreads = blockDim.x;
-  for (int idx = threadIdx.x; idx < Lp * 8; idx += nthreads) {
-    const int row = idx >> 3, c = idx & 7;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < L) v = *reinterpret_cast<const u32x4*>(base + (long)row * ld + koff + c * 8);
-    *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+  // ---- this wave's query blocks.  2 * group waves: wave w serves query head w % group and the 32-query blocks of parity
+  // w / group, so every SIMD holds two waves whose MFMA / softmax / LDS phases interleave (one wave per SIMD left the matrix
+  // pipe idle during every softmax).  Query blocks are dealt to the two waves of a head in PAIRS (k, nqb-1-k): a short causal
+  // block with a long one, every pair costs nqb + 1 key tiles, wave parity p takes pairs p, p + 2, ...  (8 blocks: {0,7,2,5}
+  // and {1,6,3,4}, 18 key tiles each, instead of 16 / 20 with alternating blocks).
+  const int head = kvh * group + (wave % group);
+  const int qb0 = wave / group;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nqb = (L + 31) >> 5;
+  const int npair = (nqb + 1) >> 1;
+  // block number bi of this wave -> query block (or -1: none): bi = 2 * (pair index) + member
+  auto block_of = [&](int bi) {
+    const int pr = qb0 + 2 * (bi >> 1);
+    if (pr >= npair) return -1;
+    const int qb = (bi & 1) ? nqb - 1 - pr : pr;
+    return ((bi & 1) && qb == pr) ? -1 : qb;  // odd block count: the middle block is its own pair
+  };
+  auto load_q = [&](int qb, bf16x8 (&qf)[4]) {
+    const int qrow = min(qb * 32 + r, L - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      qf[s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + head * 64 + s * 16 + hh * 8);
+  };
+  // The whole problem of a workgroup is 192 KB in, 128 KB out and ~7 us of arithmetic on a CU that has nothing else to
+  // do: it is a streaming problem.  Everything a wave will read is requested up front -- the query rows of its first NPRE
+  // blocks (16 VGPRs each) BEFORE the K / V staging loads -- so the memory latency is paid once, not once per block (loading
+  // each block's queries at its start left the wave waiting ~2 us per block; L <= 256 has at most 4 blocks per wave).
+  constexpr int NPRE = 4;
+  bf16x8 qpre[NPRE][4];
+#pragma unroll
+  for (int bi = 0; bi < NPRE; ++bi) {
+    const int qb = block_of(bi);
+    load_q(qb < 0 ? 0 : qb, qpre[bi]);  // (uniform; a block that does not exist loads block 0's rows and is never used)
   }
-  for (int idx = threadIdx.x; idx < (Lp >> 1) * 8; idx += nthreads) {
+
+  // ---- stage K (swizzled rows) and V^T.  The loads of the first KIT / VIT passes over the rows (all of them for
+  // L <= 256 with 512 threads) are issued together and written to LDS afterwards: written load-then-store per pass, every
+  // pass waited for its own memory round trip -- six in a row, a third of the kernel's time.
+  const int nthreads = blockDim.x;
+  constexpr int KIT = 4, VIT = 2;
+  auto stage_k = [&](int idx, const u32x4& v) {
+    const int row = idx >> 3, c = idx & 7;
+    *reinterpret_cast<u32x4*>(Ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+  };
+  auto stage_v = [&](int idx, const u32x4& a, const u32x4& bb) {
     const int kp = idx >> 3, c = idx & 7;
-    const int r0 = 2 * kp, r1 = 2 * kp + 1;
-    u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
-    if (r0 < L) a = *reinterpret_cast<const u32x4*>(base + (long)r0 * ld + voff + c * 8);
-    if (r1 < L) bb = *reinterpret_cast<const u32x4*>(base + (long)r1 * ld + voff + c * 8);
+    const int r0 = 2 * kp;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned int lo, hi;
@@ -102,35 +148,54 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e) * vstride + r0) = lo;
       *reinterpret_cast<unsigned int*>(Vt + (c * 8 + 2 * e + 1) * vstride + r0) = hi;
     }
+  };
+  // (unconditional loads from a clamped row: a "load or zero" select on a runtime condition makes the compiler branch
+  // around every load and wait for it at the join; rows >= L are zeroed when they are staged)
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_k = [&](int idx) {
+    const int row = min(idx >> 3, L - 1), c = idx & 7;
+    return *reinterpret_cast<const u32x4*>(base + (long)row * ld + koff + c * 8);
+  };
+  auto load_v = [&](int idx, int which) {
+    const int rr = min(2 * (idx >> 3) + which, L - 1), c = idx & 7;
+    return *reinterpret_cast<const u32x4*>(base + (long)rr * ld + voff + c * 8);
+  };
+  auto krow_ok = [&](int idx) { return (idx >> 3) < L; };
+  auto vrow_ok = [&](int idx, int which) { return 2 * (idx >> 3) + which < L; };
+  {
+    u32x4 kreg[KIT], va[VIT], vb[VIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) kreg[it] = load_k(threadIdx.x + it * nthreads);
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      va[it] = load_v(threadIdx.x + it * nthreads, 0);
+      vb[it] = load_v(threadIdx.x + it * nthreads, 1);
+    }
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = threadIdx.x + it * nthreads;
+      if (idx < Lp * 8) stage_k(idx, krow_ok(idx) ? kreg[it] : zero4);
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int idx = threadIdx.x + it * nthreads;
+      if (idx < (Lp >> 1) * 8) stage_v(idx, vrow_ok(idx, 0) ? va[it] : zero4, vrow_ok(idx, 1) ? vb[it] : zero4);
+    }
   }
+  for (int idx = threadIdx.x + KIT * nthreads; idx < Lp * 8; idx += nthreads)  // (L > 256)
+    stage_k(idx, krow_ok(idx) ? load_k(idx) : zero4);
+  for (int idx = threadIdx.x + VIT * nthreads; idx < (Lp >> 1) * 8; idx += nthreads)
+    stage_v(idx, vrow_ok(idx, 0) ? load_v(idx, 0) : zero4, vrow_ok(idx, 1) ? load_v(idx, 1) : zero4);
+  stamp();  // 1: staging stores issued
   __syncthreads();
+  stamp();  // 2: K / V visible
 
   const int kv_len = min(kv_len_p[b], L);
-  // 2 * group waves: wave w serves query head w % group and the 32-query blocks of parity w / group, so every
-  // SIMD holds two waves whose MFMA / softmax / LDS phases interleave (one wave per SIMD left the matrix
-  // pipe idle during every softmax)
-  const int head = kvh * group + (wave % group);
-  const int qb0 = wave / group;
-  const int r = lane & 31, hh = lane >> 5;
-  const int nqb = (L + 31) >> 5;
   const int kv_tiles = (kv_len + 31) >> 5;
   const int kswz = (r >> 1) & 7;
 
-  // Query blocks are dealt to the two waves of a head in PAIRS (k, nqb-1-k): a short causal block with a long one,
-  // every pair costs nqb + 1 key tiles, wave parity p takes pairs p, p + 2, ...  (8 blocks: {0,7,2,5} and {1,6,3,4},
-  // 18 key tiles each, instead of 16 / 20 with alternating blocks).
-  const int npair = (nqb + 1) >> 1;
-  for (int pr = qb0; pr < npair; pr += 2)
-  for (int mem = 0; mem < 2; ++mem) {
-    const int qb = mem ? nqb - 1 - pr : pr;
-    if (mem && qb == pr) break;  // odd block count: the middle block is its own pair
+  auto do_block = [&](int qb, const bf16x8 (&qf)[4]) {
     const int qi = qb * 32 + r;  // this lane's query row
-    const int qrow = min(qi, L - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      qf[s] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * ld + head * 64 + s * 16 + hh * 8);
-
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
@@ -174,10 +239,11 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
         { float a, b; halves(psum, a, b); psum = a + b; }
         lrun = lrun * alpha + psum;
         mrun = mnew;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+        // (unconditional: skipping the multiplication when no maximum moved -- a wave-uniform branch -- made the running
+        // output a phi of two register sets, and the compiler paid for it with 32 v_mov_b64 per key tile, half of them
+        // BETWEEN the dependent P.V MFMAs, whose latency they exposed)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-        }
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -198,12 +264,8 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
         { float a, b; halves(psum, a, b); psum = a + b; }
         lrun = lrun * alpha + psum;
         mrun = mnew;
-        // rescale the running output only when some query's maximum moved (wave-uniform; x 1.0f is exact, so
-        // skipping it changes nothing): after the first tiles of a block the maxima rarely move
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-        }
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
       }
       // O^T += V^T . P^T  (two 16-key k-steps; P registers 8*s2.. are the B operand)
 #pragma unroll
@@ -222,21 +284,63 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
         }
       }
     }
-    // ---- normalise + store: lane holds d = dt*32 + (i&3) + 8*(i>>2) + 4*hh of query qi
-    if (qi < L) {
-      const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
-      bf16_t* orow = out + ((long)b * L + qi) * (nq * 64) + head * 64;
+    // ---- normalise + store: lane holds d = dt*32 + (i&3) + 8*(i>>2) + 4*hh of query qi, i.e. per 8-dim group g the lower
+    // half-wave has dims 8g .. 8g+3 and the upper 8g+4 .. 8g+7 of the same row.  v_permlane32_swap on the packed words of
+    // two neighbouring groups leaves 16 consecutive bytes in every lane (lower half: group g whole, upper half: group g + 1
+    // whole) -> four 16-byte stores per row instead of eight 8-byte ones (the store tail is issue-bound)
+    const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+    if (ot_bytes) {
+      // Through a wave-private LDS tile [32 queries][64 dims] (rows padded to 144 bytes) so that every store instruction
+      // writes 8 whole 128-byte rows instead of 32-byte pieces of 32 rows: the row-per-lane form cost ~2.3k cycles per block
+      // (a quarter of the compute phase) in the store path, whose price goes by row segments, not bytes.
+      char* ot = smem + ot_off + wave * (32 * 144);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 8 * g + 4 * hh;
-        u32x2 a = {pack16x2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                   pack16x2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-        u32x2 c = {pack16x2<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                   pack16x2<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + d) = a;
-        *reinterpret_cast<u32x2*>(orow + 32 + d) = c;
+      for (int half = 0; half < 2; ++half) {
+        const f32x16& o = half ? o1 : o0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(ot + r * 144 + (half * 32 + 8 * g + 4 * hh) * 2) =
+              u32x2{pack16x2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv), pack16x2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv)};
+      }
+      // (same wave, in-order LDS queue: the reads below see the writes above)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = (lane >> 3) + 8 * k, q = qb * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * 144 + (lane & 7) * 16);
+        if (q < L) *reinterpret_cast<u32x4*>(out + ((long)b * L + q) * (nq * 64) + head * 64 + (lane & 7) * 8) = v;
+      }
+      stamp();
+      return;
+    }
+    bf16_t* orow = out + ((long)b * L + min(qi, L - 1)) * (nq * 64) + head * 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const f32x16& o = half ? o1 : o0;
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned int a0 = pack16x2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv), a1 = pack16x2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        unsigned int b0 = pack16x2<F16>(o[4 * g + 4] * inv, o[4 * g + 5] * inv), b1 = pack16x2<F16>(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        // lower half-wave: [own g | upper's g] = dims 8g .. 8g+7; upper: [lower's g+1 | own g+1] = dims 8(g+1) .. 8(g+1)+7
+        if (qi < L) *reinterpret_cast<u32x4*>(orow + half * 32 + 8 * g + 8 * hh) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
     }
+    stamp();  // 3 + block: block done (stores issued)
+  };
+
+#pragma unroll
+  for (int bi = 0; bi < NPRE; ++bi) {
+    const int qb = block_of(bi);
+    if (qb >= 0) do_block(qb, qpre[bi]);  // (uniform)
+  }
+  for (int bi = NPRE;; ++bi) {  // L > 256: further blocks load their queries when they start
+    if (qb0 + 2 * (bi >> 1) >= npair) break;
+    const int qb = block_of(bi);
+    if (qb < 0) continue;
+    bf16x8 qf[4];
+    load_q(qb, qf);
+    do_block(qb, qf);
   }
 }
 
@@ -421,9 +525,13 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
   TCAVT_CHECK_ARG(nkv > 0 && nq % nkv == 0 && nq / nkv <= 8, "attn_causal_gqa: nq/nkv must be an integer <= 8");
   TCAVT_CHECK_ARG(aligned16(qkv) && aligned16(out), "attn_causal_gqa: unaligned pointer");
   const int Lp = (L + 31) & ~31;
-  const int lds = Lp * 128 + 64 * (Lp + 4) * 2;
+  int lds = Lp * 128 + 64 * (Lp + 4) * 2;
   const int group = nq / nkv;
   const bool small = 2 * group * 64 <= 512;
+  // per-wave output tiles (32 x 144 bytes) behind K and V^T when the CU's LDS has room (L <= 384 for groups of 4)
+  int ot_bytes = 2 * group * 32 * 144;
+  if (((lds + 15) & ~15) + ot_bytes <= 160 * 1024 - 256) lds = ((lds + 15) & ~15) + ot_bytes;
+  else ot_bytes = 0;
   const bool f16 = dtype16 == TCAVT_F16;
   const void* fns[4] = {reinterpret_cast<const void*>(attn_causal_gqa_kernel<1024, false>),
                         reinterpret_cast<const void*>(attn_causal_gqa_kernel<512, false>),
@@ -442,7 +550,7 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
 #define TCAVT_ATTN(MAXT, F)                                                                                       \
   hipLaunchKernelGGL((attn_causal_gqa_kernel<MAXT, F>), dim3(B * nkv), dim3(2 * group * 64), lds,                  \
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), \
-                     kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f)
+                     kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes)
   if (which == 0) TCAVT_ATTN(1024, false);
   else if (which == 1) TCAVT_ATTN(512, false);
   else if (which == 2) TCAVT_ATTN(1024, true);
@@ -492,3 +600,22 @@ extern "C" int tcavt_mha(const void* q, int64_t ldq, const void* k, int64_t ldk,
   TCAVT_CHECK_LAUNCH("mha");
   return TCAVT_OK;
 }
+
+#ifdef TCAVT_EXPERIMENTS
+// tools/attn_stamps.py: the fp16, group-4 instantiation with s_memtime stamps (stamps: [B * nkv][8][16] uint64)
+extern "C" int tcavt_attn_causal_gqa_stamped(const void* qkv, void* out, const int32_t* kv_len, int B, int L, int nq, int nkv,
+                                             float scale, unsigned long long* stamps, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv && out && kv_len && stamps && nq / nkv == 4 && L <= 544, "attn_causal_gqa_stamped: bad args");
+  const int Lp = (L + 31) & ~31;
+  int lds = Lp * 128 + 64 * (Lp + 4) * 2;
+  int ot_bytes = 8 * 32 * 144;
+  if (((lds + 15) & ~15) + ot_bytes <= 160 * 1024 - 256) lds = ((lds + 15) & ~15) + ot_bytes;
+  else ot_bytes = 0;
+  auto kfn = attn_causal_gqa_kernel<512, true, true>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  hipLaunchKernelGGL(kfn, dim3(B * nkv), dim3(512), lds, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
+                     static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes, stamps);
+  TCAVT_CHECK_LAUNCH("attn_causal_gqa_stamped");
+  return TCAVT_OK;
+}
+#endif
