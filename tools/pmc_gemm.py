@@ -11,8 +11,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "0"
 shape = sys.argv[2] if len(sys.argv) > 2 else "gateup"
 if shape == "attn":  # the decoder attention kernel on the bench shape: B=32, L=256, 32 q heads / 8 kv heads x 64
     B, L, nq, nkv = 32, 256, 32, 8
-    qkv = torch.randn(B * L, (nq + 2 * nkv) * 64, device=dev).to(torch.bfloat16)
-    out = torch.empty(B * L, nq * 64, dtype=torch.bfloat16, device=dev)
+    qkv = (torch.randn(B * L, (nq + 2 * nkv) * 64, device=dev) * 0.5).to(torch.float16)  # (the production storage type)
+    out = torch.empty(B * L, nq * 64, dtype=torch.float16, device=dev)
     lens = torch.randint(144, 257, (B,), device=dev, dtype=torch.int32)
     for i in range(8):
         ops.attn_causal_gqa(qkv, out, lens, B, L, nq, nkv, 0.125)
