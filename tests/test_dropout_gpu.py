@@ -193,3 +193,42 @@ def test_lora_down_fused_masks(gpu, dt, p):
     assert (t[:, 32:] == 0).all()
     if p > 0:  # the two adapters really see different masks
         assert not torch.equal(_mask(M * H, p, seed, site, dev), _mask(M * H, p, seed, site + 1, dev))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_lora_dgrad_fused_masks(gpu, dt, p):
+    """tcavt_lora_dgrad (backward of tcavt_lora_down w.r.t. its input; modify_scripts/modify_train.py:512-528 trains the adapters):
+    out = mask_q * (g_t[:, :16] . A_q) + mask_v * (g_t[:, 16:32] . A_v), each adapter under its own Philox site -- against the
+    two fp32 products masked with the oracle-equal masks; M not a multiple of 16 exercises the row guard."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(9)
+    M, H, r = 100, 256, 8
+    g_t = torch.zeros(M, 64, dtype=dt, device=dev)
+    g_t[:, :r] = torch.randn(M, r, generator=g).to(dt).to(dev)
+    g_t[:, 16:16 + r] = torch.randn(M, r, generator=g).to(dt).to(dev)
+    Aq = (torch.randn(r, H, generator=g) * 0.05).to(dt)
+    Av = (torch.randn(r, H, generator=g) * 0.05).to(dt)
+    aqT = torch.zeros(H, 64, dtype=dt, device=dev)
+    avT = torch.zeros(H, 64, dtype=dt, device=dev)
+    aqT[:, :r] = Aq.T.to(dev)
+    avT[:, 16:16 + r] = Av.T.to(dev)
+    out = torch.full((M, H), float("nan"), dtype=dt, device=dev)
+    seed, site = 0x5EEDF00D, 1031
+    ops.lora_dgrad(g_t, aqT, avT, out, dropout=(p, seed, site) if p > 0 else None, site_v=site + 1)
+    torch.cuda.synchronize()
+    pq = g_t[:, :r].float() @ Aq.float().to(dev)
+    pv = g_t[:, 16:16 + r].float() @ Av.float().to(dev)
+    if p > 0:
+        kq = _mask(M * H, p, seed, site, dev).view(M, H)
+        kv = _mask(M * H, p, seed, site + 1, dev).view(M, H)
+        ref = pq * kq / (1 - p) + pv * kv / (1 - p)
+        both_dropped = ~(kq.bool() | kv.bool())
+        assert both_dropped.any() and (out.float()[both_dropped] == 0).all()   # masked elements are exact zeros
+    else:
+        ref = pq + pv
+    assert torch.isfinite(out.float()).all()
+    e = ((out.float() - ref).norm() / ref.norm()).item()
+    assert e < (4e-3 if dt == torch.bfloat16 else 5e-4), e  # one rounding to the 16-bit type

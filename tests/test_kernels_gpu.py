@@ -628,3 +628,39 @@ def test_tlayer_stack_matches_python_composition(gpu, train, monkeypatch):
     img_p, emb_p, dec_p = run(True)
     assert torch.isfinite(img_c).all() and torch.isfinite(emb_c).all() and torch.isfinite(dec_c).all()
     assert torch.equal(img_c, img_p) and torch.equal(emb_c, emb_p) and torch.equal(dec_c, dec_p)
+
+
+def test_gemm_norm_out_16bit_stream_out_of_place(gpu):
+    """tcavt_gemm_args.norm_res16: the in-place 16-bit residual epilogue reading the stream from one buffer and writing it to
+    another (the LoRA-trainable variant's per-layer stream tape) gives the bits of the in-place form, and leaves the source
+    untouched -- 4-wave kernel (16-byte accesses) and the small-tile kernel."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(4)
+    for M, N, K in ((512, 512, 256), (96, 128, 64)):
+        a = (torch.randn(M, K, generator=g) * 0.3).to(torch.float16).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(torch.float16).to(dev)
+        h0 = torch.randn(M, N, generator=g).to(torch.float16).to(dev)
+
+        def run(src, dst, part):
+            ga = capi.GemmArgs()
+            ga.A, ga.lda, ga.W, ga.ldw, ga.C, ga.ldc = a.data_ptr(), K, w.data_ptr(), K, None, N
+            ga.M, ga.N, ga.K = M, N, K
+            ga.in_dtype, ga.out_dtype = capi.F16, capi.F32
+            ga.epilogue = capi.EPI_RESIDUAL | capi.EPI_NORM_OUT
+            ga.norm_h16, ga.norm_part = dst.data_ptr(), part.data_ptr()
+            if src is not dst:
+                ga.norm_res16 = src.data_ptr()
+            capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(ga), capi.stream_ptr()), "gemm")
+
+        inpl, p0 = h0.clone(), torch.zeros(M, N // 64, device=dev)
+        run(inpl, inpl, p0)
+        src, dst, p1 = h0.clone(), torch.zeros_like(h0), torch.zeros(M, N // 64, device=dev)
+        run(src, dst, p1)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, inpl) and torch.equal(p1, p0) and torch.equal(src, h0)
+        ref = h0.float() + a.float() @ w.float().T
+        assert _rel(dst.float(), ref) < 1e-3

@@ -512,3 +512,86 @@ def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
             tr.optimizer_step()
             l1, _ = tr.forward_backward(*args)
         assert l1.item() < l0.item()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_silu_bwd_epilogue_matches_unfused(gpu, dt):
+    """TCAVT_EPI_SILU_BWD: the dgrad GEMM of down_proj with d(silu(gate) * up) in its epilogue (in place over the taped
+    pre-activations) against the unfused pair it replaces -- gemm, then tcavt_silu_mul_bwd -- and against fp32 autograd of
+    HF's LlamaMLP arithmetic (modeling_llama.py:174-176).  The fused form does not round dL/d(act) to 16 bits in between."""
+    from tcavt_amd import ops
+    from tcavt_amd.layout import interleave_gate_up
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(21)
+    M, I, H = 512, 768, 256
+    assert ops.silu_bwd_fusable(M, I, H)
+    gh = (torch.randn(M, H, generator=g) * 0.5).to(dt)
+    w_t = (torch.randn(I, H, generator=g) * 0.06).to(dt)          # down_proj.weight^T
+    gate = torch.randn(M, I, generator=g).to(dt).float().requires_grad_(True)
+    up = torch.randn(M, I, generator=g).to(dt).float().requires_grad_(True)
+    d_act = gh.float() @ w_t.float().T
+    (torch.nn.functional.silu(gate) * up * d_act).sum().backward()
+    want = interleave_gate_up(gate.grad.T.contiguous(), up.grad.T.contiguous()).T.contiguous()
+    gu = interleave_gate_up(gate.detach().T.contiguous(), up.detach().T.contiguous()).T.contiguous().to(dt).to(dev)
+    gu_fused = gu.clone()
+    ops.gemm_silu_bwd(gh.to(dev), w_t.to(dev), gu_fused)                                   # in place
+    g_act = ops.gemm_bf16(gh.to(dev), w_t.to(dev))
+    gu_unf = gu.clone()
+    ops.silu_mul_bwd(gu_unf, g_act, gu_unf)
+    torch.cuda.synchronize()
+    tol = 6e-3 if dt == torch.bfloat16 else 8e-4
+    assert rel_err(gu_fused.float().cpu(), want) < tol
+    assert rel_err(gu_unf.float().cpu(), want) < 1.5 * tol
+    assert rel_err(gu_fused.float().cpu(), gu_unf.float().cpu()) < 1.5 * tol
+    out2 = torch.empty_like(gu)
+    ops.gemm_silu_bwd(gh.to(dev), w_t.to(dev), gu, out=out2)                               # out of place: the same bits
+    assert torch.equal(out2, gu_fused)
+    with pytest.raises(Exception):
+        ops.gemm_silu_bwd(gh[:100].to(dev), w_t.to(dev), gu[:100].clone())                 # not whole tiles: refused
+
+
+def test_grad_scale_pick_and_scaled_rmsnorm_bwd(gpu):
+    """tcavt_grad_scale_pick: S = 2^k with max|g| * S in [target / 2, target], decided on the device; all-zero and non-finite
+    inputs give S = 1.  tcavt_rmsnorm_bwd applies *gy_scale to the incoming gradient: its result under the scale, divided by S,
+    equals the unscaled call (the backward is linear)."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(3)
+    scratch = torch.zeros(1, dtype=torch.int32, device=dev)
+    scale = torch.zeros(2, device=dev)
+    for amp in (3e-7, 1.0, 7.3e4):
+        a = (torch.randn(64, 256, generator=g) * amp).to(torch.bfloat16).to(dev)
+        b = (torch.randn(64, 256, generator=g) * amp * 0.5).to(torch.bfloat16).to(dev)
+        ops.grad_scale_pick(a, b, scale, scratch)
+        S, invS = scale.tolist()
+        mx = max(a.float().abs().max().item(), b.float().abs().max().item())
+        assert S == 2.0 ** round(torch.log2(torch.tensor(S)).item()) and abs(S * invS - 1.0) < 1e-6
+        assert 128.0 <= mx * S <= 256.0, (amp, mx, S)
+        assert scratch.item() == 0  # re-armed
+    ops.grad_scale_pick(torch.zeros(8, 8, dtype=torch.bfloat16, device=dev), None, scale, scratch)
+    assert scale.tolist() == [1.0, 1.0]
+    bad = torch.ones(8, 8, dtype=torch.bfloat16, device=dev)
+    bad[0, 0] = float("inf")
+    ops.grad_scale_pick(bad, None, scale, scratch)
+    assert scale.tolist() == [1.0, 1.0]
+    # the scale enters through the RMSNorm backward; x may be fp32 or the 16-bit stream of the tape
+    M, H = 40, 256
+    x32 = torch.randn(M, H, generator=g)
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    gy = (torch.randn(M, H, generator=g) * 1e-3).to(torch.bfloat16).to(dev)
+    ops.grad_scale_pick(gy, None, scale, scratch)
+    for x in (x32.to(dev), x32.to(torch.float16).to(dev)):
+        g0 = torch.empty(M, H, device=dev)
+        g1 = torch.empty(M, H, device=dev)
+        gb = torch.empty(M, H, dtype=torch.float16, device=dev)
+        ops.rmsnorm_bwd(x, gamma, gy, g0, 1e-5)
+        ops.rmsnorm_bwd(x, gamma, gy, g1, 1e-5, gx_bf16=gb, gy_scale=scale[0:1])
+        torch.cuda.synchronize()
+        assert rel_err((g1 * scale[1]).cpu(), g0.cpu()) < 1e-6
+        assert torch.equal(gb, g1.to(torch.float16)) and gb.float().abs().max().item() > 1.0   # in the half range thanks to S
+        xr = x.float().cpu().clone().requires_grad_(True)   # (autograd on the values the kernel read)
+        y = xr * torch.rsqrt((xr * xr).mean(-1, keepdim=True) + 1e-5) * gamma.cpu()
+        (y * gy.float().cpu()).sum().backward()
+        assert rel_err(g0.cpu(), xr.grad) < 1e-5
