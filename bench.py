@@ -27,6 +27,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the pool's host driver supports dmabuf IPC only: without this RCCL's peer mappings fail in hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

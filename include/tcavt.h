@@ -176,6 +176,13 @@ typedef struct tcavt_gemm_args {
    * (leading dimension ldc) and the updated stream written to norm_h16 -- out of place, so that a caller can keep the
    * stream of every layer (the LoRA-trainable variant's tape).  NULL: read from norm_h16 (in place). */
   const void* norm_res16;
+  /* Skinny form only (M <= 32: the decode step), optional: a device workspace that lets the launch split K over several
+   * workgroups per block of output columns (partial sums in fp32 slabs, combined by the last arriver in slice order:
+   * bit-reproducible).  Layout: 4096 int32 tickets, ZEROED ONCE by the caller (every launch leaves them zero), then the slabs;
+   * >= 64 KiB, 8.2 MiB covers every shape of the Llama-3.2-1B decode step.  Launches that share it must be stream-ordered.
+   * NULL: one workgroup per column block over all of K (N / 16 workgroups). */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -873,6 +880,8 @@ typedef struct tcavt_decode_args {
   int32_t n_layers, B, H, I, nq, nkv, V, dtype16, kv_lmax, rope_L;
   float rms_eps, lora_scale;
   int32_t* nonfinite_flag;         /* optional, as tcavt_llama_stack_args.nonfinite_flag */
+  void* splitk_ws;                 /* optional: tcavt_gemm_args.splitk_ws for the step's projections (tickets zeroed once) */
+  int64_t splitk_ws_bytes;
 } tcavt_decode_args;
 
 int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);

@@ -491,6 +491,91 @@ def test_skinny_gemm_matches_tile_kernels(gpu, M, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 8, 32])
+def test_skinny_gemm_split_k_across_workgroups(gpu, M, dt):
+    """tcavt_gemm_args.splitk_ws: with a workspace the skinny form splits K over several workgroups per column block (fp32
+    slabs + ticket, the last arriver adds the slices in order and runs the epilogue).  At the decode step's own shapes
+    (Llama-3.2-1B: q|k|v 3072 x 2048 RoPE + LoRA + row scale, o 2048 x 2048 and down 2048 x 8192 residual + 16-bit copy +
+    sums of squares, gate|up 16384 x 2048 SiLU) the result must equal the one-workgroup form to summation-order noise, be
+    bit-identical from launch to launch, leave the tickets at zero, and the LoRA source must be added exactly once."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(4100 + M)
+    ws = torch.zeros(9 << 20, dtype=torch.uint8, device=dev)
+    ws[16 << 10:] = 0x7F  # (slabs start as garbage: every word read must have been written by this launch)
+
+    def run(x, K, N, epi, w, out, split, **kw):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), K, None if out is None else out.data_ptr(), N if out is None else out.stride(0)
+        a.M, a.N, a.K, a.tile, a.epilogue = M, N, K, 0, epi
+        a.in_dtype, a.out_dtype = ops._DT[dt], capi.F32 if out is None else ops._DT[out.dtype]
+        if split:
+            a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+        capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()), "gemm")
+
+    def tickets_clear():
+        return int(ws[: 16 << 10].view(torch.int32).abs().sum()) == 0
+
+    tol = 2e-3 if dt == torch.float16 else 8e-3
+    K = 2048
+    x = torch.randn(M, K, generator=g).to(dt).to(dev)
+    part = (torch.rand(M, 128, generator=g) * 40 + 10).to(dev)
+    rs = dict(rowscale_part=part, rowscale_npart=128, rowscale_h=K, rowscale_eps=1e-5)
+    # q|k|v
+    N = 3072
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(dev)
+    t2 = torch.randn(M, 64, generator=g).to(dt).to(dev)
+    w2 = (torch.randn(N, 64, generator=g) * 0.2).to(dt).to(dev)
+    cos, sin = torch.rand(50, 32, generator=g).to(dev), torch.rand(50, 32, generator=g).to(dev)
+    pos = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(dev)
+    kw = dict(A2=t2, lda2=64, W2=w2, ldw2=64, K2=64, rope_cos=cos, rope_sin=sin, rope_L=50, rope_cols=2560, rope_pos=pos, **rs)
+    o = [torch.empty(M, N, dtype=dt, device=dev) for _ in range(3)]
+    run(x, K, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, w, o[0], False, **kw)
+    run(x, K, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, w, o[1], True, **kw)
+    run(x, K, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, w, o[2], True, **kw)
+    assert _rel(o[1].float(), o[0].float()) < tol and torch.equal(o[1], o[2]) and tickets_clear()
+    # gate|up
+    N = 16384
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(dev)
+    o = [torch.empty(M, N // 2, dtype=dt, device=dev) for _ in range(3)]
+    for i in range(3):
+        run(x, K, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, w, o[i], i > 0, **rs)
+    assert _rel(o[1].float(), o[0].float()) < tol and torch.equal(o[1], o[2]) and tickets_clear()
+    # o (K = 2048) and down (K = 8192): fp32 stream and 16-bit stream
+    changed = False
+    for K in (2048, 8192):
+        N = 2048
+        x = torch.randn(M, K, generator=g).to(dt).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(dev)
+        res = torch.randn(M, N, generator=g).to(dev)
+        outs = []
+        for i in range(3):
+            h16 = torch.zeros(M, N, dtype=dt, device=dev)
+            pt = torch.zeros(M, N // 16, device=dev)
+            c = torch.empty(M, N, device=dev)
+            run(x, K, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, w, c, i > 0, residual=res, ldr=N, norm_h16=h16, norm_part=pt)
+            outs.append((c, h16, pt))
+        assert _rel(outs[1][0], outs[0][0]) < 1e-5 and _rel(outs[1][2].sum(1), outs[0][2].sum(1)) < 1e-5
+        assert _rel(outs[1][0], x.float() @ w.float().T + res) < 1e-5
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[1], outs[2])) and tickets_clear()
+        changed |= not torch.equal(outs[1][0], outs[0][0])
+        outs = []
+        for i in range(3):
+            h16 = res.to(dt)
+            pt = torch.zeros(M, N // 16, device=dev)
+            run(x, K, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, w, None, i > 0, norm_h16=h16, norm_part=pt)  # (in place: h16 += x W^T)
+            outs.append((h16, pt))
+        assert _rel(outs[1][0].float(), outs[0][0].float()) < tol and _rel(outs[1][1].sum(1), outs[0][1].sum(1)) < tol
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[1], outs[2])) and tickets_clear()
+    assert changed  # (a different summation order: the split really ran)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,tile", [(300, 128), (300, 256), (512, 257), (512, 272), (512, 0), (20, 0)])
 def test_gemm_norm_out_fp32_and_16bit_stream(gpu, M, tile, dt):
     """TCAVT_EPI_NORM_OUT on every kernel form that serves it, in both residual-stream modes:

@@ -56,7 +56,7 @@ class GemmArgs(ctypes.Structure):
         ("reserved1", ctypes.c_int32),
         ("rope_pos", c_void_p),
         ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
-        ("norm_res16", c_void_p),
+        ("norm_res16", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
     ]
 
 
@@ -179,7 +179,8 @@ class DecodeArgs(ctypes.Structure):
         "gamma_final", "rope_cos", "rope_sin", "table", "txt_mod", "cur_tok", "pos", "h", "h16", "part", "qkv", "att", "act",
         "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
-        ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p)]
+        ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p),
+        ("splitk_ws_bytes", c_int64)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)

@@ -59,6 +59,13 @@ struct GemmP {
   float rs_eps, rs_inv_h;
   const int* rope_pos;    // ROPE: position of row m (decode step: one row per sample); NULL: m % rope_L
   const bf16_t* res16;    // NORM16: where the 16-bit residual is read from (norm_h16 itself unless the caller keeps every layer's stream)
+  // skinny form, split K across workgroups (decode step): S = sk_split workgroups share one block of output columns, each
+  // over K / S; partial sums meet in sk_slab, the last arriver (ticket in sk_cnt) adds them in slice order and finishes
+  int sk_split;
+  float* sk_slab;
+  int* sk_cnt;
+  long sk_slab_bytes;
+  int sk_cnt_n;
   int* nf_flag;           // NORM_OUT: receives nf_tag (CAS from 0) when a partial sum / rounded element is not finite
   int nf_tag;
 };
@@ -1757,29 +1764,52 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 
 constexpr int SK_WAVES = 8;
 
+// agent-scope store / load of four floats (relaxed atomics: global_store / global_load ... sc1, coherent across the XCDs)
+__device__ __forceinline__ void sk_store(float* ptr, f32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) __hip_atomic_store(ptr + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 sk_load(const float* ptr) {
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(ptr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
 template <int EPI, int NCB, bool F16>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   __shared__ f32x4 red[SK_WAVES][NCB * 2][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n0 = blockIdx.x * (16 * NCB);
+  // Split K (p.sk_split = S > 1): the S slices of one column block get ids that are congruent mod 8 -- workgroups are dealt
+  // round-robin to the 8 XCDs, so the slabs the last arriver reads were written through its own XCD's L2 (a speed choice
+  // only: the hand-off below is correct for any placement).  Host: (number of column blocks) % 8 == 0 when S > 1.
+  const int S = p.sk_split;
+  int blk = blockIdx.x, ks = 0;
+  if (S > 1) {
+    const int q = blockIdx.x >> 3;
+    ks = q % S;
+    blk = (q / S) * 8 + (blockIdx.x & 7);
+  }
+  const int n0 = blk * (16 * NCB);
   const int r16 = lane & 15, kq = lane >> 4;
   // first output column of column block c.  RoPE: a workgroup owns the two 16-column blocks of one head that rotate
   // together (dimensions d and d + 32), so that two workgroups share a head (96 workgroups for the fused q|k|v instead of 48)
   int ncol[NCB];
 #pragma unroll
   for (int c = 0; c < NCB; ++c)
-    ncol[c] = EPI == EPI_ROPE ? (blockIdx.x >> 1) * 64 + (blockIdx.x & 1) * 16 + c * 32 : n0 + c * 16;
+    ncol[c] = EPI == EPI_ROPE ? (blk >> 1) * 64 + (blk & 1) * 16 + c * 32 : n0 + c * 16;
   f32x4 acc[NCB][2];
 #pragma unroll
   for (int c = 0; c < NCB; ++c) acc[c][0] = acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // this wave's K slice: K / 8 (K % 256 == 0), 32 per MFMA step
-  const int kper = p.K / SK_WAVES;
+  // this wave's K slice: K / (8 S) (a multiple of 32), 32 per MFMA step
+  const int kper = p.K / (SK_WAVES * S);
+  const int kbeg = (ks * SK_WAVES + wave) * kper;
   const bf16_t* wp[NCB];
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(ncol[c] + r16) * p.ldw + wave * kper + kq * 8;
-  const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + wave * kper + kq * 8;
-  const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + wave * kper + kq * 8;
+  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
+  const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + kbeg + kq * 8;
+  const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bool two = p.M > 16;
   constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
   // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
@@ -1810,11 +1840,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       if constexpr (EPI == EPI_ROPE) {
         if (ncol[0] < p.rope_cols) {
           const int pos = p.rope_pos ? p.rope_pos[pmm] : (int)(pmm % p.rope_L);
-          const int d = (blockIdx.x & 1) * 16 + 4 * kq;
+          const int d = (blk & 1) * 16 + 4 * kq;
           rope_c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
           rope_s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
         }
-        if (wave == 0 && p.K2 > 0) {
+        if (wave == 0 && p.K2 > 0 && ks == 0) {  // (the second K source is added once: by slice 0)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (32 * u < p.K2) {
@@ -1845,8 +1875,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       }
     }
   }
-  if constexpr (EPI == EPI_ROPE) {  // LoRA second K source (K2 = 64: two steps), done by wave 0
-    if (p.K2 > 0 && wave == 0) {
+  if constexpr (EPI == EPI_ROPE) {  // LoRA second K source (K2 = 64: two steps), done by wave 0 (of slice 0)
+    if (p.K2 > 0 && wave == 0 && ks == 0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {  // the first two steps come from the registers filled under the first weight batch
         if (32 * u < p.K2) {
@@ -1875,20 +1905,58 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     red[wave][c * 2 + 1][lane] = acc[c][1];
   }
   __syncthreads();
-  if (wave >= 2 || (wave == 1 && !two)) return;
+  const bool finisher = wave == 0 || (wave == 1 && two);
+  if (S <= 1 && !finisher) return;
   // ---- wave mb (0 / 1) finishes token block mb: lane holds features 4 (lane >> 4) .. + 3 of every column block for
   // token m = 16 mb + (lane & 15); the partials are added in wave order
-  const int mb = wave;
+  const int mb = wave & 1;
   const int m = mb * 16 + r16, nq = 4 * kq;
   const bool rowok = m < p.M;
   const long mm = rowok ? m : 0;
   f32x4 v[NCB];
+  if (finisher) {
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) {
-    f32x4 t = red[0][c * 2 + mb][lane];
+    for (int c = 0; c < NCB; ++c) {
+      f32x4 t = red[0][c * 2 + mb][lane];
 #pragma unroll
-    for (int w = 1; w < SK_WAVES; ++w) t += red[w][c * 2 + mb][lane];
-    v[c] = t;
+      for (int w = 1; w < SK_WAVES; ++w) t += red[w][c * 2 + mb][lane];
+      v[c] = t;
+    }
+  }
+  if (S > 1) {
+    // ---- cross-workgroup combine: every slice writes its partial sums to its slab, every storing wave drains its stores,
+    // barrier, ONE agent-scope ticket; the workgroup that draws S - 1 adds the S slabs in slice order (bit-reproducible
+    // whatever the arrival order) and runs the epilogue.  The counter is re-armed by the last arriver (zeroed once by the
+    // caller before first use).  The slabs move with agent-scope (sc1) stores and loads -- write-through to / read from the
+    // point where the 8 XCDs' L2s agree -- and the order "slab stores complete -> ticket" is the s_waitcnt + barrier: the
+    // release / acquire FENCES that plain stores would need write back and invalidate a whole L2 per workgroup
+    // (buffer_wbl2 / buffer_inv: measured + 10 us per launch, twice what the split gains).
+    float* slab = p.sk_slab + ((long)(blk * S + ks) * 2 * NCB) * 256;  // [mb][c][64 lanes][4]
+    if (finisher) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) sk_store(slab + ((mb * NCB + c) * 64 + lane) * 4, v[c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last_flag = reinterpret_cast<int*>(&red[0][0][0]);  // (the one LDS array: all waves are past their reads of it)
+    if (threadIdx.x == 0) {
+      const int ticket = __hip_atomic_fetch_add(p.sk_cnt + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == S - 1;
+      if (last) __hip_atomic_store(p.sk_cnt + blk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+      *last_flag = last;
+    }
+    __syncthreads();
+    if (*last_flag == 0 || !finisher) return;
+    const float* base = p.sk_slab + ((long)(blk * S) * 2 * NCB) * 256;
+    f32x4 part[NCB];
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) v[c] = sk_load(base + ((mb * NCB + c) * 64 + lane) * 4);
+    for (int s2 = 1; s2 < S; ++s2) {
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) part[c] = sk_load(base + (long)s2 * 2 * NCB * 256 + ((mb * NCB + c) * 64 + lane) * 4);
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) v[c] += part[c];
+    }
   }
   constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
   if constexpr (EPI == EPI_GENERIC) {
@@ -1925,7 +1993,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     if (lane < 16 && rowok) {
-      p.norm_part[(long)m * gridDim.x + blockIdx.x] = ss;
+      p.norm_part[(long)m * (p.N / (16 * NCB)) + blk] = ss;
       flag_nonfinite(p, ss);
     }
   } else if constexpr (EPI == EPI_SILU) {
@@ -1955,7 +2023,19 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
 
 template <int EPI, int NCB, bool F16>
 static int launch_skinny(const GemmP& p, hipStream_t stream) {
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(p.N / (16 * NCB)), dim3(SK_WAVES * 64), 0, stream, p);  // (RoPE: N / 64 heads x 2 halves = N / 32)
+  GemmP q = p;
+  const int nblk = p.N / (16 * NCB);  // (RoPE: N / 64 heads x 2 halves = N / 32)
+  // split K over S workgroups per column block when the caller lent a workspace: the decode step's projections are streams of
+  // their weights, and N / 16 workgroups of 8 waves (128 for N = 2048: half the CUs, 4 KB per wave in flight) cannot keep the
+  // memory system busy -- S is chosen so that ~two workgroups per CU stream, each wave's K slice staying a multiple of 32
+  int S = 1;
+  if (p.sk_slab && p.sk_cnt && nblk % 8 == 0) {
+    static const int max_wg = [] { const char* e = getenv("TCAVT_SK_MAXWG"); return e ? atoi(e) : 640; }();
+    while (S < 8 && nblk * S * 2 <= max_wg && p.K % (SK_WAVES * S * 2 * 32) == 0) S *= 2;
+    if ((long)nblk * S * 2 * NCB * 256 * 4 > p.sk_slab_bytes || nblk > p.sk_cnt_n) S = 1;
+  }
+  q.sk_split = S;
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(nblk * S), dim3(SK_WAVES * 64), 0, stream, q);
   TCAVT_CHECK_LAUNCH("gemm_bf16(skinny)");
   return TCAVT_OK;
 }
@@ -2050,6 +2130,18 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.norm_h16 = nullptr;
   p.norm_part = nullptr;
   p.res16 = nullptr;
+  p.sk_split = 1;
+  p.sk_slab = nullptr;
+  p.sk_cnt = nullptr;
+  p.sk_slab_bytes = 0;
+  p.sk_cnt_n = 0;
+  if (a->splitk_ws && a->splitk_ws_bytes >= (64 << 10)) {  // [0, 16 KiB): 4096 tickets; the rest: slabs
+    TCAVT_CHECK_ARG(aligned16(a->splitk_ws), "gemm_bf16: splitk_ws must be 16-byte aligned");
+    p.sk_cnt = static_cast<int*>(a->splitk_ws);
+    p.sk_cnt_n = 4096;
+    p.sk_slab = reinterpret_cast<float*>(static_cast<char*>(a->splitk_ws) + (16 << 10));
+    p.sk_slab_bytes = a->splitk_ws_bytes - (16 << 10);
+  }
   p.nf_flag = (epi & TCAVT_EPI_NORM_OUT) ? a->nonfinite_flag : nullptr;
   p.nf_tag = a->nonfinite_tag;
   p.rs_part = nullptr;

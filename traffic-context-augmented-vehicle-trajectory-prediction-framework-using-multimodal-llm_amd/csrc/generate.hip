@@ -507,6 +507,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       tcavt_gemm_args g = {};
       g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
       g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {
@@ -518,6 +519,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->rope_L; g.rope_cols = (nq + nkv) * 64;
       g.rope_pos = a->pos;
       g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     bf16_t* kc = static_cast<bf16_t*>(a->k_cache) + li * per_layer;
@@ -537,6 +539,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {
@@ -545,6 +548,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
       g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {
@@ -554,6 +558,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
   }
@@ -563,5 +568,6 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   tcavt_gemm_args g = {};
   g.A = a->x16; g.lda = H; g.W = a->table; g.ldw = H; g.C = a->logits; g.ldc = a->V;
   g.M = B; g.N = a->V; g.K = H; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
+  g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
   return tcavt_gemm_bf16(&g, stream);
 }

@@ -1090,6 +1090,11 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     a.k_cache, a.v_cache, a.kv_lmax = kc.data_ptr(), vc.data_ptr(), Lmax
                     a.x16, a.logits, a.bad_id_flag = x16.data_ptr(), logits.data_ptr(), flags.data_ptr()
                     a.nonfinite_flag = flags[2:3].data_ptr()
+                    # K split across workgroups (tcavt_gemm_args.splitk_ws): off by default -- measured 1.30 vs 1.22 ms per step
+                    # at B = 8 and 1.84 vs 1.87 at B = 32 (the hand-off costs what the split gains)
+                    if os.environ.get("TCAVT_DECODE_SPLITK", "0") == "1":
+                        skws = ws.get("gen.splitk", (9 << 20,), torch.uint8, dev, zero=True)  # tickets zeroed once, slabs behind
+                        a.splitk_ws, a.splitk_ws_bytes = skws.data_ptr(), skws.numel()
                     a.n_layers, a.B, a.H, a.I, a.nq, a.nkv, a.V = ll.layers, B, H, ll.inter, ll.n_q_heads, ll.n_kv_heads, ll.vocab
                     a.dtype16 = capi.F16 if st == torch.float16 else capi.BF16
                     a.rms_eps, a.lora_scale = ll.rms_eps, (LW.lora_alpha / LW.lora_r) if LW.use_lora else 0.0

@@ -62,13 +62,16 @@ def _drop(d):
 
 
 def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual=None, a2=None,
-              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None, silu_preact=None):
+              w2=None, silu_mul=False, rope=None, tile=0, acc_scale=1.0, dropout=None, silu_preact=None, splitk_ws=None):
     """C = a @ w.T (+ a2 @ w2.T) with fused epilogue.  a [M,K], w [N,K]: both fp16 or both bf16 (the name is
     historical); out: fp32 or either 16-bit type (default: the operands' type).
 
     silu_preact (with silu_mul): bf16 [M, N] buffer that receives the gate|up pre-activations (for silu_mul_bwd).
 
     rope = (cos [L,32] f32, sin [L,32] f32, rope_cols) applies RoPE with position m % L.
+
+    splitk_ws (M <= 32 only): uint8 device workspace (>= 64 KiB, first 16 KiB zeroed once) that lets the skinny form split K
+    across workgroups -- tcavt_gemm_args.splitk_ws.
     """
     _req16(a, "gemm_bf16.a", rows_ok=True)  # (A may be a column slice: lda = its row stride)
     _req16(w, "gemm_bf16.w", like=a, rows_ok=True)
@@ -130,6 +133,9 @@ def gemm_bf16(a, w, out=None, *, out_dtype=None, bias=None, relu=False, residual
     args.tile = tile
     args.acc_scale = acc_scale
     args.dropout_p, args.dropout_seed, args.dropout_site = _drop(dropout)
+    if splitk_ws is not None:
+        _req(splitk_ws, torch.uint8, "gemm_bf16.splitk_ws")
+        args.splitk_ws, args.splitk_ws_bytes = splitk_ws.data_ptr(), splitk_ws.numel()
     check(lib().tcavt_gemm_bf16(ctypes.byref(args), stream_ptr()), "tcavt_gemm_bf16")
     return out
 
