@@ -183,6 +183,19 @@ typedef struct tcavt_gemm_args {
    * NULL: one workgroup per column block over all of K (N / 16 workgroups). */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
+  /* Skinny form only (decode step), optional: the NEXT layer's LoRA down-projection t = scale * h16 . a_cat^T without a launch
+   * of its own (r <= 8: adapter rows 0..7 = A_q and 16..23 = A_v of a_cat [>= 24, lda]).
+   *   producer = a residual GEMM (TCAVT_EPI_NORM_OUT) with lora_part + lora_part_a: workgroup b (16 output columns) also writes
+   *     lora_part[b][m][16] (fp32) = the dot products of ITS columns of the rounded 16-bit stream with the 16 adapter rows;
+   *   consumer = the q|k|v GEMM (TCAVT_EPI_ROPE) with lora_part + lora_part_np (= producer's N / 16) + W2 (= b_ext [N, ldw2 >= 32])
+   *     and A2 == NULL, K2 == 0: t[m][j] = round16(lora_part_scale * sum_b lora_part[b][m][j]), partials added in index
+   *     order (bit-reproducible), then used as the second K source (32 deep).
+   * lora_part: M * 16 * (N / 16) floats, 16-byte aligned. */
+  void* lora_part;
+  const void* lora_part_a;
+  int64_t lora_part_lda;
+  int32_t lora_part_np;
+  float lora_part_scale;
 } tcavt_gemm_args;
 
 int tcavt_gemm_bf16(const tcavt_gemm_args* args, tcavt_stream_t stream);
@@ -882,6 +895,11 @@ typedef struct tcavt_decode_args {
   int32_t* nonfinite_flag;         /* optional, as tcavt_llama_stack_args.nonfinite_flag */
   void* splitk_ws;                 /* optional: tcavt_gemm_args.splitk_ws for the step's projections (tickets zeroed once) */
   int64_t splitk_ws_bytes;
+  void* lora_part;                 /* optional, B * H floats: layers 1.. take their LoRA down-projection from partial sums the
+                                      previous layer's down-projection GEMM leaves here (tcavt_gemm_args.lora_part: one launch
+                                      per layer less); adapters of rank <= 8 only (lora_rank), NULL = a launch per layer */
+  int32_t lora_rank;
+  int32_t reserved3;
 } tcavt_decode_args;
 
 int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);

@@ -575,6 +575,92 @@ def test_skinny_gemm_split_k_across_workgroups(gpu, M, dt):
     assert changed  # (a different summation order: the split really ran)
 
 
+@pytest.mark.parametrize("stream16", [True, False])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 8, 13, 32])
+def test_skinny_gemm_lora_down_from_partial_sums(gpu, M, dt, stream16):
+    """tcavt_gemm_args.lora_part (decode step): the down-projection GEMM's workgroups leave the partial dot products of their
+    16 columns of the rounded residual stream with the next layer's adapter rows, and the q|k|v GEMM adds them up in place of
+    the separate LoRA down-projection launch.  Against the two-launch form (t = scale * h16 . a_cat^T as a GEMM of its own,
+    then A2 = t) at the decode step's shapes: equal up to one 16-bit rounding of t (its summation order differs), and the
+    adapter term must be a visible part of the output."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(5200 + M)
+    H, I, NQKV, r, LV = 2048, 8192, 3072, 8, 16
+    x = torch.randn(M, I, generator=g).to(dt).to(dev)
+    w_d = (torch.randn(H, I, generator=g) * 0.02).to(dt).to(dev)
+    res = torch.randn(M, H, generator=g).to(dev)
+    a_cat = torch.zeros(64, H)
+    a_cat[:r] = torch.randn(r, H, generator=g) * 0.05
+    a_cat[LV:LV + r] = torch.randn(r, H, generator=g) * 0.05
+    a_cat = a_cat.to(dt).to(dev)
+    b_ext = torch.zeros(NQKV, 64)
+    b_ext[:2048, :r] = torch.randn(2048, r, generator=g) * 0.3
+    b_ext[2560:, LV:LV + r] = torch.randn(512, r, generator=g) * 0.3
+    b_ext = b_ext.to(dt).to(dev)
+    w_qkv = (torch.randn(NQKV, H, generator=g) * 0.03).to(dt).to(dev)
+    cos, sin = torch.rand(50, 32, generator=g).to(dev), torch.rand(50, 32, generator=g).to(dev)
+    pos = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(dev)
+    scale = 4.0
+
+    def gemm(A, K, W, N, out, epi, **kw):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw = A.data_ptr(), K, W.data_ptr(), K
+        a.C, a.ldc = (None, N) if out is None else (out.data_ptr(), out.stride(0))
+        a.M, a.N, a.K, a.tile, a.epilogue = M, N, K, 0, epi
+        a.in_dtype, a.out_dtype = ops._DT[dt], capi.F32 if out is None else ops._DT[out.dtype]
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+        capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()), "gemm")
+
+    def down(lp):
+        h16 = res.to(dt) if stream16 else torch.zeros(M, H, dtype=dt, device=dev)
+        part = torch.zeros(M, H // 16, device=dev)
+        kw = dict(norm_h16=h16, norm_part=part)
+        c = None
+        if not stream16:
+            c = torch.empty(M, H, device=dev)
+            kw.update(residual=res, ldr=H)
+        if lp is not None:
+            kw.update(lora_part=lp, lora_part_a=a_cat, lora_part_lda=H)
+        gemm(x, I, w_d, H, c, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, **kw)
+        return h16, part
+
+    rope = dict(rope_cos=cos, rope_sin=sin, rope_L=50, rope_cols=2560, rope_pos=pos)
+    # two launches
+    h16, part = down(None)
+    t = torch.zeros(M, 64, dtype=dt, device=dev)
+    gemm(h16, H, a_cat, 64, t, 0, acc_scale=scale)
+    rs = dict(rowscale_part=part, rowscale_npart=H // 16, rowscale_h=H, rowscale_eps=1e-5)
+    want = torch.empty(M, NQKV, dtype=dt, device=dev)
+    gemm(h16, H, w_qkv, NQKV, want, capi.EPI_ROPE | capi.EPI_ROWSCALE, A2=t, lda2=64, W2=b_ext, ldw2=64, K2=64, **rope, **rs)
+    plain = torch.empty(M, NQKV, dtype=dt, device=dev)
+    gemm(h16, H, w_qkv, NQKV, plain, capi.EPI_ROPE | capi.EPI_ROWSCALE, **rope, **rs)
+    # partial sums
+    lp = torch.full((H // 16, M, 16), float("nan"), device=dev)
+    h16b, partb = down(lp)
+    assert torch.equal(h16b, h16) and torch.equal(partb, part)
+    t_ref = (h16.float() @ a_cat.float().T)[:, list(range(r)) + list(range(LV, LV + r))]
+    assert _rel(lp.sum(0), t_ref) < 1e-5
+    got = [torch.empty(M, NQKV, dtype=dt, device=dev) for _ in range(2)]
+    for o in got:
+        gemm(h16, H, w_qkv, NQKV, o, capi.EPI_ROPE | capi.EPI_ROWSCALE, W2=b_ext, ldw2=64, lora_part=lp, lora_part_np=H // 16,
+             lora_part_scale=scale, **rope, **rs)
+    assert torch.equal(got[0], got[1])
+    ulp = 2.0 ** (-10 if dt == torch.float16 else -7)
+    assert _rel(want.float(), plain.float()) > 0.05                 # the adapters matter here
+    assert _rel(got[0].float(), want.float()) < 2 * ulp             # ... and arrive the same way (t within one rounding)
+    assert torch.equal(got[0][:, 2048:2560], want[:, 2048:2560])    # k rows of b_ext are zero: untouched
+    # refused outside the decode step's form
+    with pytest.raises(capi.TcavtError):
+        gemm(h16, H, w_qkv, NQKV, got[0], capi.EPI_ROPE | capi.EPI_ROWSCALE, W2=b_ext, ldw2=64, lora_part=lp, lora_part_np=0,
+             lora_part_scale=scale, **rope, **rs)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,tile", [(300, 128), (300, 256), (512, 257), (512, 272), (512, 0), (20, 0)])
 def test_gemm_norm_out_fp32_and_16bit_stream(gpu, M, tile, dt):

@@ -57,6 +57,8 @@ class GemmArgs(ctypes.Structure):
         ("rope_pos", c_void_p),
         ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
         ("norm_res16", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
+        ("lora_part", c_void_p), ("lora_part_a", c_void_p), ("lora_part_lda", c_int64), ("lora_part_np", c_int),
+        ("lora_part_scale", c_float),
     ]
 
 
@@ -180,7 +182,7 @@ class DecodeArgs(ctypes.Structure):
         "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
         ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p),
-        ("splitk_ws_bytes", c_int64)]
+        ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("reserved3", c_int)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)

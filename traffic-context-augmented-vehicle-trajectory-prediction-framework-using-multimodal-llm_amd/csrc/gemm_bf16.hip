@@ -61,6 +61,15 @@ struct GemmP {
   const bf16_t* res16;    // NORM16: where the 16-bit residual is read from (norm_h16 itself unless the caller keeps every layer's stream)
   // skinny form, split K across workgroups (decode step): S = sk_split workgroups share one block of output columns, each
   // over K / S; partial sums meet in sk_slab, the last arriver (ticket in sk_cnt) adds them in slice order and finishes
+  // skinny form (decode step): the NEXT layer's LoRA down-projection folded into this layer's residual GEMM and q|k|v GEMM.
+  // Producer (NORM_OUT forms, lp_a != nullptr): every workgroup also writes t_part[blk][m][16] = its 16 output columns of the
+  // rounded stream times the 16 adapter rows (A_q rows 0..7, A_v rows LORA_V..LORA_V+7 of a_cat).  Consumer (RoPE form,
+  // lp_np > 0): t = round16(lp_scale * sum over the lp_np partials, in index order) replaces the A2 operand (K2 = 32).
+  float* lp_part;
+  const bf16_t* lp_a;
+  long lp_lda;
+  int lp_np;
+  float lp_scale;
   int sk_split;
   float* sk_slab;
   int* sk_cnt;
@@ -1779,8 +1788,15 @@ __device__ __forceinline__ f32x4 sk_load(const float* ptr) {
 template <int EPI, int NCB, bool F16>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   __shared__ f32x4 red[SK_WAVES][NCB * 2][64];
+  // fused LoRA down-projection, consumer side (RoPE form): group sums of the partials, then t as 16-bit rows [32][32]
+  __shared__ float lp_sum[EPI == EPI_ROPE ? 512 : 1];
+  __shared__ __attribute__((aligned(16))) bf16_t lp_t[EPI == EPI_ROPE ? 32 * 32 : 8];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool lp_in = EPI == EPI_ROPE && p.lp_np > 0;
+  if constexpr (EPI == EPI_ROPE) {
+    if (lp_in) reinterpret_cast<unsigned int*>(lp_t)[threadIdx.x] = 0u;  // 512 threads x 4 B = the whole tile
+  }
   // Split K (p.sk_split = S > 1): the S slices of one column block get ids that are congruent mod 8 -- workgroups are dealt
   // round-robin to the 8 XCDs, so the slabs the last arriver reads were written through its own XCD's L2 (a speed choice
   // only: the hand-off below is correct for any placement).  Host: (number of column blocks) % 8 == 0 when S > 1.
@@ -1822,6 +1838,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   f32x4 rope_c = {1.f, 1.f, 1.f, 1.f}, rope_s = {0.f, 0.f, 0.f, 0.f};
   u32x2 old16[NCB];
   u32x4 l_a0[2], l_a1[2], l_w[2][NCB];
+  constexpr bool NORMF = EPI == EPI_NORM || EPI == EPI_NORM16;
+  u32x2 lp_af[NORMF ? NCB : 1][NORMF ? 16 : 1];  // producer: this lane's 4 columns of the 16 adapter rows
   for (int k = 0; k < kper; k += 32 * U) {
     u32x4 wf[U][NCB], x0[U], x1[U];
 #pragma unroll
@@ -1831,6 +1849,29 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + k + 32 * u);
         x0[u] = *reinterpret_cast<const u32x4*>(xp0 + k + 32 * u);
         if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + k + 32 * u);
+      }
+    }
+    if constexpr (EPI == EPI_ROPE) {
+      if (k == 0 && lp_in) {
+        // t = lp_scale * sum of the lp_np partials the previous residual GEMM left: value (m, j) by thread m * 16 + j of
+        // group g, groups of lp_np / G consecutive partials (G = a power of two that divides lp_np), combined in group order
+        const int nv = p.M * 16;
+        int G = 1;
+        while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
+        const int tid = threadIdx.x;
+        if (tid < G * nv) {
+          const int g = tid / nv, v = tid - g * nv, per = p.lp_np / G;
+          const float* src = p.lp_part + (long)g * per * nv + v;
+          float acc_t = 0.f;
+          for (int i = 0; i < per; i += 32) {  // (32 loads in flight: one round trip for M <= 8, lp_np = 128)
+            float tv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) tv[u] = src[(long)min(i + u, per - 1) * nv];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc_t += i + u < per ? tv[u] : 0.f;
+          }
+          lp_sum[tid] = acc_t;
+        }
       }
     }
     if (k == 0 && wave < 2) {
@@ -1844,7 +1885,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
           rope_c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
           rope_s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
         }
-        if (wave == 0 && p.K2 > 0 && ks == 0) {  // (the second K source is added once: by slice 0)
+        if (lp_in) {
+          // (the partial sums: below, by all eight waves)
+          if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) l_w[0][c] = *reinterpret_cast<const u32x4*>(p.W2 + (long)(ncol[c] + r16) * p.ldw2 + kq * 8);
+          }
+        } else if (wave == 0 && p.K2 > 0 && ks == 0) {  // (the second K source is added once: by slice 0)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (32 * u < p.K2) {
@@ -1863,6 +1910,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
           for (int c = 0; c < NCB; ++c) old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + pmm * p.ldc + n0 + c * 16 + 4 * kq);
         }
       }
+      if constexpr (NORMF) {
+        if (p.lp_a) {
+#pragma unroll
+          for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              lp_af[c][j] = *reinterpret_cast<const u32x2*>(p.lp_a + (long)(j < 8 ? j : 8 + j) * p.lp_lda + n0 + c * 16 + 4 * kq);
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1875,8 +1931,32 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       }
     }
   }
+  if constexpr (EPI == EPI_ROPE) {
+    if (lp_in) {  // (uniform) fused LoRA down-projection: group sums -> t rows in LDS -> wave 0's B fragments, one 32-deep step
+      __syncthreads();
+      const int nv = p.M * 16;
+      if ((int)threadIdx.x < nv) {
+        int G = 1;
+        while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
+        float tot = lp_sum[threadIdx.x];
+        for (int g = 1; g < G; ++g) tot += lp_sum[g * nv + threadIdx.x];
+        const int m_ = threadIdx.x >> 4, j = threadIdx.x & 15;
+        lp_t[m_ * 32 + (j < 8 ? j : 8 + j)] = to16<F16>(tot * p.lp_scale);
+      }
+      __syncthreads();
+      if (wave == 0 && ks == 0) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(lp_t + min(r16, p.M - 1) * 32 + kq * 8);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lp_t + min(16 + r16, p.M - 1) * 32 + kq * 8);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          acc[c][0] = mfma16<F16>(l_w[0][c], a0, acc[c][0]);
+          if (two) acc[c][1] = mfma16<F16>(l_w[0][c], a1, acc[c][1]);
+        }
+      }
+    }
+  }
   if constexpr (EPI == EPI_ROPE) {  // LoRA second K source (K2 = 64: two steps), done by wave 0 (of slice 0)
-    if (p.K2 > 0 && wave == 0 && ks == 0) {
+    if (!lp_in && p.K2 > 0 && wave == 0 && ks == 0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {  // the first two steps come from the registers filled under the first weight batch
         if (32 * u < p.K2) {
@@ -1966,6 +2046,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   } else if constexpr (EPI == EPI_NORM || EPI == EPI_NORM16) {
     const bool res = p.flags & TCAVT_EPI_RESIDUAL;
     float ss = 0.f;
+    f32x4 hq[NCB];  // the 16-bit stream's values (what the next layer's projections read)
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
       f32x4 o = v[c];
@@ -1978,12 +2059,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
         if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
         o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
+        hq[c] = o;
       } else {
         if (res) o += *reinterpret_cast<const f32x4*>(p.residual + mm * p.ldr + n0 + c * 16 + nq);
+        const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
         if (rowok) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
-          *reinterpret_cast<u32x2*>(p.norm_h16 + off) = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
         }
+        hq[c] = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
       }
       ss += o[0] * o[0];
       ss += o[1] * o[1];
@@ -1995,6 +2079,30 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     if (lane < 16 && rowok) {
       p.norm_part[(long)m * (p.N / (16 * NCB)) + blk] = ss;
       flag_nonfinite(p, ss);
+    }
+    if (p.lp_a) {  // (uniform) this workgroup's share of the next layer's LoRA down-projection
+      float pj[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float a_ = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+          const u32x2 w = lp_af[c][j];
+          a_ += hq[c][0] * from16_lo<F16>(w[0]);
+          a_ += hq[c][1] * from16_hi<F16>(w[0]);
+          a_ += hq[c][2] * from16_lo<F16>(w[1]);
+          a_ += hq[c][3] * from16_hi<F16>(w[1]);
+        }
+        a_ += __shfl_xor(a_, 16, 64);
+        a_ += __shfl_xor(a_, 32, 64);
+        pj[j] = a_;
+      }
+      if (lane < 16 && rowok) {
+        float* dst = p.lp_part + ((long)blk * p.M + m) * 16;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<f32x4*>(dst + 4 * q4) = f32x4{pj[4 * q4], pj[4 * q4 + 1], pj[4 * q4 + 2], pj[4 * q4 + 3]};
+      }
     }
   } else if constexpr (EPI == EPI_SILU) {
     static_assert(EPI != EPI_SILU || NCB == 2, "gate block + up block");
@@ -2029,7 +2137,7 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
   // their weights, and N / 16 workgroups of 8 waves (128 for N = 2048: half the CUs, 4 KB per wave in flight) cannot keep the
   // memory system busy -- S is chosen so that ~two workgroups per CU stream, each wave's K slice staying a multiple of 32
   int S = 1;
-  if (p.sk_slab && p.sk_cnt && nblk % 8 == 0) {
+  if (p.sk_slab && p.sk_cnt && nblk % 8 == 0 && !p.lp_a && p.lp_np == 0) {
     static const int max_wg = [] { const char* e = getenv("TCAVT_SK_MAXWG"); return e ? atoi(e) : 640; }();
     while (S < 8 && nblk * S * 2 <= max_wg && p.K % (SK_WAVES * S * 2 * 32) == 0) S *= 2;
     if ((long)nblk * S * 2 * NCB * 256 * 4 > p.sk_slab_bytes || nblk > p.sk_cnt_n) S = 1;
@@ -2072,7 +2180,8 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   const int n_out = (a->epilogue & TCAVT_EPI_SILU_MUL) ? a->N / 2 : a->N;
   TCAVT_CHECK_ARG(a->ldc >= n_out && a->ldc % 4 == 0, "gemm_bf16: ldc=%ld too small or not a multiple of 4", (long)a->ldc);
   int K2 = 0;
-  if (a->A2 || a->W2 || a->K2) {
+  const bool lp_consumer = a->lora_part && (a->epilogue & TCAVT_EPI_ROPE);  // (W2 without A2: checked with lora_part below)
+  if ((a->A2 || a->W2 || a->K2) && !lp_consumer) {
     TCAVT_CHECK_ARG(a->A2 && a->W2 && a->K2 > 0 && a->K2 % 64 == 0,
                     "gemm_bf16: second K-source needs A2, W2 and K2 %% 64 == 0");
     TCAVT_CHECK_ARG(a->lda2 % 8 == 0 && a->ldw2 % 8 == 0 && a->lda2 >= a->K2 && a->ldw2 >= a->K2 &&
@@ -2130,6 +2239,31 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.norm_h16 = nullptr;
   p.norm_part = nullptr;
   p.res16 = nullptr;
+  p.lp_part = nullptr;
+  p.lp_a = nullptr;
+  p.lp_lda = 0;
+  p.lp_np = 0;
+  p.lp_scale = 1.f;
+  if (a->lora_part) {
+    // (decode step only: the skinny form; anything else is a caller error rather than a silent no-op)
+    TCAVT_CHECK_ARG(a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f && aligned16(a->lora_part),
+                    "gemm_bf16: lora_part goes with the skinny form only (M <= 32, tile 0)");
+    p.lp_part = static_cast<float*>(a->lora_part);
+    if (epi & TCAVT_EPI_NORM_OUT) {
+      TCAVT_CHECK_ARG(a->lora_part_a && a->lora_part_lda >= a->N && a->lora_part_lda % 4 == 0 && ((uintptr_t)a->lora_part_a & 7) == 0,
+                      "gemm_bf16: lora_part with NORM_OUT needs lora_part_a [32, lda >= N]");
+      p.lp_a = static_cast<const bf16_t*>(a->lora_part_a);
+      p.lp_lda = a->lora_part_lda;
+    } else {
+      TCAVT_CHECK_ARG((epi & TCAVT_EPI_ROPE) && a->lora_part_np > 0 && a->W2 && !a->A2 && a->K2 == 0 && a->ldw2 >= 32 && a->ldw2 % 8 == 0 &&
+                          aligned16(a->W2) && a->M * 16 <= 512,
+                      "gemm_bf16: lora_part with ROPE needs lora_part_np > 0, W2 (ldw2 >= 32) and no A2");
+      p.lp_np = a->lora_part_np;
+      p.lp_scale = a->lora_part_scale;
+      p.W2 = static_cast<const bf16_t*>(a->W2);
+      p.ldw2 = a->ldw2;
+    }
+  }
   p.sk_split = 1;
   p.sk_slab = nullptr;
   p.sk_cnt = nullptr;

@@ -503,7 +503,13 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   for (int li = 0; li < a->n_layers; ++li) {
     const tcavt_llama_layer& w = a->layers[li];
     TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (!w.a_cat || (w.b_ext && a->t)), "llama_decode_step: layer %d: null weight", li);
-    if (w.a_cat) {
+    // LoRA down-projection: a launch of its own for layer 0 (and without a->lora_part); layers 1.. read the partial sums the
+    // previous layer's down-projection GEMM wrote next to its residual epilogue
+    // (B <= 16: every q|k|v workgroup reads all B x 16 x H / 16 partial sums -- at B = 32 that is twice its weight bytes, and
+    // the launch saved is paid back: 1.860 vs 1.871 ms per step, against 1.18 vs 1.23 at B = 8)
+    const bool lp_ok = a->lora_part && a->lora_rank > 0 && a->lora_rank <= 8 && B <= 16;
+    const bool t_fused = lp_ok && li > 0 && w.a_cat && a->layers[li - 1].w_d;
+    if (w.a_cat && !t_fused) {
       tcavt_gemm_args g = {};
       g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
       g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;
@@ -514,7 +520,9 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       tcavt_gemm_args g = {};
       g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv;
       g.M = B; g.N = nqkv; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
-      if (w.a_cat) { g.A2 = a->t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
+      if (t_fused) {
+        g.W2 = w.b_ext; g.ldw2 = 64; g.lora_part = a->lora_part; g.lora_part_np = H / 16; g.lora_part_scale = a->lora_scale;
+      } else if (w.a_cat) { g.A2 = a->t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->rope_L; g.rope_cols = (nq + nkv) * 64;
       g.rope_pos = a->pos;
@@ -558,6 +566,9 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
+      if (lp_ok && li + 1 < a->n_layers && a->layers[li + 1].a_cat) {
+        g.lora_part = a->lora_part; g.lora_part_a = a->layers[li + 1].a_cat; g.lora_part_lda = H;
+      }
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }

@@ -1090,6 +1090,8 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     a.k_cache, a.v_cache, a.kv_lmax = kc.data_ptr(), vc.data_ptr(), Lmax
                     a.x16, a.logits, a.bad_id_flag = x16.data_ptr(), logits.data_ptr(), flags.data_ptr()
                     a.nonfinite_flag = flags[2:3].data_ptr()
+                    if LW.use_lora and LW.lora_r <= 8 and os.environ.get("TCAVT_DECODE_LORA_LAUNCH", "0") != "1":  # (A/B switch)
+                        a.lora_part, a.lora_rank = ws.get("gen.lpart", (B * H,), torch.float32, dev).data_ptr(), LW.lora_r
                     # K split across workgroups (tcavt_gemm_args.splitk_ws): off by default -- measured 1.30 vs 1.22 ms per step
                     # at B = 8 and 1.84 vs 1.87 at B = 32 (the hand-off costs what the split gains)
                     if os.environ.get("TCAVT_DECODE_SPLITK", "0") == "1":
