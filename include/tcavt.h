@@ -281,6 +281,11 @@ int tcavt_mask_to_kvlen(const int64_t* mask, int B, int Lt, int Nq, int32_t* kv_
  * ---------------------------------------------------------------------- */
 int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B,
                           int L, int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream);
+/* The same, also leaving lse fp32 [B][nq][L] (NULL: none) = log sum_j exp(scale * q_i . k_j) over the keys query i attends
+ * (0 for a query without one): with it and the output, tcavt_attn_bwd_scores needs one sweep over the keys instead of two
+ * (LoRA-trainable variant, modify_scripts/modify_train.py:512-528). */
+int tcavt_attn_causal_gqa_lse(const void* qkv, void* out, float* lse, const int32_t* kv_len, int B,
+                              int L, int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row softmax for the batched cross-attention: P[r][c] = softmax_c(S[r][c]) over c < n_valid,
@@ -454,10 +459,14 @@ int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, void* dS_bf1
    dQ (optional): fp32 [B*T, ld_dq], head h at columns 64 h, receives dQ = dS K computed in the same kernel; dS_bf16
    (optional) is the row-major dS for an external product; at least one of the two.  PT / dST are optional (both or
    neither; the GEMM form of dK, dV); stats (optional; required without PT/dST): fp32 [B*nq*T, 4] = row maximum of the
-   scaled scores, 1 / row sum, sum(P dP), 0 -- the input of tcavt_attn_bwd_dkv */
+   scaled scores, 1 / row sum, sum(P dP), 0 -- the input of tcavt_attn_bwd_dkv.
+   lse + att (optional, both or neither): the forward's log-sum-exp fp32 [B*nq*T] and output 16-bit [B*T, nq*64]
+   (tcavt_attn_causal_gqa_lse).  With them the row statistics come from the forward -- P = exp(s - lse), sum(P dP) = dO . O --
+   and the kernel makes one sweep over the key blocks instead of two (stats then holds lse, 1, dO . O, 0) */
 int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
                           float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp, int nq,
-                          int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream);
+                          int nkv, int head_dim, float scale, int dtype16, const float* lse, const void* att,
+                          tcavt_stream_t stream);
 /* dK, dV of the attention backward, key-major on the matrix cores (one workgroup per sample, key/value head and 64 keys;
    P^T, dS^T rebuilt from `stats`, the query heads of the group summed in registers): writes the k and v columns of
    g32 [B*T, (nq+2nkv)*64] fp32 (every row; no zero-initialisation needed) */
@@ -541,6 +550,9 @@ typedef struct tcavt_llama_layer {
   void* tape_qkv;     /* 16-bit [M (+ pad)][(nq + 2 nkv) * 64]: rotated q|k|v of this layer */
   void* tape_gu;      /* 16-bit [M][2 I]: gate|up pre-activations (interleaved layout) */
   void* tape_t;       /* 16-bit [M][64]: LoRA down-projection */
+  void* tape_att;     /* optional, 16-bit [M][nq * 64]: the attention's output (instead of the shared workspace `att`) ... */
+  float* tape_lse;    /* ... and fp32 [B][nq][L]: its log-sum-exp per query row (tcavt_attn_causal_gqa_lse); both or neither:
+                         with them tcavt_attn_bwd_scores runs one sweep over the keys instead of two */
 } tcavt_llama_layer;
 
 typedef struct tcavt_llama_stack_args {

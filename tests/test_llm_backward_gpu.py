@@ -595,3 +595,68 @@ def test_grad_scale_pick_and_scaled_rmsnorm_bwd(gpu):
         y = xr * torch.rsqrt((xr * xr).mean(-1, keepdim=True) + 1e-5) * gamma.cpu()
         (y * gy.float().cpu()).sum().backward()
         assert rel_err(g0.cpu(), xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,T,nq,nkv,lens", [(2, 40, 4, 1, [40, 23]), (3, 64, 8, 2, [64, 1, 33]), (2, 256, 32, 8, [256, 170]),
+                                             (1, 300, 4, 2, [211])])
+def test_attn_bwd_one_sweep_from_the_forwards_row_statistics(gpu, B, T, nq, nkv, lens, dt):
+    """tcavt_attn_causal_gqa_lse leaves the log-sum-exp of every query row; with it and the forward's output the scores
+    kernel of the backward needs no first sweep for the row maximum / sum / sum(P dP) (P = exp(s - lse), sum(P dP) = dO . O).
+    The lse against torch.logsumexp of the masked scores; the one-sweep gradients against fp32 autograd (same bar as the
+    two-sweep form) and against the two-sweep form itself."""
+    from tcavt_amd import ops
+    from tcavt_amd.config import LlamaShape
+    from tcavt_amd.llm_backward import attn_bwd_composed
+    from tcavt_amd.rope import rope_tables
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(17)
+    ncols = (nq + 2 * nkv) * 64
+    M = B * T
+    qkv_p = torch.zeros(M + 64, ncols, dtype=dt, device=dev)
+    qkv_p[:M] = torch.randn(M, ncols, generator=g).to(dt).to(dev)
+    dO = torch.randn(M, nq * 64, generator=g).to(dt).to(dev)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+    cos, sin = (t.to(dev) for t in rope_tables(LlamaShape(), T))
+    att = torch.empty(M, nq * 64, dtype=dt, device=dev)
+    lse = torch.full((B * nq * T,), float("nan"), device=dev)
+    ops.attn_causal_gqa(qkv_p[:M], att, kv_len, B, T, nq, nkv, 0.125, lse=lse)
+    att0 = torch.empty_like(att)
+    ops.attn_causal_gqa(qkv_p[:M], att0, kv_len, B, T, nq, nkv, 0.125)
+    assert torch.equal(att, att0)  # (the statistics are a by-product)
+    v3 = qkv_p[:M].float().view(B, T, nq + 2 * nkv, 64)
+    q = v3[:, :, :nq].permute(0, 2, 1, 3)
+    k = v3[:, :, nq:nq + nkv].permute(0, 2, 1, 3).repeat_interleave(nq // nkv, dim=1)
+    i = torch.arange(T, device=dev)
+    allowed = (i[None, :] <= i[:, None])[None] & (i[None, None, :] < kv_len.long()[:, None, None])
+    s = ((q @ k.transpose(-1, -2)) * 0.125).masked_fill(~allowed[:, None], float("-inf"))
+    want_lse = torch.logsumexp(s, dim=-1).reshape(-1)
+    assert torch.isfinite(lse).all() and (lse - want_lse).abs().max().item() < 2e-4
+
+    pool = {}
+
+    def buf(name, shape, dtype, zero=False):
+        if name not in pool:
+            pool[name] = torch.zeros(shape, dtype=dtype, device=dev)
+        return pool[name]
+
+    two = torch.empty(M, ncols, dtype=dt, device=dev)
+    attn_bwd_composed(buf, qkv_p, dO, kv_len, B, T, nq, nkv, 0.125, cos, sin, two)
+    stats2 = pool["at.stats"].clone()
+    one = torch.empty(M, ncols, dtype=dt, device=dev)
+    pool["at.stats"].fill_(float("nan"))
+    attn_bwd_composed(buf, qkv_p, dO, kv_len, B, T, nq, nkv, 0.125, cos, sin, one, lse=lse, att=att)
+    stats1 = pool["at.stats"]
+    # the statistics the key-major kernel reads: log(sum) + max == lse, sum(P dP) == dO . O up to the rounding of O
+    lse2 = stats2[:, 0] - torch.log(stats2[:, 1])
+    assert (stats1[:, 0] - lse2).abs().max().item() < 2e-4 and torch.equal(stats1[:, 1], torch.ones_like(stats1[:, 1]))
+    assert rel_err(stats1[:, 2].cpu(), stats2[:, 2].cpu()) < (3e-3 if dt == torch.float16 else 2e-2)
+    want32 = _attn_ref(qkv_p[:M], dO, kv_len, B, T, nq, nkv)
+    want = torch.empty_like(one)
+    ops.rope_bwd_pack(want32.contiguous(), want, cos, sin, (nq + nkv) * 64, T)
+    for name, lo, hi in (("dq", 0, nq * 64), ("dk", nq * 64, (nq + nkv) * 64), ("dv", (nq + nkv) * 64, ncols)):
+        e1 = rel_err(one[:, lo:hi].float().cpu(), want[:, lo:hi].float().cpu())
+        e2 = rel_err(two[:, lo:hi].float().cpu(), want[:, lo:hi].float().cpu())
+        assert e1 < (3e-3 if dt == torch.float16 else 1e-2), (name, e1, e2)
+        assert e1 < 1.5 * e2 + 1e-4, (name, e1, e2)  # no worse than the form that recomputes the statistics

@@ -50,6 +50,15 @@ def main(path):
         print(f"  {t / 1000:8.1f} us  n={n:3d}  avg {t / n / 1000:7.1f} us  {k}")
     gaps = [(b["s"] - a["e"]) / 1000 for a, b in zip(main_q, main_q[1:])]
     print(f"main queue idle: {sum(g for g in gaps if g > 0) / 1000:.2f} ms in {len(gaps)} gaps ({sum(1 for g in gaps if g > 30)} above 30 us)")
+    # the largest gaps with their neighbours, and what the other queues ran meanwhile
+    order = sorted(range(len(gaps)), key=lambda i: -gaps[i])[:24]
+    short = lambda r: r["Kernel_Name"].split("(")[0][-48:]
+    for i in sorted(order):
+        a, b = main_q[i], main_q[i + 1]
+        other = [r for r in step if r["Queue_Id"] != a["Queue_Id"] and r["e"] > a["e"] and r["s"] < b["s"]]
+        busy = union_ms(other) * 1000 if other else 0.0
+        print(f"  gap {gaps[i]:7.1f} us at +{(a['e'] - t0) / 1e6:6.2f} ms  after {short(a)}  before {short(b)}  "
+              f"(other queues: {len(other)} kernels, {busy:.0f} us busy)")
 
 
 if __name__ == "__main__":

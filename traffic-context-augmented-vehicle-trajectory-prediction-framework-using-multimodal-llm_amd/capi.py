@@ -66,7 +66,7 @@ class LlamaLayer(ctypes.Structure):
     """Mirror of ``tcavt_llama_layer`` (include/tcavt.h)."""
 
     _fields_ = [(n, c_void_p) for n in ("w_qkv", "a_cat", "b_ext", "w_o", "w_gu", "w_d", "tape_h_mid", "tape_h_out",
-                                        "tape_qkv", "tape_gu", "tape_t")]
+                                        "tape_qkv", "tape_gu", "tape_t", "tape_att", "tape_lse")]
 
 
 TLAYER_FIELDS = ("w_in", "b_in", "w_out", "b_out", "w_q", "b_q", "w_kv", "b_kv", "w_co", "b_co", "w1", "b1", "w2", "b2",
@@ -204,6 +204,7 @@ _SIGNATURES = {
     "tcavt_dropout": [c_void_p, c_void_p, c_int64, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p, c_void_p],
     "tcavt_mask_to_kvlen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_causal_gqa": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+    "tcavt_attn_causal_gqa_lse": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "tcavt_mha": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                   c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32, c_void_p],
     "tcavt_gemm_f32": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
@@ -239,7 +240,7 @@ _SIGNATURES = {
     "tcavt_causal_softmax_bwd_tiles": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_float, c_void_p],
     "tcavt_attn_bwd_scores": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
-                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
     "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_int, c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
                                                               const int* __restrict__ kv_len_p,
                                                               int L, int Lp, int nq, int nkv,
                                                               float scale_log2e, int ot_bytes,
-                                                              unsigned long long* __restrict__ stamps = nullptr) {
+                                                              unsigned long long* __restrict__ stamps = nullptr,
+                                                              float* __restrict__ lse = nullptr) {
   int n_stamp = 0;
   auto stamp = [&]() {
     if constexpr (STAMP) {
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(MAXT) void attn_causal_gqa_kernel(const bf16_t* __r
     // two neighbouring groups leaves 16 consecutive bytes in every lane (lower half: group g whole, upper half: group g + 1
     // whole) -> four 16-byte stores per row instead of eight 8-byte ones (the store tail is issue-bound)
     const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+    // (LoRA-trainable variant) log-sum-exp of the row's scaled scores, natural log: the backward rebuilds P = exp(s - lse)
+    // from it instead of sweeping the keys once more for the row maximum and sum
+    if (lse && hh == 0 && qi < L) lse[((long)b * nq + head) * L + qi] = lrun > 0.f ? (mrun + __log2f(lrun)) * 0.6931471805599453f : 0.f;
     if (ot_bytes) {
       // Through a wave-private LDS tile [32 queries][64 dims] (rows padded to 144 bytes) so that every store instruction
       // writes 8 whole 128-byte rows instead of 32-byte pieces of 32 rows: the row-per-lane form cost ~2.3k cycles per block
@@ -519,6 +523,11 @@ using namespace tcavt;
 
 extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* kv_len, int B, int L,
                                      int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream) {
+  return tcavt_attn_causal_gqa_lse(qkv, out, nullptr, kv_len, B, L, nq, nkv, scale, dtype16, stream);
+}
+
+extern "C" int tcavt_attn_causal_gqa_lse(const void* qkv, void* out, float* lse, const int32_t* kv_len, int B, int L,
+                                         int nq, int nkv, float scale, int dtype16, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(qkv && out && kv_len, "attn_causal_gqa: null pointer");
   TCAVT_CHECK_ARG(is16(dtype16), "attn_causal_gqa: dtype16 must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG(B > 0 && L > 0 && L <= 544, "attn_causal_gqa: L=%d must be in [1, 544]", L);
@@ -550,7 +559,7 @@ extern "C" int tcavt_attn_causal_gqa(const void* qkv, void* out, const int32_t* 
 #define TCAVT_ATTN(MAXT, F)                                                                                       \
   hipLaunchKernelGGL((attn_causal_gqa_kernel<MAXT, F>), dim3(B * nkv), dim3(2 * group * 64), lds,                  \
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv), static_cast<bf16_t*>(out), \
-                     kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes)
+                     kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes, nullptr, lse)
   if (which == 0) TCAVT_ATTN(1024, false);
   else if (which == 1) TCAVT_ATTN(512, false);
   else if (which == 2) TCAVT_ATTN(1024, true);

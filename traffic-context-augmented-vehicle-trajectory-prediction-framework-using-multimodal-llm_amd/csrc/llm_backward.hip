@@ -7,6 +7,7 @@
 // scalar-FMA attn_causal_gqa_bwd_kernel are cross-checks, not product paths.
 #include "common.hpp"
 #include "philox.hpp"
+#include <stdlib.h>
 
 namespace tcavt {
 
@@ -446,7 +447,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
                                                               bf16_t* __restrict__ dS, bf16_t* __restrict__ PT,
                                                               bf16_t* __restrict__ dST, float* __restrict__ dQ, long ld_dq,
                                                               float* __restrict__ stats, const int* __restrict__ kv_len, int T,
-                                                              int Tp, int nq, int nkv, float scale) {
+                                                              int Tp, int nq, int nkv, float scale,
+                                                              const float* __restrict__ lse, const bf16_t* __restrict__ att) {
+  // lse + att (optional, both or neither): the forward's log-sum-exp per query row [B*nq*T] (tcavt_attn_causal_gqa_lse) and
+  // its output [B*T, nq*64].  With them the row statistics are known before any key is read -- P = exp(s - lse), and
+  // sum(P dP) = dO . O (the row of the output times the row of its gradient, as in FlashAttention-2's backward) -- so the
+  // first of the two sweeps over the key blocks (S and dP on the matrix cores, for the maximum, the sum and sum(P dP)) is
+  // not run: 3 instead of 5 block products per key block.
   // stats (optional, fp32 [B*nq*T, 4]): row maximum of the scaled scores, 1 / row sum, sum(P dP) -- what
   // attn_bwd_dkv_kernel needs to rebuild P and dS for its key block.  PT / dST (optional): only for the GEMM form of dK, dV.
   // dQ (optional, fp32 [B*T, ld_dq], head h at columns 64 h): dQ = dS K accumulated over the key blocks inside the last
@@ -560,6 +567,34 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
   // (its own running maximum; sums rescaled when it moves), the 16 lanes of a row are merged afterwards
   float m[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
   float sum[4] = {0.f, 0.f, 0.f, 0.f}, dot[4] = {0.f, 0.f, 0.f, 0.f};
+  float inv[4];
+  if (lse) {  // (uniform) statistics from the forward: no first sweep
+    // dO . O of query row wave * 16 + l15: this lane's 16 elements of the A-fragment rows, then the four lane groups
+    float dsum = 0.f;
+    {
+      const long ar = row0 + min(q0 + wave * 16 + l15, T - 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(att + ar * (long)(nq * 64) + h * 64 + kk * 32 + l4 * 8);
+        const u32x4 gv = __builtin_bit_cast(u32x4, gf[kk]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dsum = fmaf(from16_lo<F16>(ov[e]), from16_lo<F16>(gv[e]), dsum);
+          dsum = fmaf(from16_hi<F16>(ov[e]), from16_hi<F16>(gv[e]), dsum);
+        }
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = q0 + wave * 16 + l4 * 4 + e;
+      m[e] = lse[bh * T + min(i, T - 1)];
+      inv[e] = 1.f;
+      dot[e] = __shfl(dsum, l4 * 4 + e, 64);  // (lane l4 * 4 + e holds row l4 * 4 + e: its l15)
+      if (stats && l15 == 0 && i < T) *reinterpret_cast<f32x4*>(stats + (bh * T + i) * 4) = f32x4{m[e], 1.f, dot[e], 0.f};
+    }
+  } else {
   sweep(true, [&](int kb, f32x4 (&sa)[4], f32x4 (&da)[4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -588,7 +623,6 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
     dot[e] *= resc;
     m[e] = mr;
   }
-  float inv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     sum[e] = group16(sum[e], false);
@@ -598,6 +632,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
     const int i = q0 + wave * 16 + l4 * 4 + e;
     if (stats && l15 == 0 && i < T) *reinterpret_cast<f32x4*>(stats + (bh * T + i) * 4) = f32x4{m[e], inv[e], dot[e], 0.f};
   }
+  }  // (two-sweep form)
   f32x4 dq[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -665,6 +700,150 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// dQ of the attention backward from the forward's row statistics (the product form of the query-major half when the tape
+// holds lse and the attention's output: T <= 256, 16 % (nq / nkv) == 0).  One workgroup per (sample, key/value head) as in
+// the forward: K, V (row-major) and K^T of the head are staged in LDS ONCE -- 110 KB -- and sixteen waves walk
+// (query head, strip of 16 queries) units with no barrier after the staging one; the strips are dealt in (short, long)
+// pairs, so every wave sees the same number of keys.  attn_bwd_scores_kernel re-staged the K / V block for every query
+// head and every block of 64 queries (two barriers each) and passed P and dS through LDS tiles with two-byte stores.
+//   S^T = K q^T and dP^T = V dO^T  (keys x queries: A = K / V rows from LDS, B = the strip's q / dO rows in registers)
+//   P = exp(s - lse),  dS = scale P (dP - dO . O)   per element; D[m][n] sits in lane l as key 4 (l >> 4) + e, query l & 15
+//   dQ += dS K: the lane's eight values of two key tiles ARE its A fragment (contraction index = keys, taken in the order
+//   tile 0 keys 4 g .. 4 g + 3, tile 1 keys 4 g .. 4 g + 3), the B fragment reads K^T with the same key order.
+// Nothing is written but dQ (fp32, head h at columns 64 h) and stats = (lse, 1, dO . O, 0) for attn_bwd_dkv_kernel.
+// ---------------------------------------------------------------------------
+constexpr int ABQ_WAVES = 16;
+
+template <bool F16>
+__global__ __launch_bounds__(ABQ_WAVES * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                                     const bf16_t* __restrict__ att, const float* __restrict__ lse,
+                                                                     float* __restrict__ dQ, long ld_dq, float* __restrict__ stats,
+                                                                     const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
+                                                                     float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [Tp][72]
+  bf16_t* Vs = Ks + Tp * 72;                                    // [Tp][72]
+  bf16_t* KT = Vs + Tp * 72;                                    // [64][Tp + 4]
+  const int kts = Tp + 4;
+  const int group = nq / nkv;
+  const int b = blockIdx.x / nkv, j = blockIdx.x % nkv;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long nqkv = (long)(nq + 2 * nkv) * 64;
+  const long row0 = (long)b * T;
+  const int klen = min(kv_len[b], T);
+  // ---- stage K, V, K^T: thread (key pair kp, 16-byte chunk c): rows 2 kp, 2 kp + 1; all loads first, rows >= T as zeros
+  {
+    const bf16_t* kbase = qkv + (nq + j) * 64;
+    const bf16_t* vbase = qkv + (nq + nkv + j) * 64;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int idx = threadIdx.x; idx < (Tp >> 1) * 8; idx += ABQ_WAVES * 64) {
+      const int kp = idx >> 3, c = idx & 7;
+      const int r0 = 2 * kp, r1 = r0 + 1;
+      const long g0 = (row0 + min(r0, T - 1)) * nqkv + c * 8, g1 = (row0 + min(r1, T - 1)) * nqkv + c * 8;
+      u32x4 ka = *reinterpret_cast<const u32x4*>(kbase + g0), kb = *reinterpret_cast<const u32x4*>(kbase + g1);
+      u32x4 va = *reinterpret_cast<const u32x4*>(vbase + g0), vb = *reinterpret_cast<const u32x4*>(vbase + g1);
+      if (r0 >= T) { ka = zero4; va = zero4; }
+      if (r1 >= T) { kb = zero4; vb = zero4; }
+      *reinterpret_cast<u32x4*>(Ks + r0 * 72 + c * 8) = ka;
+      *reinterpret_cast<u32x4*>(Ks + r1 * 72 + c * 8) = kb;
+      *reinterpret_cast<u32x4*>(Vs + r0 * 72 + c * 8) = va;
+      *reinterpret_cast<u32x4*>(Vs + r1 * 72 + c * 8) = vb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // two keys of one dimension per dword
+        *reinterpret_cast<unsigned int*>(KT + (c * 8 + 2 * e) * kts + r0) = (ka[e] & 0xffffu) | (kb[e] << 16);
+        *reinterpret_cast<unsigned int*>(KT + (c * 8 + 2 * e + 1) * kts + r0) = (ka[e] >> 16) | (kb[e] & 0xffff0000u);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- units: wave w serves query head w % group; its strips come in pairs (k, nstrips - 1 - k), k = w / group + NG * i
+  const int h = j * group + wave % group;
+  const int g0w = wave / group, NG = ABQ_WAVES / group;
+  const int nstrips = (T + 15) >> 4;
+  const int npair = (nstrips + 1) >> 1;
+  const float c2 = scale * 1.4426950408889634f;
+  for (int u = 0;; ++u) {
+    const int pr = g0w + NG * (u >> 1);
+    if (pr >= npair) break;  // (uniform)
+    const int strip = (u & 1) ? nstrips - 1 - pr : pr;
+    if ((u & 1) && strip == pr) continue;  // odd count: the middle strip is its own pair
+    const int qi = strip * 16 + l15;       // this lane's query (B-fragment column / D column)
+    const long ar = row0 + min(qi, T - 1);
+    bf16x8 qf[2], gf[2];
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + h * 64 + kk * 32 + l4 * 8);
+      gf[kk] = *reinterpret_cast<const bf16x8*>(dO + ar * (long)(nq * 64) + h * 64 + kk * 32 + l4 * 8);
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(att + ar * (long)(nq * 64) + h * 64 + kk * 32 + l4 * 8);
+      const u32x4 gv = __builtin_bit_cast(u32x4, gf[kk]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        delta = fmaf(from16_lo<F16>(ov[e]), from16_lo<F16>(gv[e]), delta);
+        delta = fmaf(from16_hi<F16>(ov[e]), from16_hi<F16>(gv[e]), delta);
+      }
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const long srow = ((long)b * nq + h) * T + min(qi, T - 1);
+    const float l_nat = lse[srow];
+    const float l2 = l_nat * 1.4426950408889634f;
+    const int nv = qi < T ? min(qi + 1, klen) : 0;
+    if (stats && l4 == 0 && qi < T) *reinterpret_cast<f32x4*>(stats + srow * 4) = f32x4{l_nat, 1.f, delta, 0.f};
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkeys = min(strip * 16 + 16, klen);  // keys any query of the strip attends
+    for (int k0 = 0; k0 < nkeys; k0 += 32) {
+      f32x4 sa[2], da[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+        const int krow = k0 + t * 16 + l15;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + krow * 72 + kk * 32 + l4 * 8);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + krow * 72 + kk * 32 + l4 * 8);
+          sacc = mfma16b<F16>(kf, qf[kk], sacc);
+          dacc = mfma16b<F16>(vf, gf[kk], dacc);
+        }
+        sa[t] = sacc;
+        da[t] = dacc;
+      }
+      u32x4 af;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float ds[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = k0 + t * 16 + 4 * l4 + e;
+          const float pv = key < nv ? __builtin_amdgcn_exp2f(fmaf(sa[t][e], c2, -l2)) : 0.f;
+          ds[e] = scale * pv * (da[t][e] - delta);
+        }
+        af[2 * t] = pack16x2<F16>(ds[0], ds[1]);
+        af[2 * t + 1] = pack16x2<F16>(ds[2], ds[3]);
+      }
+      const bf16x8 afr = __builtin_bit_cast(bf16x8, af);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* kt = KT + (dt * 16 + l15) * kts + k0 + 4 * l4;
+        const u32x2 b0 = *reinterpret_cast<const u32x2*>(kt), b1 = *reinterpret_cast<const u32x2*>(kt + 16);
+        const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
+        dq[dt] = mfma16b<F16>(afr, __builtin_bit_cast(bf16x8, bv), dq[dt]);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = strip * 16 + l4 * 4 + e;
+        if (i < T) dQ[(row0 + i) * ld_dq + h * 64 + dt * 16 + l15] = dq[dt][e];
+      }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // dK, dV of the attention backward, key-major: one workgroup per (sample, key/value head, block of 64 keys); wave w owns
@@ -1145,8 +1324,10 @@ extern "C" int tcavt_causal_softmax_bwd_tiles(const float* S, const float* dP, v
 
 extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf16, void* PT_bf16, void* dST_bf16,
                                      float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp,
-                                     int nq, int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream) {
+                                     int nq, int nkv, int head_dim, float scale, int dtype16, const float* lse, const void* att,
+                                     tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(qkv_bf16 && dO_bf16 && kv_len && B > 0 && T > 0 && is16(dtype16), "attn_bwd_scores: bad args");
+  TCAVT_CHECK_ARG((lse != nullptr) == (att != nullptr) && aligned16(att), "attn_bwd_scores: lse and att come together (att 16-byte aligned)");
   TCAVT_CHECK_ARG((PT_bf16 != nullptr) == (dST_bf16 != nullptr), "attn_bwd_scores: PT and dST come together");
   TCAVT_CHECK_ARG(PT_bf16 || stats, "attn_bwd_scores: give PT/dST (GEMM form of dK, dV) or stats (tcavt_attn_bwd_dkv)");
   TCAVT_CHECK_ARG(aligned16(stats), "attn_bwd_scores: stats must be 16-byte aligned");
@@ -1155,11 +1336,32 @@ extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, 
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_scores: head_dim 64 and nq %% nkv == 0 required");
   TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_scores: Tp must be T rounded up to a multiple of 64");
   TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16), "attn_bwd_scores: 16-byte alignment required");
+  const int group = nq / nkv;
+  static const bool no_resident = getenv("TCAVT_ATTN_BWD_NO_RESIDENT") != nullptr;  // (A/B switch)
+  if (lse && dQ && stats && !dS_bf16 && !PT_bf16 && Tp <= 256 && ABQ_WAVES % group == 0 && !no_resident) {
+    // statistics from the forward, nothing but dQ wanted: K, V, K^T of a key/value head resident in LDS, no key-block loop
+    const int lds = (2 * Tp * 72 + 64 * (Tp + 4)) * 2;
+    auto kq = dtype16 == TCAVT_F16 ? attn_bwd_dq_kernel<true> : attn_bwd_dq_kernel<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[dtype16 == TCAVT_F16]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+      if (e != hipSuccess) {
+        tcavt::set_error("attn_bwd_scores: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return TCAVT_ERR_HIP;
+      }
+      attr_set[dtype16 == TCAVT_F16] = true;
+    }
+    hipLaunchKernelGGL(kq, dim3((unsigned)(B * nkv)), dim3(ABQ_WAVES * 64), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16), static_cast<const bf16_t*>(att), lse,
+                       dQ, (long)ld_dq, stats, kv_len, T, Tp, nq, nkv, scale);
+    TCAVT_CHECK_LAUNCH("attn_bwd_scores(resident)");
+    return TCAVT_OK;
+  }
   auto kfn = dtype16 == TCAVT_F16 ? attn_bwd_scores_kernel<true> : attn_bwd_scores_kernel<false>;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((long)B * nq * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      static_cast<bf16_t*>(dS_bf16), static_cast<bf16_t*>(PT_bf16), static_cast<bf16_t*>(dST_bf16), dQ, (long)ld_dq,
-                     stats, kv_len, T, Tp, nq, nkv, scale);
+                     stats, kv_len, T, Tp, nq, nkv, scale, lse, static_cast<const bf16_t*>(att));
   TCAVT_CHECK_LAUNCH("attn_bwd_scores");
   return TCAVT_OK;
 }

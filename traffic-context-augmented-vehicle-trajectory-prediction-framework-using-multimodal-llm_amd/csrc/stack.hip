@@ -256,12 +256,14 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     }
     // ---- causal grouped-query attention
     ev.rec(2);
-    TCAVT_TRY(tcavt_attn_causal_gqa(qkv, a->att, a->kv_len, a->B, a->L, nq, nkv, scale, dt, stream));
+    TCAVT_CHECK_ARG((w.tape_att != nullptr) == (w.tape_lse != nullptr), "llama_stack_forward: layer %d: tape_att and tape_lse come together", li);
+    void* att = tape && w.tape_att ? w.tape_att : a->att;
+    TCAVT_TRY(tcavt_attn_causal_gqa_lse(qkv, att, tape ? w.tape_lse : nullptr, a->kv_len, a->B, a->L, nq, nkv, scale, dt, stream));
     ev.rec(3);
     // ---- h_mid = h + att . W_o^T; 16-bit copy + partial sums of squares for the post-attention norm
     {
       tcavt_gemm_args g = {};
-      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = h_mid; g.ldc = H;
+      g.A = att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = h_mid; g.ldc = H;
       g.M = M; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;  // (stream16: C = residual = NULL)
       if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_mid; g.norm_res16 = x16; }

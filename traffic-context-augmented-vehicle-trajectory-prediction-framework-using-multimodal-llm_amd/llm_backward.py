@@ -45,7 +45,7 @@ def lora_named_parameters(model):
     return out
 
 
-def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv, scores="fused"):
+def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qkv, scores="fused", lse=None, att=None):
     """Backward of the causal grouped-query attention.  scores="fused" (the product path): two MFMA kernels + the RoPE
     pack; "scores+gemm" / "gemm": the same mathematics with dK, dV (or all five products) on the batched MFMA GEMM around
     a row kernel -- kept as cross-checks.
@@ -68,7 +68,8 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
         # S, dP, P, dS never reach memory
         g32 = buf("at.g32", (B * T, nqkv), f32)
         stats = buf("at.stats", (BH * T, 4), f32)
-        ops.attn_bwd_scores(qkv, dO, None, None, None, kv_len, B, T, Tp, nq, nkv, scale, dQ=g32, stats=stats)
+        # (lse / att from the forward's tape: the scores kernel sweeps the keys once, not twice)
+        ops.attn_bwd_scores(qkv, dO, None, None, None, kv_len, B, T, Tp, nq, nkv, scale, dQ=g32, stats=stats, lse=lse, att=att)
         ops.attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale)
         ops.rope_bwd_pack(g32, g_qkv, cos, sin, (nq + nkv) * hd, T)
         return g_qkv
@@ -196,8 +197,9 @@ class LoraBackward:
             g_qkv, g_t = g_qkv2[par], g_t2[par]
             if leaf_done[par] is not None:
                 torch.cuda.current_stream().wait_event(leaf_done[par])  # the leaf of layer li + 2 has read them
+            one_sweep = os.environ.get("TCAVT_ATTN_BWD_TWO_SWEEPS", "0") != "1" and getattr(sv, "lse", None) is not None  # (A/B switch)
             attn_bwd_composed(self._buf, sv.qkv_padded, g_att, tape.kv_len, B, L, nq, nkv, 1.0 / math.sqrt(hd), cos, sin,
-                              g_qkv)
+                              g_qkv, lse=sv.lse if one_sweep else None, att=sv.att if one_sweep else None)
             # ---- adapters: q|k|v += t B_ext^T,  t = bf16(s * dropout(xn) A_cat^T)
             ops.gemm_bf16(g_qkv, dT.b_ext, out=g_t, acc_scale=s)
 

@@ -355,15 +355,19 @@ def mask_to_kvlen(mask, Nq, kv_len, flag):
           "tcavt_mask_to_kvlen")
 
 
-def attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, scale):
+def attn_causal_gqa(qkv, out, kv_len, B, L, nq, nkv, scale, lse=None):
+    """lse (optional, fp32 [B, nq, L]): receives the log-sum-exp of every query row's scaled scores (for attn_bwd_scores)."""
     _req16(qkv, "attn.qkv")
     _req16(out, "attn.out", like=qkv)
     _req(kv_len, torch.int32, "attn.kv_len")
     _need(qkv, B * L * (nq + 2 * nkv) * 64, "attn.qkv")
     _need(out, B * L * nq * 64, "attn.out")
     _need(kv_len, B, "attn.kv_len")
-    check(lib().tcavt_attn_causal_gqa(ptr(qkv), ptr(out), ptr(kv_len), B, L, nq, nkv, scale, _DT[qkv.dtype],
-                                      stream_ptr()), "tcavt_attn_causal_gqa")
+    if lse is not None:
+        _req(lse, torch.float32, "attn.lse")
+        _need(lse, B * nq * L, "attn.lse")
+    check(lib().tcavt_attn_causal_gqa_lse(ptr(qkv), ptr(out), ptr(lse) if lse is not None else None, ptr(kv_len), B, L, nq, nkv,
+                                          scale, _DT[qkv.dtype], stream_ptr()), "tcavt_attn_causal_gqa")
 
 
 def mha(q, k, v, out, B, Lq, Lk, nh, dh, scale, key_len=None, ldq=None, ldk=None, ldv=None, ldo=None, dropout=None):
@@ -641,9 +645,11 @@ def attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale):
                                    _DT16(qkv), stream_ptr()), "tcavt_attn_bwd_dkv")
 
 
-def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None, stats=None):
+def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=None, stats=None, lse=None, att=None):
     """Scores + softmax backward in one kernel (MFMA inside): P^T, dS^T (zero-initialised once), plus dQ = dS K (fp32
-    [B*T, >= nq*64], any leading dimension) computed in place and / or the row-major dS for an external dQ product."""
+    [B*T, >= nq*64], any leading dimension) computed in place and / or the row-major dS for an external dQ product.
+    lse (fp32 [B*nq*T]) + att (the forward's output, 16-bit [B*T, nq*64]), from attn_causal_gqa(..., lse=...): the row
+    statistics come from the forward and the kernel sweeps the keys once instead of twice."""
     rows, ncols = B * nq * T, (nq + 2 * nkv) * 64
     if dQ is not None:
         if dQ.dtype != torch.float32 or dQ.stride(-1) != 1 or _avail(dQ) < (B * T - 1) * dQ.stride(0) + nq * 64:
@@ -660,10 +666,17 @@ def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=N
     if stats is not None:
         _req(stats, torch.float32, "attn_bwd_scores.stats")
         _need(stats, rows * 4, "attn_bwd_scores.stats")
+    if (lse is None) != (att is None):
+        raise capi.TcavtError("attn_bwd_scores: lse and att come together")
+    if lse is not None:
+        _req(lse, torch.float32, "attn_bwd_scores.lse")
+        _need(lse, rows, "attn_bwd_scores.lse")
+        if att.dtype != qkv.dtype or not att.is_contiguous() or _avail(att) < B * T * nq * 64:
+            raise capi.TcavtError("attn_bwd_scores.att: contiguous 16-bit [B*T, nq*64] of the type of qkv required")
     opt = lambda t: ptr(t) if t is not None else None
     check(lib().tcavt_attn_bwd_scores(ptr(qkv), ptr(dO), opt(dS), opt(PT), opt(dST), opt(dQ),
                                       dQ.stride(0) if dQ is not None else 0, opt(stats), ptr(kv_len), B, T, Tp, nq, nkv, 64,
-                                      scale, _DT16(qkv), stream_ptr()), "tcavt_attn_bwd_scores")
+                                      scale, _DT16(qkv), opt(lse), opt(att), stream_ptr()), "tcavt_attn_bwd_scores")
 
 
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
