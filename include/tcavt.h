@@ -467,6 +467,16 @@ int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, void* dS_bf
                           float* dQ, int64_t ld_dq, float* stats, const int32_t* kv_len, int B, int T, int Tp, int nq,
                           int nkv, int head_dim, float scale, int dtype16, const float* lse, const void* att,
                           tcavt_stream_t stream);
+/* The attention backward of the LoRA-trainable variant in two launches when a head's keys / queries fit in LDS
+   (tcavt_attn_bwd_resident_ok: T <= 256, 16 % (nq / nkv) == 0): K, V, K^T resident for dQ; q, dO and their transposes resident
+   for dK, dV; row statistics from the forward (lse, att: tcavt_attn_causal_gqa_lse).  Writes g_qkv16 [B*T][(nq + 2 nkv) * 64]
+   = the 16-bit gradient of the q|k|v projection's output with the RoPE rotation of q and k undone (rope_cos / rope_sin
+   fp32 [T][32], position = row inside the sample) -- what tcavt_attn_bwd_scores + tcavt_attn_bwd_dkv + tcavt_rope_bwd_pack
+   produce through an fp32 buffer.  stats: fp32 [B*nq*T][4] scratch (lse, 1, dO . O, 0 per query row). */
+int tcavt_attn_bwd_resident_ok(int T, int nq, int nkv);
+int tcavt_attn_bwd_resident(const void* qkv16, const void* dO16, const void* att16, const float* lse, void* g_qkv16,
+                            float* stats, const float* rope_cos, const float* rope_sin, const int32_t* kv_len, int B, int T,
+                            int nq, int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream);
 /* dK, dV of the attention backward, key-major on the matrix cores (one workgroup per sample, key/value head and 64 keys;
    P^T, dS^T rebuilt from `stats`, the query heads of the group summed in registers): writes the k and v columns of
    g32 [B*T, (nq+2nkv)*64] fp32 (every row; no zero-initialisation needed) */

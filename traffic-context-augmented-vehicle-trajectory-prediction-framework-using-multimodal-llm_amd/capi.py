@@ -241,6 +241,9 @@ _SIGNATURES = {
                                        c_float, c_void_p],
     "tcavt_attn_bwd_scores": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
+    "tcavt_attn_bwd_resident_ok": [c_int, c_int, c_int],
+    "tcavt_attn_bwd_resident": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "tcavt_attn_bwd_dkv": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                            c_int, c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],

@@ -716,12 +716,45 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_scores_kernel(const bf16_t* _
 // ---------------------------------------------------------------------------
 constexpr int ABQ_WAVES = 16;
 
+// The gradient of 16 rows x 64 dimensions of one head in MFMA accumulator layout (acc[dt][e]: row r0 + 4 (l >> 4) + e,
+// dimension 16 dt + (l & 15)) -> the 16-bit gradient of the projections' outputs: dimensions d and d + 32 of a row sit in
+// the same lane (dt and dt + 2), so the transposed rotation of rope_bwd_pack_kernel needs no exchange:
+//   g_t1 = g_o1 cos + g_o2 sin,   g_t2 = g_o2 cos - g_o1 sin     (position = row inside the sample)
+template <bool F16>
+__device__ __forceinline__ void store_grad16(const f32x4 (&acc)[4], bf16_t* __restrict__ out, long ld, long row0, int r0, int T,
+                                             int col0, bool rotate, const float* __restrict__ cosT,
+                                             const float* __restrict__ sinT, int lane) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = r0 + 4 * l4 + e;
+    if (i >= T) continue;
+    bf16_t* o = out + (row0 + i) * ld + col0 + l15;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      float a = acc[w][e], b2 = acc[w + 2][e];
+      if (rotate) {
+        const float cs = cosT[i * 32 + w * 16 + l15], sn = sinT[i * 32 + w * 16 + l15];
+        const float t1 = a * cs + b2 * sn, t2 = b2 * cs - a * sn;
+        a = t1;
+        b2 = t2;
+      }
+      o[w * 16] = to16<F16>(a);
+      o[w * 16 + 32] = to16<F16>(b2);
+    }
+  }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(ABQ_WAVES * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                      const bf16_t* __restrict__ att, const float* __restrict__ lse,
                                                                      float* __restrict__ dQ, long ld_dq, float* __restrict__ stats,
                                                                      const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
-                                                                     float scale) {
+                                                                     float scale, bf16_t* __restrict__ g16,
+                                                                     const float* __restrict__ cosT, const float* __restrict__ sinT) {
+  // g16 (optional, with cosT / sinT [T][32]): the 16-bit gradient of the q|k|v projection's output [B*T][(nq + 2 nkv) * 64];
+  // the q columns are written here directly, transposed rotation applied (then dQ is not written: no fp32 round trip and
+  // no rope_bwd_pack launch)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);                 // [Tp][72]
   bf16_t* Vs = Ks + Tp * 72;                                    // [Tp][72]
@@ -834,6 +867,10 @@ __global__ __launch_bounds__(ABQ_WAVES * 64) void attn_bwd_dq_kernel(const bf16_
         const u32x4 bv = {b0[0], b0[1], b1[0], b1[1]};
         dq[dt] = mfma16b<F16>(afr, __builtin_bit_cast(bf16x8, bv), dq[dt]);
       }
+    }
+    if (g16) {
+      store_grad16<F16>(dq, g16, nqkv, row0, strip * 16, T, h * 64, true, cosT, sinT, lane);
+      continue;
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -983,6 +1020,169 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int key = k0 + wave * 16 + l4 * 4 + e;
+      if (key < T) {
+        g32[(row0 + key) * nqkv + (nq + j) * 64 + dt * 16 + l15] = dk[dt][e];
+        g32[(row0 + key) * nqkv + (nq + nkv + j) * 64 + dt * 16 + l15] = dv[dt][e];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dK, dV with the query side resident (T <= 256): one workgroup per (sample, key/value head), sixteen waves of 16 keys each
+// (their K / V rows are B fragments held in registers for the whole kernel).  Per query head of the group, q and dO of ALL
+// queries are staged once -- row-major for the score products, transposed (two queries per dword) for the gradient
+// products: 140 KB -- and every wave walks the queries at or below its keys' diagonal, 32 at a time, without a barrier:
+//   S = q K^T, dP = dO V^T as [queries x keys] tiles (A = q / dO rows from LDS): D[m][n] = query 4 (l >> 4) + e, key l & 15
+//   P = exp(s - m) inv,  dS = scale P (dP - dot)         (statistics of the query, from LDS)
+//   dV += P^T dO, dK += dS^T q: the lane's eight values of two query tiles ARE its A fragment (rows = keys, contraction
+//   over queries in the order tile 0 queries 4 g .. 4 g + 3, tile 1 the same), B = dO^T / q^T read with the same order.
+// attn_bwd_dkv_kernel re-staged a 64-query
+// block per iteration behind four barriers and moved P^T / dS^T through LDS tiles with two-byte stores.
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(1024) void attn_bwd_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                                const float* __restrict__ stats, float* __restrict__ g32,
+                                                                const int* __restrict__ kv_len, int T, int Tp, int nq, int nkv,
+                                                                float scale, bf16_t* __restrict__ g16,
+                                                                const float* __restrict__ cosT, const float* __restrict__ sinT) {
+  // g16 (optional): as in attn_bwd_dq_kernel -- the k (rotation undone) and v columns go out as 16 bits, g32 is not written
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tts = Tp + 4;
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);  // [Tp][72]
+  bf16_t* Gs = Qs + Tp * 72;                     // [Tp][72]
+  bf16_t* QT = Gs + Tp * 72;                     // [64][Tp + 4]
+  bf16_t* GT = QT + 64 * tts;                    // [64][Tp + 4]
+  float* st = reinterpret_cast<float*>(GT + 64 * tts);  // [3][Tp]: m * log2(e), 1 / sum, sum(P dP)
+  const int grp = nq / nkv;
+  const int b = blockIdx.x / nkv, j = blockIdx.x % nkv;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long nqkv = (long)(nq + 2 * nkv) * 64;
+  const long row0 = (long)b * T;
+  const int klen = min(kv_len[b], T);
+  // key strip of this wave: (s, 7 - s, 8 + s, 15 - s) for the four waves of SIMD s -- equal numbers of query tiles per SIMD
+  const int sd = wave & 3, rr = wave >> 2;
+  const int strip = rr == 0 ? sd : rr == 1 ? 7 - sd : rr == 2 ? 8 + sd : 15 - sd;
+  const int key0 = strip * 16;
+  const bool active = key0 < Tp;  // (uniform)
+  bf16x8 kf[2], vf[2];
+  {
+    const long ar = row0 + min(key0 + l15, T - 1);  // keys >= T: clamped load; masked (>= klen)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + (nq + j) * 64 + kk * 32 + l4 * 8);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(qkv + ar * nqkv + (nq + nkv + j) * 64 + kk * 32 + l4 * 8);
+    }
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging: thread (query pair qp, 16-byte chunk c) -> rows 2 qp, 2 qp + 1 of q and dO (Tp / 2 * 8 <= 1024 pair-chunks)
+  const int qp = threadIdx.x >> 3, ch = threadIdx.x & 7;
+  const bool stager = threadIdx.x < (Tp >> 1) * 8;
+  u32x4 qa, qb, ga, gb;
+  auto fetch = [&](int hh) {
+    const int h = j * grp + hh;
+    const long g0 = row0 + min(2 * qp, T - 1), g1 = row0 + min(2 * qp + 1, T - 1);
+    qa = *reinterpret_cast<const u32x4*>(qkv + g0 * nqkv + h * 64 + ch * 8);
+    qb = *reinterpret_cast<const u32x4*>(qkv + g1 * nqkv + h * 64 + ch * 8);
+    ga = *reinterpret_cast<const u32x4*>(dO + g0 * (long)(nq * 64) + h * 64 + ch * 8);
+    gb = *reinterpret_cast<const u32x4*>(dO + g1 * (long)(nq * 64) + h * 64 + ch * 8);
+  };
+  const float c2 = scale * 1.4426950408889634f;
+  for (int hh = 0; hh < grp; ++hh) {
+    const int h = j * grp + hh;
+    if (hh > 0) __syncthreads();  // everyone is done with the previous head's blocks
+    // (keeping the next head's rows in flight in registers over this head's arithmetic pushed the kernel past its 128
+    //  registers: measured slower, 40.5 vs 40.2 ms per step)
+    if (stager) fetch(hh);
+    if (stager) {
+      const int r0 = 2 * qp, r1 = r0 + 1;
+      const u32x4 zero4 = {0u, 0u, 0u, 0u};
+      if (r0 >= T) { qa = zero4; ga = zero4; }
+      if (r1 >= T) { qb = zero4; gb = zero4; }
+      *reinterpret_cast<u32x4*>(Qs + r0 * 72 + ch * 8) = qa;
+      *reinterpret_cast<u32x4*>(Qs + r1 * 72 + ch * 8) = qb;
+      *reinterpret_cast<u32x4*>(Gs + r0 * 72 + ch * 8) = ga;
+      *reinterpret_cast<u32x4*>(Gs + r1 * 72 + ch * 8) = gb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<unsigned int*>(QT + (ch * 8 + 2 * e) * tts + r0) = (qa[e] & 0xffffu) | (qb[e] << 16);
+        *reinterpret_cast<unsigned int*>(QT + (ch * 8 + 2 * e + 1) * tts + r0) = (qa[e] >> 16) | (qb[e] & 0xffff0000u);
+        *reinterpret_cast<unsigned int*>(GT + (ch * 8 + 2 * e) * tts + r0) = (ga[e] & 0xffffu) | (gb[e] << 16);
+        *reinterpret_cast<unsigned int*>(GT + (ch * 8 + 2 * e + 1) * tts + r0) = (ga[e] >> 16) | (gb[e] & 0xffff0000u);
+      }
+    }
+    if ((int)threadIdx.x < Tp) {
+      const int i = threadIdx.x;
+      f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+      if (i < T) sv = *reinterpret_cast<const f32x4*>(stats + (((long)b * nq + h) * T + i) * 4);
+      st[i] = sv[0] * 1.4426950408889634f;
+      st[Tp + i] = i < T ? sv[1] : 0.f;  // (queries >= T: P = 0)
+      st[2 * Tp + i] = sv[2];
+    }
+    __syncthreads();
+    if (active) {
+      for (int q0 = key0 & ~31; q0 < Tp; q0 += 32) {  // queries at or below the diagonal of this wave's keys
+        f32x4 sa[2], da[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
+          const int qrow = q0 + t * 16 + l15;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qrow * 72 + kk * 32 + l4 * 8);
+            const bf16x8 gf = *reinterpret_cast<const bf16x8*>(Gs + qrow * 72 + kk * 32 + l4 * 8);
+            sacc = mfma16b<F16>(qf, kf[kk], sacc);
+            dacc = mfma16b<F16>(gf, vf[kk], dacc);
+          }
+          sa[t] = sacc;
+          da[t] = dacc;
+        }
+        u32x4 pfr, dfr;
+        const int key = key0 + l15;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int qi = q0 + t * 16 + 4 * l4;
+          const f32x4 m2 = *reinterpret_cast<const f32x4*>(st + qi), iv = *reinterpret_cast<const f32x4*>(st + Tp + qi),
+                      dt_ = *reinterpret_cast<const f32x4*>(st + 2 * Tp + qi);
+          float pv[4], ds[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = key <= qi + e && key < klen;  // (queries >= T have 1 / sum = 0)
+            pv[e] = ok ? __builtin_amdgcn_exp2f(fmaf(sa[t][e], c2, -m2[e])) * iv[e] : 0.f;
+            ds[e] = scale * pv[e] * (da[t][e] - dt_[e]);
+          }
+          pfr[2 * t] = pack16x2<F16>(pv[0], pv[1]);
+          pfr[2 * t + 1] = pack16x2<F16>(pv[2], pv[3]);
+          dfr[2 * t] = pack16x2<F16>(ds[0], ds[1]);
+          dfr[2 * t + 1] = pack16x2<F16>(ds[2], ds[3]);
+        }
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pfr), df = __builtin_bit_cast(bf16x8, dfr);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16_t* gt = GT + (dt * 16 + l15) * tts + q0 + 4 * l4;
+          const bf16_t* qt = QT + (dt * 16 + l15) * tts + q0 + 4 * l4;
+          const u32x2 g0 = *reinterpret_cast<const u32x2*>(gt), g1 = *reinterpret_cast<const u32x2*>(gt + 16);
+          const u32x2 q0v = *reinterpret_cast<const u32x2*>(qt), q1v = *reinterpret_cast<const u32x2*>(qt + 16);
+          const u32x4 gv = {g0[0], g0[1], g1[0], g1[1]}, qv = {q0v[0], q0v[1], q1v[0], q1v[1]};
+          dv[dt] = mfma16b<F16>(pf, __builtin_bit_cast(bf16x8, gv), dv[dt]);
+          dk[dt] = mfma16b<F16>(df, __builtin_bit_cast(bf16x8, qv), dk[dt]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  if (g16) {
+    store_grad16<F16>(dk, g16, nqkv, row0, key0, T, (nq + j) * 64, true, cosT, sinT, lane);
+    store_grad16<F16>(dv, g16, nqkv, row0, key0, T, (nq + nkv + j) * 64, false, cosT, sinT, lane);
+    return;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = key0 + l4 * 4 + e;
       if (key < T) {
         g32[(row0 + key) * nqkv + (nq + j) * 64 + dt * 16 + l15] = dk[dt][e];
         g32[(row0 + key) * nqkv + (nq + nkv + j) * 64 + dt * 16 + l15] = dv[dt][e];
@@ -1353,7 +1553,8 @@ extern "C" int tcavt_attn_bwd_scores(const void* qkv_bf16, const void* dO_bf16, 
     }
     hipLaunchKernelGGL(kq, dim3((unsigned)(B * nkv)), dim3(ABQ_WAVES * 64), lds, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16), static_cast<const bf16_t*>(att), lse,
-                       dQ, (long)ld_dq, stats, kv_len, T, Tp, nq, nkv, scale);
+                       dQ, (long)ld_dq, stats, kv_len, T, Tp, nq, nkv, scale, static_cast<bf16_t*>(nullptr),
+                       static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
     TCAVT_CHECK_LAUNCH("attn_bwd_scores(resident)");
     return TCAVT_OK;
   }
@@ -1373,12 +1574,73 @@ extern "C" int tcavt_attn_bwd_dkv(const void* qkv_bf16, const void* dO_bf16, con
   TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_dkv: head_dim 64 and nq %% nkv == 0 required");
   TCAVT_CHECK_ARG(Tp >= T && Tp - T < 64 && Tp % 64 == 0, "attn_bwd_dkv: Tp must be T rounded up to a multiple of 64");
   TCAVT_CHECK_ARG(aligned16(qkv_bf16) && aligned16(dO_bf16) && aligned16(stats), "attn_bwd_dkv: 16-byte alignment required");
+  static const bool no_resident = getenv("TCAVT_ATTN_BWD_NO_RESIDENT") != nullptr;  // (A/B switch)
+  if (Tp <= 256 && !no_resident) {  // the query side of a whole head fits in LDS: no query-block loop
+    const int lds = (2 * Tp * 72 + 2 * 64 * (Tp + 4)) * 2 + 3 * Tp * 4;
+    auto kr = dtype16 == TCAVT_F16 ? attn_bwd_dkv_res_kernel<true> : attn_bwd_dkv_res_kernel<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[dtype16 == TCAVT_F16]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      if (e != hipSuccess) {
+        tcavt::set_error("attn_bwd_dkv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return TCAVT_ERR_HIP;
+      }
+      attr_set[dtype16 == TCAVT_F16] = true;
+    }
+    hipLaunchKernelGGL(kr, dim3((unsigned)(B * nkv)), dim3(1024), lds, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16), stats, g32, kv_len, T, Tp, nq, nkv,
+                       scale, static_cast<bf16_t*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr));
+    TCAVT_CHECK_LAUNCH("attn_bwd_dkv(resident)");
+    return TCAVT_OK;
+  }
   auto kfn = dtype16 == TCAVT_F16 ? attn_bwd_dkv_kernel<true> : attn_bwd_dkv_kernel<false>;
   hipLaunchKernelGGL(kfn, dim3((unsigned)((long)B * nkv * (Tp / 64))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv_bf16), static_cast<const bf16_t*>(dO_bf16),
                      stats, g32, kv_len, T, Tp, nq, nkv, scale);
   TCAVT_CHECK_LAUNCH("attn_bwd_dkv");
   return TCAVT_OK;
+}
+
+// Whole attention backward of the LoRA-trainable variant in its resident form: two launches, 16-bit output, no fp32 scratch
+extern "C" int tcavt_attn_bwd_resident(const void* qkv16, const void* dO16, const void* att16, const float* lse, void* g_qkv16,
+                                       float* stats, const float* rope_cos, const float* rope_sin, const int32_t* kv_len, int B,
+                                       int T, int nq, int nkv, int head_dim, float scale, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(qkv16 && dO16 && att16 && lse && g_qkv16 && stats && rope_cos && rope_sin && kv_len && B > 0 && T > 0 && is16(dtype16),
+                  "attn_bwd_resident: bad args");
+  TCAVT_CHECK_ARG(head_dim == 64 && nkv > 0 && nq % nkv == 0, "attn_bwd_resident: head_dim 64 and nq %% nkv == 0 required");
+  TCAVT_CHECK_ARG(tcavt_attn_bwd_resident_ok(T, nq, nkv), "attn_bwd_resident: T=%d, nq / nkv = %d outside the resident form (T <= 256, 16 %% (nq / nkv) == 0)", T, nq / nkv);
+  TCAVT_CHECK_ARG(aligned16(qkv16) && aligned16(dO16) && aligned16(att16) && aligned16(stats) && aligned16(g_qkv16),
+                  "attn_bwd_resident: 16-byte alignment required");
+  const int Tp = (T + 63) & ~63;
+  const bool f16 = dtype16 == TCAVT_F16;
+  auto kq = f16 ? attn_bwd_dq_kernel<true> : attn_bwd_dq_kernel<false>;
+  auto kr = f16 ? attn_bwd_dkv_res_kernel<true> : attn_bwd_dkv_res_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[f16]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kr), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) {
+      tcavt::set_error("attn_bwd_resident: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return TCAVT_ERR_HIP;
+    }
+    attr_set[f16] = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bf16_t* q_ = static_cast<const bf16_t*>(qkv16);
+  const bf16_t* g_ = static_cast<const bf16_t*>(dO16);
+  hipLaunchKernelGGL(kq, dim3((unsigned)(B * nkv)), dim3(ABQ_WAVES * 64), (2 * Tp * 72 + 64 * (Tp + 4)) * 2, st, q_, g_,
+                     static_cast<const bf16_t*>(att16), lse, static_cast<float*>(nullptr), 0L, stats, kv_len, T, Tp, nq, nkv, scale,
+                     static_cast<bf16_t*>(g_qkv16), rope_cos, rope_sin);
+  TCAVT_CHECK_LAUNCH("attn_bwd_resident(dq)");
+  hipLaunchKernelGGL(kr, dim3((unsigned)(B * nkv)), dim3(1024), (2 * Tp * 72 + 2 * 64 * (Tp + 4)) * 2 + 3 * Tp * 4, st, q_, g_,
+                     static_cast<const float*>(stats), static_cast<float*>(nullptr), kv_len, T, Tp, nq, nkv, scale,
+                     static_cast<bf16_t*>(g_qkv16), rope_cos, rope_sin);
+  TCAVT_CHECK_LAUNCH("attn_bwd_resident(dkv)");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_attn_bwd_resident_ok(int T, int nq, int nkv) {
+  return T > 0 && T <= 256 && nkv > 0 && nq % nkv == 0 && ABQ_WAVES % (nq / nkv) == 0;
 }
 
 extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float grad_scale, float* scratch,

@@ -66,8 +66,12 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
     if scores == "fused":
         # two MFMA kernels and the pack: query-major (row statistics, dQ), key-major (dK, dV; group sum in registers);
         # S, dP, P, dS never reach memory
-        g32 = buf("at.g32", (B * T, nqkv), f32)
         stats = buf("at.stats", (BH * T, 4), f32)
+        if (lse is not None and ops.attn_bwd_resident_ok(T, nq, nkv) and cos.shape[0] >= T
+                and os.environ.get("TCAVT_ATTN_BWD_NO_RESIDENT") is None):
+            # a head's keys / queries fit in LDS: two launches, 16-bit output with the rotation undone in their epilogues
+            return ops.attn_bwd_resident(qkv, dO, att, lse, g_qkv, stats, cos, sin, kv_len, B, T, nq, nkv, scale)
+        g32 = buf("at.g32", (B * T, nqkv), f32)
         # (lse / att from the forward's tape: the scores kernel sweeps the keys once, not twice)
         ops.attn_bwd_scores(qkv, dO, None, None, None, kv_len, B, T, Tp, nq, nkv, scale, dQ=g32, stats=stats, lse=lse, att=att)
         ops.attn_bwd_dkv(qkv, dO, stats, g32, kv_len, B, T, Tp, nq, nkv, scale)

@@ -679,6 +679,30 @@ def attn_bwd_scores(qkv, dO, dS, PT, dST, kv_len, B, T, Tp, nq, nkv, scale, dQ=N
                                       scale, _DT16(qkv), opt(lse), opt(att), stream_ptr()), "tcavt_attn_bwd_scores")
 
 
+def attn_bwd_resident_ok(T, nq, nkv):
+    """Shapes the two-launch resident form of the attention backward serves (T <= 256, 16 % (nq / nkv) == 0)."""
+    return bool(lib().tcavt_attn_bwd_resident_ok(T, nq, nkv))
+
+
+def attn_bwd_resident(qkv, dO, att, lse, g_qkv, stats, cos, sin, kv_len, B, T, nq, nkv, scale):
+    """The whole causal GQA attention backward in two launches (tcavt_attn_bwd_resident): g_qkv 16-bit [B*T, (nq+2nkv)*64]
+    = gradient of the projections' outputs, RoPE undone; att / lse from attn_causal_gqa(..., lse=...)."""
+    ncols = (nq + 2 * nkv) * 64
+    for t, n, nm in ((qkv, B * T * ncols, "qkv"), (dO, B * T * nq * 64, "dO"), (att, B * T * nq * 64, "att"),
+                     (g_qkv, B * T * ncols, "g_qkv")):
+        if t.dtype != qkv.dtype or t.dtype not in _H16 or not t.is_contiguous() or (not t.is_cuda and not _ALLOW_CPU):
+            raise capi.TcavtError(f"attn_bwd_resident.{nm}: contiguous 16-bit GPU tensor of the type of qkv required")
+        if _avail(t) < n:
+            raise capi.TcavtError(f"attn_bwd_resident.{nm}: buffer too small")
+    for t, n, nm in ((lse, B * nq * T, "lse"), (stats, B * nq * T * 4, "stats"), (cos, T * 32, "cos"), (sin, T * 32, "sin")):
+        _req(t, torch.float32, f"attn_bwd_resident.{nm}")
+        _need(t, n, f"attn_bwd_resident.{nm}")
+    _need(kv_len, B, "attn_bwd_resident.kv_len")
+    check(lib().tcavt_attn_bwd_resident(ptr(qkv), ptr(dO), ptr(att), ptr(lse), ptr(g_qkv), ptr(stats), ptr(cos), ptr(sin),
+                                        ptr(kv_len), B, T, nq, nkv, 64, scale, _DT16(qkv), stream_ptr()), "tcavt_attn_bwd_resident")
+    return g_qkv
+
+
 def gqa_rope_bwd_pack(G3, out, cos, sin, nq, nkv, L):
     M = G3.shape[0]
     _req(G3, torch.float32, "gqa_rope_bwd_pack.G3")
