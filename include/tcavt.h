@@ -490,9 +490,23 @@ int tcavt_gqa_rope_bwd_pack(const float* G3, void* out_bf16, const float* rope_c
  * G bf16 [M][ldg] (a gradient), X 16-bit [M][ldx] of x_dtype (an fp16 forward activation is converted to bf16 on the way),
  * C fp32, ACCUMULATED into with float atomics (zero it or let it hold an earlier contribution): [n][ldc], or, with
  * trans_out != 0, the transpose [H][ldc].
- * g_dtype: 0 / TCAVT_BF16 (as described), or TCAVT_F16 together with an fp16 X: both operands as they are on the f16 MFMA. */
+ * g_dtype: 0 / TCAVT_BF16 (as described), or TCAVT_F16 together with an fp16 X: both operands as they are on the f16 MFMA.
+ * rs_part (optional, NULL: none): fp32 [M][rs_npart] partial sums of squares of the fused RMSNorm over rs_h features
+ *   (tcavt_llama_layer.tape_part): row m of G is multiplied by rsqrt(sum / rs_h + rs_eps) on the way in -- dB of the adapters
+ *   from the taped, un-normalised t. */
 int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
-                   int64_t ldc, int M, int H, int trans_out, int g_dtype, tcavt_stream_t stream);
+                   int64_t ldc, int M, int H, int trans_out, int g_dtype, const float* rs_part, int rs_npart, int rs_h,
+                   float rs_eps, tcavt_stream_t stream);
+/* dA of both adapters in one pass over the taped residual stream (LoRA-trainable variant; modify_scripts/modify_train.py:512-528:
+ * PEFT lora_A of q_proj and v_proj behind their own lora_dropout modules, input = input_layernorm(h)):
+ *   dA[r][n]      += gamma[n] * sum_m g_t[m][r]      * rs[m] * drop_q(x16[m][n])        r < 16
+ *   dA[16 + r][n] += gamma[n] * sum_m g_t[m][16 + r] * rs[m] * drop_v(x16[m][n])
+ * x16 16-bit [M][H] = the layer's input stream, part fp32 [M][npart] = its partial sums of squares (rs as in tcavt_wgrad_tn),
+ * gamma fp32 [H], g_t 16-bit [M][64], dA fp32 [>= 32][ldc] ACCUMULATED into with float atomics; masks of sites site_q / site_v
+ * as tcavt_lora_down draws them (dropout_p == 0: none).  Replaces rmsnorm + two mask kernels + two tcavt_wgrad_tn launches. */
+int tcavt_lora_wgrad_a(const void* x16, const float* part, int npart, float eps, const float* gamma, const void* g_t, float* dA,
+                       int64_t ldc, int M, int H, float dropout_p, uint64_t dropout_seed, uint32_t site_q, uint32_t site_v,
+                       int dtype16, tcavt_stream_t stream);
 
 /* clip_grad_norm_ on a flat fp32 gradient vector (modify_scripts/modify_train.py:1192):
      g *= grad_scale;  g *= min(1, max_norm / (||g|| + 1e-6))
@@ -563,6 +577,9 @@ typedef struct tcavt_llama_layer {
   void* tape_att;     /* optional, 16-bit [M][nq * 64]: the attention's output (instead of the shared workspace `att`) ... */
   float* tape_lse;    /* ... and fp32 [B][nq][L]: its log-sum-exp per query row (tcavt_attn_causal_gqa_lse); both or neither:
                          with them tcavt_attn_bwd_scores runs one sweep over the keys instead of two */
+  float* tape_part;   /* optional, fp32 [M][npart_in]: the partial sums of squares of this layer's INPUT stream (what its fused
+                         input RMSNorm reads; otherwise they live in the shared `part` and are overwritten by the o_proj
+                         epilogue) -- 1 / rms of every token for the adapters' weight gradients */
 } tcavt_llama_layer;
 
 typedef struct tcavt_llama_stack_args {

@@ -660,3 +660,69 @@ def test_attn_bwd_one_sweep_from_the_forwards_row_statistics(gpu, B, T, nq, nkv,
         e2 = rel_err(two[:, lo:hi].float().cpu(), want[:, lo:hi].float().cpu())
         assert e1 < (3e-3 if dt == torch.float16 else 1e-2), (name, e1, e2)
         assert e1 < 1.5 * e2 + 1e-4, (name, e1, e2)  # no worse than the form that recomputes the statistics
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("drop", [False, True])
+def test_lora_wgrad_a_one_pass_matches_the_composed_leaf(gpu, drop, dt):
+    """tcavt_lora_wgrad_a (dA of both adapters from the taped input stream: norm, masks and both products in one pass) and
+    tcavt_wgrad_tn's row scale (dB from the taped un-normalised t) against the composed form they replace -- rmsnorm16, two
+    mask kernels, lora_down, three wgrad_tn -- and against fp32 arithmetic on the same 16-bit operands."""
+    from tcavt_amd import ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(31)
+    M, H, nqkv, eps, s = 200, 512, 384, 1e-5, 4.0
+    h16 = (torch.randn(M, H, generator=g) * 1.5).to(dt).to(dev)
+    gamma = (torch.rand(H, generator=g) + 0.5).to(dev)
+    g_t = torch.zeros(M, 64)
+    g_t[:, :32] = torch.randn(M, 32, generator=g) * 3
+    g_t = g_t.to(dt).to(dev)
+    g_qkv = torch.randn(M, nqkv, generator=g).to(dt).to(dev)
+    a_plain = torch.zeros(64, H)
+    a_plain[:8] = torch.randn(8, H, generator=g) * 0.05
+    a_plain[16:24] = torch.randn(8, H, generator=g) * 0.05
+    a_plain = a_plain.to(dt).to(dev)
+    npart = 8
+    part = h16.float().pow(2).view(M, npart, H // npart).sum(-1).contiguous()
+    rs = torch.rsqrt(part.sum(1) / H + eps)
+    spec = (0.1, 0xABCDE, 77) if drop else None
+    site_v = 91 if drop else None
+    # composed leaf (the round-3 form before the fusion)
+    xn = torch.empty(M, H, dtype=dt, device=dev)
+    ops.rmsnorm16(h16, gamma, eps, out16=xn)
+    xq, xv = xn, xn
+    if drop:
+        xq, xv = torch.empty_like(xn), torch.empty_like(xn)
+        ops.dropout(xn, xq, *spec)
+        ops.dropout(xn, xv, spec[0], spec[1], site_v)
+    dA0 = torch.zeros(64, H, device=dev)
+    ops.wgrad_tn(g_t, 0, 16, xq, dA0)
+    ops.wgrad_tn(g_t, 16, 16, xv, dA0[16:])
+    # one pass
+    dA1 = torch.zeros(64, H, device=dev)
+    ops.lora_wgrad_a(h16, part, gamma, g_t, dA1, eps, dropout=spec, site_v=site_v)
+    # fp32 arithmetic on the same operands and masks (mask = where the composed form's dropped copy is non-zero or xn is zero)
+    keep_q = (xq.float() != 0) | (xn.float() == 0)
+    keep_v = (xv.float() != 0) | (xn.float() == 0)
+    inv_keep = 1.0 / (1.0 - spec[0]) if drop else 1.0
+    xn32 = h16.float() * rs[:, None] * gamma[None, :]
+    want_q = g_t[:, :16].float().T @ (xn32 * keep_q * inv_keep)
+    want_v = g_t[:, 16:32].float().T @ (xn32 * keep_v * inv_keep)
+    tol = 2e-3 if dt == torch.float16 else 1.2e-2
+    assert rel_err(dA1[:16].cpu(), want_q.cpu()) < tol and rel_err(dA1[16:32].cpu(), want_v.cpu()) < tol
+    assert rel_err(dA0[:16].cpu(), want_q.cpu()) < tol  # (the composed form rounds xn instead of g_t * rs: the same class of error)
+    assert rel_err(dA1[:32].cpu(), dA0[:32].cpu()) < 2 * tol and float(dA1[32:].abs().max()) == 0.0
+    # dB: taped un-normalised t (as tcavt_lora_down leaves it in the forward: no row scale), scaled by rs while staged
+    t_tape = torch.zeros(M, 64, dtype=dt, device=dev)
+    a_cat = (a_plain.float() * gamma[None, :]).to(dt)  # the forward's operand: gain folded in
+    ops.lora_down(h16, a_cat, t_tape, s, dropout=spec, site_v=site_v)
+    dB1 = torch.zeros(nqkv, 64, device=dev)
+    ops.wgrad_tn(t_tape, 0, 32, g_qkv, dB1, trans_out=True, rs_part=part, rs_h=H, rs_eps=eps)
+    want_b = g_qkv.float().T @ (t_tape.float()[:, :32] * rs[:, None])
+    assert rel_err(dB1[:, :32].cpu(), want_b.cpu()) < tol
+    t_re = torch.zeros(M, 64, dtype=dt, device=dev)
+    ops.lora_down(xn, a_plain, t_re, s, dropout=spec, site_v=site_v)  # the composed form's recomputed t
+    dB0 = torch.zeros(nqkv, 64, device=dev)
+    ops.wgrad_tn(t_re, 0, 32, g_qkv, dB0, trans_out=True)
+    assert rel_err(dB1[:, :32].cpu(), dB0[:, :32].cpu()) < 3 * tol

@@ -66,7 +66,7 @@ class LlamaLayer(ctypes.Structure):
     """Mirror of ``tcavt_llama_layer`` (include/tcavt.h)."""
 
     _fields_ = [(n, c_void_p) for n in ("w_qkv", "a_cat", "b_ext", "w_o", "w_gu", "w_d", "tape_h_mid", "tape_h_out",
-                                        "tape_qkv", "tape_gu", "tape_t", "tape_att", "tape_lse")]
+                                        "tape_qkv", "tape_gu", "tape_t", "tape_att", "tape_lse", "tape_part")]
 
 
 TLAYER_FIELDS = ("w_in", "b_in", "w_out", "b_out", "w_q", "b_q", "w_kv", "b_kv", "w_co", "b_co", "w1", "b1", "w2", "b2",
@@ -248,7 +248,9 @@ _SIGNATURES = {
                            c_int, c_void_p],
     "tcavt_gqa_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_wgrad_tn": [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int,
-                       c_void_p],
+                       c_void_p, c_int, c_int, c_float, c_void_p],
+    "tcavt_lora_wgrad_a": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                           ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_int, c_void_p],
     "tcavt_clip_grad_norm": [c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p],
     "tcavt_layernorm_bwd": [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "tcavt_mha_bwd": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

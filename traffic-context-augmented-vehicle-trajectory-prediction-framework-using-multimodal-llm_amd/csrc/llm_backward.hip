@@ -1270,6 +1270,135 @@ static size_t attn_bwd_lds(int T) {
   return (size_t)2 * AB_QB * T * 4 + (size_t)2 * AB_QB * (AB_HD + 1) * 4 + (size_t)2 * T * AB_LDK * 2;
 }
 
+// 1 / rms of a token from the fused RMSNorm's partial sums of squares, added in index order (as row_rscale of the GEMMs)
+__device__ __forceinline__ float part_rscale(const float* __restrict__ q, int npart, float inv_h, float eps) {
+  float ss = 0.f;
+  for (int i = 0; i < npart; i += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(q + i);
+    ss += v[0];
+    ss += v[1];
+    ss += v[2];
+    ss += v[3];
+  }
+  return rsqrtf(ss * inv_h + eps);
+}
+
+// ---------------------------------------------------------------------------
+// dA of both adapters in ONE pass over the taped residual stream (LoRA-trainable variant):
+//     dA_q[r][n] = gamma[n] * sum_m (g_t[m][r] rs[m]) * drop_q(h[m][n]),   dA_v likewise with g_t[m][16 + r] and drop_v
+// h = the layer's 16-bit input stream, rs = 1 / rms of its rows (from the forward's partial sums), gamma = the input
+// norm's gain, drop = the forward's masks regenerated (Philox, one call per octet and site) -- i.e. g_t^T (mask * rmsnorm(h))
+// without ever writing rmsnorm(h), its two dropped copies or reading them back (round 3 before this: one norm kernel, two mask
+// kernels and two wgrad_tn launches per layer, ~230 MB of traffic instead of 33).  Layout of the work as wgrad_tn_kernel:
+// a workgroup owns 256 columns and a range of tokens, stages 32 tokens per step transposed in LDS (two tokens per dword),
+// partial sums meet in dA through fp32 atomics.
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void lora_wgrad_a_kernel(const bf16_t* __restrict__ X, const float* __restrict__ part, int npart,
+                                                           float inv_h, float eps, const float* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ Gt, float* __restrict__ dA, long ldc, int M,
+                                                           int H, int m_per_wg, DropoutP dq, DropoutP dv) {
+  constexpr int XS = 40;
+  __shared__ __attribute__((aligned(16))) bf16_t xq[256 * XS];
+  __shared__ __attribute__((aligned(16))) bf16_t xv[256 * XS];
+  __shared__ __attribute__((aligned(16))) bf16_t gt[32 * XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h0 = blockIdx.x * 256;
+  const int mbeg = blockIdx.y * m_per_wg, mend = min(mbeg + m_per_wg, M);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const bool drop = dq.p > 0.f;
+  const bf16_t* xvp = drop ? xv : xq;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tp = tid >> 4, cc = (tid & 15) * 16;  // this thread stages tokens 2 tp, 2 tp + 1, columns cc .. cc + 15
+  const int grow = tid >> 2, gc0 = (tid & 3) * 8;  // ... and (tid < 128) token grow, g_t columns gc0 .. gc0 + 7
+  for (int m0 = mbeg; m0 < mend; m0 += 32) {
+    {
+      u32x4 v[2][2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int m = m0 + 2 * tp + r;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          v[r][o] = u32x4{0u, 0u, 0u, 0u};
+          if (m < mend && h0 + cc + 8 * o < H) v[r][o] = *reinterpret_cast<const u32x4*>(X + (long)m * H + h0 + cc + 8 * o);
+        }
+      }
+      u32x4 gv = {0u, 0u, 0u, 0u};
+      float rs = 0.f;
+      if (tid < 128 && m0 + grow < mend) {
+        gv = *reinterpret_cast<const u32x4*>(Gt + (long)(m0 + grow) * 64 + gc0);
+        rs = part_rscale(part + (long)(m0 + grow) * npart, npart, inv_h, eps);
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        u32x4 wq[2], wv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          wq[r] = v[r][o];
+          if (drop) {  // (uniform) the forward's masks: element (m, n) of site q / v, one generator call per octet
+            const unsigned long long oct =
+                ((unsigned long long)(m0 + 2 * tp + r) * (unsigned long long)H + (unsigned long long)(h0 + cc + 8 * o)) >> 3;
+            float sq[8], sv[8];
+            dropout_oct(dq, oct, sq);
+            dropout_oct(dv, oct, sv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = from16_lo<F16>(v[r][o][e]), hi = from16_hi<F16>(v[r][o][e]);
+              wq[r][e] = pack16x2<F16>(lo * sq[2 * e], hi * sq[2 * e + 1]);
+              wv[r][e] = pack16x2<F16>(lo * sv[2 * e], hi * sv[2 * e + 1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // columns cc + 8 o + 2 e (+ 1): tokens 2 tp | 2 tp + 1 in one dword
+          const int c = cc + 8 * o + 2 * e;
+          *reinterpret_cast<unsigned int*>(&xq[c * XS + 2 * tp]) = (wq[0][e] & 0xffffu) | (wq[1][e] << 16);
+          *reinterpret_cast<unsigned int*>(&xq[(c + 1) * XS + 2 * tp]) = (wq[0][e] >> 16) | (wq[1][e] & 0xffff0000u);
+          if (drop) {
+            *reinterpret_cast<unsigned int*>(&xv[c * XS + 2 * tp]) = (wv[0][e] & 0xffffu) | (wv[1][e] << 16);
+            *reinterpret_cast<unsigned int*>(&xv[(c + 1) * XS + 2 * tp]) = (wv[0][e] >> 16) | (wv[1][e] & 0xffff0000u);
+          }
+        }
+      }
+      if (tid < 128) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          gt[(gc0 + 2 * e) * XS + grow] = to16<F16>(from16_lo<F16>(gv[e]) * rs);
+          gt[(gc0 + 2 * e + 1) * XS + grow] = to16<F16>(from16_hi<F16>(gv[e]) * rs);
+        }
+      }
+    }
+    __syncthreads();
+    // wave: columns h0 + 64 wave .. + 63; A = (g_t rs)^T rows (q adapter: 0..15, v adapter: 16..31), B = masked h^T rows, K = 32 tokens
+    const u32x4 aq = *reinterpret_cast<const u32x4*>(&gt[r16 * XS + kq * 8]);
+    const u32x4 av = *reinterpret_cast<const u32x4*>(&gt[(16 + r16) * XS + kq * 8]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int row = (wave * 64 + b * 16 + r16) * XS + kq * 8;
+      const u32x4 bq = *reinterpret_cast<const u32x4*>(&xq[row]);
+      const u32x4 bv = *reinterpret_cast<const u32x4*>(&xvp[row]);
+      acc[0][b] = mfma16b<F16>(__builtin_bit_cast(bf16x8, aq), __builtin_bit_cast(bf16x8, bq), acc[0][b]);
+      acc[1][b] = mfma16b<F16>(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[1][b]);
+    }
+    __syncthreads();
+  }
+  // acc[a][b]: adapter a, rank row 4 kq + e, column h0 + 64 wave + 16 b + r16
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int h = h0 + wave * 64 + b * 16 + r16;
+      if (h >= H) continue;
+      const float gm = gamma[h];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dA + (long)(a * 16 + 4 * kq + e) * ldc + h, acc[a][b][e] * gm);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Weight gradient with a SKINNY output, without physical transposes:
 //     C[n][h] (+)= sum_m G[m][g0 + n] * X[m][h]          n < 16 * NB (NB <= 4),  h < H,  contraction over the M tokens
@@ -1286,7 +1415,12 @@ static size_t attn_bwd_lds(int T) {
 template <bool XF16, bool GF16 = false>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ G, long ldg, int g0, int NB,
                                                        const bf16_t* __restrict__ X, long ldx, float* __restrict__ C,
-                                                       long ldc, int M, int H, int m_per_wg, int trans_out) {
+                                                       long ldc, int M, int H, int m_per_wg, int trans_out,
+                                                       const float* __restrict__ rs_part, int rs_npart, float rs_inv_h,
+                                                       float rs_eps) {
+  // rs_part (optional): G's rows are multiplied by 1 / rms of their token while they are staged -- the fused RMSNorm's partial
+  // sums of squares [M][rs_npart], added in index order as the forward's GEMMs do (dB of the adapters: the tape holds the
+  // un-normalised t, the graph's t is rs * t)
   constexpr int XS = 40;  // LDS row stride in 16-bit elements (32 tokens + pad; 80 bytes: 16-byte aligned rows)
   __shared__ __attribute__((aligned(16))) bf16_t xt[256 * XS];
   __shared__ __attribute__((aligned(16))) bf16_t gt[64 * XS];
@@ -1325,6 +1459,11 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
         u32x4 v = {0u, 0u, 0u, 0u};
         const int mg = m0 + grow;
         if (mg < mend) v = *reinterpret_cast<const u32x4*>(G + (long)mg * ldg + g0 + gc0);
+        if (rs_part && mg < mend) {
+          const float rs = part_rscale(rs_part + (long)mg * rs_npart, rs_npart, rs_inv_h, rs_eps);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pack16x2<GF16>(from16_lo<GF16>(v[e]) * rs, from16_hi<GF16>(v[e]) * rs);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           gt[(gc0 + 2 * e) * XS + grow] = static_cast<bf16_t>(v[e] & 0xffffu);
@@ -1657,7 +1796,11 @@ extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float g
 }
 
 extern "C" int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X, int64_t ldx, int x_dtype, float* C,
-                              int64_t ldc, int M, int H, int trans_out, int g_dtype, tcavt_stream_t stream) {
+                              int64_t ldc, int M, int H, int trans_out, int g_dtype, const float* rs_part, int rs_npart, int rs_h,
+                              float rs_eps, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(!rs_part || (rs_npart > 0 && rs_npart % 4 == 0 && rs_h > 0 && aligned16(rs_part)),
+                  "wgrad_tn: rs_part needs rs_npart %% 4 == 0, rs_h > 0 and 16-byte alignment");
+  const float rs_inv_h = rs_part ? 1.f / (float)rs_h : 0.f;
   TCAVT_CHECK_ARG(G && X && C && M > 0 && H > 0 && n > 0 && n <= 64 && n % 16 == 0 && g_col0 >= 0 && g_col0 % 8 == 0 &&
                       ldg % 8 == 0 && ldx % 8 == 0 && H % 8 == 0 && is16(x_dtype),
                   "wgrad_tn: n in {16, 32, 48, 64}, g_col0 / ldg / ldx / H multiples of 8");
@@ -1672,14 +1815,37 @@ extern "C" int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, con
   const dim3 grid(gx, split), block(256);
   if (g_dtype == TCAVT_F16)
     hipLaunchKernelGGL((wgrad_tn_kernel<true, true>), grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
-                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out,
+                       rs_part, rs_npart, rs_inv_h, rs_eps);
   else if (x_dtype == TCAVT_F16)
     hipLaunchKernelGGL(wgrad_tn_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
-                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out,
+                       rs_part, rs_npart, rs_inv_h, rs_eps);
   else
     hipLaunchKernelGGL(wgrad_tn_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(G),
-                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out);
+                       (long)ldg, g_col0, n / 16, static_cast<const bf16_t*>(X), (long)ldx, C, (long)ldc, M, H, m_per_wg, trans_out,
+                       rs_part, rs_npart, rs_inv_h, rs_eps);
   TCAVT_CHECK_LAUNCH("wgrad_tn");
+  return TCAVT_OK;
+}
+
+extern "C" int tcavt_lora_wgrad_a(const void* x16, const float* part, int npart, float eps, const float* gamma, const void* g_t,
+                                  float* dA, int64_t ldc, int M, int H, float dropout_p, uint64_t dropout_seed, uint32_t site_q,
+                                  uint32_t site_v, int dtype16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(x16 && part && gamma && g_t && dA && M > 0 && H > 0 && H % 16 == 0 && npart > 0 && npart % 4 == 0 && ldc >= H &&
+                      is16(dtype16) && dropout_p >= 0.f && dropout_p < 1.f,
+                  "lora_wgrad_a: bad args (H %% 16 == 0, npart %% 4 == 0, ldc >= H, 0 <= dropout_p < 1)");
+  TCAVT_CHECK_ARG(aligned16(x16) && aligned16(part) && aligned16(g_t), "lora_wgrad_a: 16-byte alignment required");
+  const DropoutP dq = make_dropout(dropout_p, dropout_seed, site_q), dv = make_dropout(dropout_p, dropout_seed, site_v);
+  const int gx = (H + 255) / 256;
+  int split = 256 / gx;  // ~one workgroup per CU
+  if (split < 1) split = 1;
+  int m_per_wg = ((M + split - 1) / split + 31) / 32 * 32;
+  split = (M + m_per_wg - 1) / m_per_wg;
+  auto kfn = dtype16 == TCAVT_F16 ? lora_wgrad_a_kernel<true> : lora_wgrad_a_kernel<false>;
+  hipLaunchKernelGGL(kfn, dim3(gx, split), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16), part, npart,
+                     1.f / (float)H, eps, gamma, static_cast<const bf16_t*>(g_t), dA, (long)ldc, M, H, m_per_wg, dq, dv);
+  TCAVT_CHECK_LAUNCH("lora_wgrad_a");
   return TCAVT_OK;
 }
 

@@ -227,6 +227,13 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     void* x_out = (stream16 && tape) ? static_cast<void*>(w.tape_h_out) : a->h16;
     TCAVT_CHECK_ARG(qkv && (!w.a_cat || t), "llama_stack_forward: qkv / t workspace missing");
     const Ev ev{a->events, st, li};
+    if (tape && w.tape_part) {  // the input stream's partial sums of squares, before the o_proj epilogue reuses `part`
+      const hipError_t rc = hipMemcpyAsync(w.tape_part, a->part, (size_t)M * np_in * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (rc != hipSuccess) {
+        set_error("llama_stack_forward: layer %d: copy of the partial sums failed: %s", li, hipGetErrorString(rc));
+        return TCAVT_ERR_HIP;
+      }
+    }
     // ---- LoRA down-projection: t = (alpha / r) * dropout(x16) . (A * gamma)^T, un-normalised (the row scale is applied
     // to the whole q|k|v accumulator, the adapter update included); one fused kernel for both adapters and their masks
     if (w.a_cat) {

@@ -212,7 +212,15 @@ class LoraBackward:
                 # kept only the un-normalised t of its fused RMSNorm): xn = rmsnorm(h_in), t = s * dropout(xn) A^T
                 dA.zero_()
                 dB.zero_()
-                if sv.dspec is not None:  # ... with the forward's two masks
+                if (sv.h_in.dtype == g_t.dtype and getattr(sv, "part", None) is not None and H % 16 == 0
+                        and os.environ.get("TCAVT_LORA_LEAF_UNFUSED") is None):  # (A/B switch)
+                    # one pass over the taped input stream for dA (norm and both masks recomputed on the way in), dB from
+                    # the taped un-normalised t with 1 / rms applied while it is staged: two launches, ~85 MB instead of
+                    # nine passes and ~350 MB per layer
+                    ops.lora_wgrad_a(sv.h_in, sv.part, d.g1, g_t, dA, eps, dropout=None if sv.dspec is None else sv.dspec[0],
+                                     site_v=None if sv.dspec is None else sv.dspec[1][2])
+                    ops.wgrad_tn(sv.t, 0, 2 * LORA_V, g_qkv, dB, trans_out=True, rs_part=sv.part, rs_h=H, rs_eps=eps)
+                elif sv.dspec is not None:  # ... with the forward's two masks
                     if sv.h_in.dtype == torch.float32:
                         ops.rmsnorm(sv.h_in, d.g1, eps, out_bf16=xn, out_drop=xl, dropout=sv.dspec[0])
                     else:  # 16-bit residual stream on the tape

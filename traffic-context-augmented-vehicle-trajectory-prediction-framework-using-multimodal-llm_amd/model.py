@@ -764,7 +764,10 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                                      t=ws.get(f"ll.sv.t{li}", (M, 64), self.storage, dev, zero=True) if self.use_lora else None,
                                      # the attention's output and row log-sum-exp: one sweep over the keys in its backward
                                      att=ws.get(f"ll.sv.att{li}", (M, ll.n_q_heads * ll.head_dim), self.storage, dev),
-                                     lse=ws.get(f"ll.sv.lse{li}", (B * ll.n_q_heads * L,), torch.float32, dev))
+                                     lse=ws.get(f"ll.sv.lse{li}", (B * ll.n_q_heads * L,), torch.float32, dev),
+                                     # partial sums of squares of the layer's input stream: 1 / rms per token for the adapters'
+                                     # weight gradients (the shared `part` is reused by the o_proj epilogue)
+                                     part=ws.get(f"ll.sv.part{li}", (M, self.norm_npart(M)), torch.float32, dev))
                 sv.qkv = sv.qkv_padded[:M]  # (the backward's score products read keys up to the next multiple of 64)
                 tape.layers.append(sv)
                 c, src = carr[li], P.carr[li]
@@ -772,7 +775,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                     setattr(c, f, getattr(src, f))
                 c.tape_h_mid, c.tape_h_out = sv.h_mid.data_ptr(), sv.h_out.data_ptr()
                 c.tape_qkv, c.tape_gu = sv.qkv_padded.data_ptr(), sv.gu.data_ptr()
-                c.tape_att, c.tape_lse = sv.att.data_ptr(), sv.lse.data_ptr()
+                c.tape_att, c.tape_lse, c.tape_part = sv.att.data_ptr(), sv.lse.data_ptr(), sv.part.data_ptr()
                 if self.use_lora:
                     c.tape_t = sv.t.data_ptr()
                 h_in = sv.h_out

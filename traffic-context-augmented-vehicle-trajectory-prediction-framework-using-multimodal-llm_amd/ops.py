@@ -793,9 +793,10 @@ def masked_mean_bwd(gemb, lens, genc, B, P, D):
     check(lib().tcavt_masked_mean_bwd(ptr(gemb), ptr(lens), ptr(genc), B, P, D, stream_ptr()), "tcavt_masked_mean_bwd")
 
 
-def wgrad_tn(g, g_col0, n, x, out, trans_out=False):
+def wgrad_tn(g, g_col0, n, x, out, trans_out=False, rs_part=None, rs_h=0, rs_eps=0.0):
     """out[i, h] += sum_m g[m, g_col0 + i] * x[m, h] (i < n; trans_out: out[h, i]) -- skinny weight gradient without
-    transposes (tcavt_wgrad_tn).  g bf16 [M, >= g_col0 + n], x fp16 / bf16 [M, H], out fp32, accumulated into."""
+    transposes (tcavt_wgrad_tn).  g bf16 [M, >= g_col0 + n], x fp16 / bf16 [M, H], out fp32, accumulated into.
+    rs_part (fp32 [M, npart], with rs_h, rs_eps): rows of g are scaled by 1 / rms of their token on the way in."""
     if g.dtype not in _H16 or x.dtype not in _H16 or out.dtype != torch.float32 or (g.dtype == torch.float16 and x.dtype != torch.float16):
         raise capi.TcavtError("wgrad_tn: g bf16 with x fp16 / bf16, or g fp16 with x fp16; out fp32")
     M, H = x.shape
@@ -804,8 +805,35 @@ def wgrad_tn(g, g_col0, n, x, out, trans_out=False):
     rows, cols = (H, n) if trans_out else (n, H)
     if out.shape[0] < rows or out.shape[1] < cols:
         raise capi.TcavtError(f"wgrad_tn.out: needs at least ({rows}, {cols})")
+    npart = 0
+    if rs_part is not None:
+        _req(rs_part, torch.float32, "wgrad_tn.rs_part")
+        if rs_part.dim() != 2 or rs_part.shape[0] < M or not rs_part.is_contiguous() or rs_h <= 0:
+            raise capi.TcavtError("wgrad_tn.rs_part: contiguous fp32 [M, npart] and rs_h > 0 required")
+        npart = rs_part.shape[1]
     check(lib().tcavt_wgrad_tn(ptr(g), g.stride(0), int(g_col0), int(n), ptr(x), x.stride(0), _DT[x.dtype], ptr(out), out.stride(0),
-                               M, H, int(trans_out), _DT[g.dtype], stream_ptr()), "tcavt_wgrad_tn")
+                               M, H, int(trans_out), _DT[g.dtype], ptr(rs_part) if rs_part is not None else None, npart, int(rs_h),
+                               float(rs_eps), stream_ptr()), "tcavt_wgrad_tn")
+
+
+def lora_wgrad_a(x16, part, gamma, g_t, dA, eps, dropout=None, site_v=None):
+    """dA (fp32 [>= 32, H], accumulated into) of both adapters in one pass over the layer's taped input stream x16 [M, H]:
+    rows 0..15 = (g_t[:, :16] * rs)^T drop_q(x16) * gamma, rows 16..31 the v adapter (tcavt_lora_wgrad_a).  part: the
+    stream's partial sums of squares [M, npart]; dropout = (p, seed, site_q) with site_v as in lora_down."""
+    _req16(x16, "lora_wgrad_a.x16")
+    _req16(g_t, "lora_wgrad_a.g_t", like=x16)
+    _req(part, torch.float32, "lora_wgrad_a.part")
+    _req(gamma, torch.float32, "lora_wgrad_a.gamma")
+    _req(dA, torch.float32, "lora_wgrad_a.dA")
+    M, H = x16.shape
+    if (part.dim() != 2 or part.shape[0] < M or not part.is_contiguous() or g_t.shape[0] < M or g_t.shape[1] != 64
+            or not g_t.is_contiguous() or dA.dim() != 2 or dA.shape[0] < 32 or dA.shape[1] < H or dA.stride(1) != 1):
+        raise capi.TcavtError("lora_wgrad_a: part [M, npart], g_t [M, 64], dA [>= 32, >= H] required")
+    _need(gamma, H, "lora_wgrad_a.gamma")
+    p, seed, site = _drop(dropout)
+    check(lib().tcavt_lora_wgrad_a(ptr(x16), ptr(part), part.shape[1], float(eps), ptr(gamma), ptr(g_t), ptr(dA), dA.stride(0), M, H,
+                                   p, seed, site, site + 1 if site_v is None else int(site_v), _DT16(x16), stream_ptr()),
+          "tcavt_lora_wgrad_a")
 
 
 def clip_grad_norm(g, max_norm, scratch, grad_scale=1.0):
