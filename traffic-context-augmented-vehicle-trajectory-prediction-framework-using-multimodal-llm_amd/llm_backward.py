@@ -212,8 +212,9 @@ class LoraBackward:
                 # kept only the un-normalised t of its fused RMSNorm): xn = rmsnorm(h_in), t = s * dropout(xn) A^T
                 dA.zero_()
                 dB.zero_()
-                if (sv.h_in.dtype == g_t.dtype and getattr(sv, "part", None) is not None and H % 16 == 0
-                        and os.environ.get("TCAVT_LORA_LEAF_UNFUSED") is None):  # (A/B switch)
+                fused_leaf = (sv.h_in.dtype == g_t.dtype and getattr(sv, "part", None) is not None and H % 16 == 0
+                              and os.environ.get("TCAVT_LORA_LEAF_UNFUSED") is None)  # (A/B switch)
+                if fused_leaf:
                     # one pass over the taped input stream for dA (norm and both masks recomputed on the way in), dB from
                     # the taped un-normalised t with 1 / rms applied while it is staged: two launches, ~85 MB instead of
                     # nine passes and ~350 MB per layer
@@ -237,7 +238,8 @@ class LoraBackward:
                         ops.rmsnorm16(sv.h_in, d.g1, eps, out16=xn)
                     ops.lora_down(xn, dT.a_plain, t_re, s)
                     ops.wgrad_tn(g_t, 0, 2 * LORA_V, xn, dA)
-                ops.wgrad_tn(t_re, 0, 2 * LORA_V, g_qkv, dB, trans_out=True)  # dB = g_qkv^T t, stored as [nqkv, 64]
+                if not fused_leaf:
+                    ops.wgrad_tn(t_re, 0, 2 * LORA_V, g_qkv, dB, trans_out=True)  # dB = g_qkv^T t, stored as [nqkv, 64]
                 p = f"{pre}{li}.self_attn."
                 if scaled:  # out of the backward's scale (device scalar, no synchronisation)
                     torch.mul(dA[:r], inv_s, out=G[p + "q_proj.lora_A.weight"])
