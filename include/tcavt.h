@@ -499,8 +499,8 @@ int tcavt_wgrad_tn(const void* G, int64_t ldg, int g_col0, int n, const void* X,
                    float rs_eps, tcavt_stream_t stream);
 /* dA of both adapters in one pass over the taped residual stream (LoRA-trainable variant; modify_scripts/modify_train.py:512-528:
  * PEFT lora_A of q_proj and v_proj behind their own lora_dropout modules, input = input_layernorm(h)):
- *   dA[r][n]      += gamma[n] * sum_m g_t[m][r]      * rs[m] * drop_q(x16[m][n])        r < 16
- *   dA[16 + r][n] += gamma[n] * sum_m g_t[m][16 + r] * rs[m] * drop_v(x16[m][n])
+ *   dA[r][n]      += gamma[n] * sum_m g_t[m][r]      * drop_q(round16(rs[m] * x16[m][n]))        r < 16
+ *   dA[16 + r][n] += gamma[n] * sum_m g_t[m][16 + r] * drop_v(round16(rs[m] * x16[m][n]))
  * x16 16-bit [M][H] = the layer's input stream, part fp32 [M][npart] = its partial sums of squares (rs as in tcavt_wgrad_tn),
  * gamma fp32 [H], g_t 16-bit [M][64], dA fp32 [>= 32][ldc] ACCUMULATED into with float atomics; masks of sites site_q / site_v
  * as tcavt_lora_down draws them (dropout_p == 0: none).  Replaces rmsnorm + two mask kernels + two tcavt_wgrad_tn launches. */

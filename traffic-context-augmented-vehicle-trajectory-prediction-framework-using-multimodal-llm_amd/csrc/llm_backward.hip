@@ -1285,7 +1285,7 @@ __device__ __forceinline__ float part_rscale(const float* __restrict__ q, int np
 
 // ---------------------------------------------------------------------------
 // dA of both adapters in ONE pass over the taped residual stream (LoRA-trainable variant):
-//     dA_q[r][n] = gamma[n] * sum_m (g_t[m][r] rs[m]) * drop_q(h[m][n]),   dA_v likewise with g_t[m][16 + r] and drop_v
+//     dA_q[r][n] = gamma[n] * sum_m g_t[m][r] * drop_q(rs[m] h[m][n]),   dA_v likewise with g_t[m][16 + r] and drop_v
 // h = the layer's 16-bit input stream, rs = 1 / rms of its rows (from the forward's partial sums), gamma = the input
 // norm's gain, drop = the forward's masks regenerated (Philox, one call per octet and site) -- i.e. g_t^T (mask * rmsnorm(h))
 // without ever writing rmsnorm(h), its two dropped copies or reading them back (round 3 before this: one norm kernel, two mask
@@ -1302,6 +1302,10 @@ __global__ __launch_bounds__(256) void lora_wgrad_a_kernel(const bf16_t* __restr
   __shared__ __attribute__((aligned(16))) bf16_t xq[256 * XS];
   __shared__ __attribute__((aligned(16))) bf16_t xv[256 * XS];
   __shared__ __attribute__((aligned(16))) bf16_t gt[32 * XS];
+  // 1 / rms of the 32 tokens of a step.  It goes to the STREAM operand (rs h: rms 1 whatever the layer), not to g_t: the
+  // gradient operand sits under the backward's power-of-two scale near the top of the half range, and 1 / rms of the
+  // embedding rows layer 0 reads is ~50 -- g_t rs left the range there (inf, then NaN in the product)
+  __shared__ float rs_s[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h0 = blockIdx.x * 256;
   const int mbeg = blockIdx.y * m_per_wg, mend = min(mbeg + m_per_wg, M);
@@ -1328,29 +1332,27 @@ __global__ __launch_bounds__(256) void lora_wgrad_a_kernel(const bf16_t* __restr
         }
       }
       u32x4 gv = {0u, 0u, 0u, 0u};
-      float rs = 0.f;
-      if (tid < 128 && m0 + grow < mend) {
-        gv = *reinterpret_cast<const u32x4*>(Gt + (long)(m0 + grow) * 64 + gc0);
-        rs = part_rscale(part + (long)(m0 + grow) * npart, npart, inv_h, eps);
-      }
+      if (tid < 128 && m0 + grow < mend) gv = *reinterpret_cast<const u32x4*>(Gt + (long)(m0 + grow) * 64 + gc0);
+      if (tid < 32) rs_s[tid] = m0 + tid < mend ? part_rscale(part + (long)(m0 + tid) * npart, npart, inv_h, eps) : 0.f;
+      __syncthreads();
+      const float rs2[2] = {rs_s[2 * tp], rs_s[2 * tp + 1]};
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
         u32x4 wq[2], wv[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          wq[r] = v[r][o];
+          float sq[8], sv[8];
           if (drop) {  // (uniform) the forward's masks: element (m, n) of site q / v, one generator call per octet
             const unsigned long long oct =
                 ((unsigned long long)(m0 + 2 * tp + r) * (unsigned long long)H + (unsigned long long)(h0 + cc + 8 * o)) >> 3;
-            float sq[8], sv[8];
             dropout_oct(dq, oct, sq);
             dropout_oct(dv, oct, sv);
+          }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = from16_lo<F16>(v[r][o][e]), hi = from16_hi<F16>(v[r][o][e]);
-              wq[r][e] = pack16x2<F16>(lo * sq[2 * e], hi * sq[2 * e + 1]);
-              wv[r][e] = pack16x2<F16>(lo * sv[2 * e], hi * sv[2 * e + 1]);
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float lo = from16_lo<F16>(v[r][o][e]) * rs2[r], hi = from16_hi<F16>(v[r][o][e]) * rs2[r];
+            wq[r][e] = drop ? pack16x2<F16>(lo * sq[2 * e], hi * sq[2 * e + 1]) : pack16x2<F16>(lo, hi);
+            if (drop) wv[r][e] = pack16x2<F16>(lo * sv[2 * e], hi * sv[2 * e + 1]);
           }
         }
 #pragma unroll
@@ -1367,13 +1369,13 @@ __global__ __launch_bounds__(256) void lora_wgrad_a_kernel(const bf16_t* __restr
       if (tid < 128) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          gt[(gc0 + 2 * e) * XS + grow] = to16<F16>(from16_lo<F16>(gv[e]) * rs);
-          gt[(gc0 + 2 * e + 1) * XS + grow] = to16<F16>(from16_hi<F16>(gv[e]) * rs);
+          gt[(gc0 + 2 * e) * XS + grow] = static_cast<bf16_t>(gv[e] & 0xffffu);
+          gt[(gc0 + 2 * e + 1) * XS + grow] = static_cast<bf16_t>(gv[e] >> 16);
         }
       }
     }
     __syncthreads();
-    // wave: columns h0 + 64 wave .. + 63; A = (g_t rs)^T rows (q adapter: 0..15, v adapter: 16..31), B = masked h^T rows, K = 32 tokens
+    // wave: columns h0 + 64 wave .. + 63; A = g_t^T rows (q adapter: 0..15, v adapter: 16..31), B = masked (rs h)^T rows, K = 32 tokens
     const u32x4 aq = *reinterpret_cast<const u32x4*>(&gt[r16 * XS + kq * 8]);
     const u32x4 av = *reinterpret_cast<const u32x4*>(&gt[(16 + r16) * XS + kq * 8]);
 #pragma unroll
