@@ -70,6 +70,9 @@ struct GemmP {
   long lp_lda;
   int lp_np;
   float lp_scale;
+  // skinny form, M > 16: the two 16-token blocks of a column block go to TWO workgroups (sk_msplit = 2) instead of one that
+  // loads both blocks' activation rows for every weight fragment (twice the weight bytes through the CU's load path)
+  int sk_msplit;
   int sk_split;
   float* sk_slab;
   int* sk_cnt;
@@ -1801,11 +1804,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   // round-robin to the 8 XCDs, so the slabs the last arriver reads were written through its own XCD's L2 (a speed choice
   // only: the hand-off below is correct for any placement).  Host: (number of column blocks) % 8 == 0 when S > 1.
   const int S = p.sk_split;
-  int blk = blockIdx.x, ks = 0;
+  int blk = blockIdx.x, ks = 0, mrow0 = 0;
   if (S > 1) {
     const int q = blockIdx.x >> 3;
     ks = q % S;
     blk = (q / S) * 8 + (blockIdx.x & 7);
+  } else if (p.sk_msplit > 1) {  // (the two token blocks of a column block: ids congruent mod 8 -> one XCD, the weights' second read is an L2 hit)
+    const int q = blockIdx.x >> 3;
+    mrow0 = 16 * (q & 1);
+    blk = (q >> 1) * 8 + (blockIdx.x & 7);
   }
   const int n0 = blk * (16 * NCB);
   const int r16 = lane & 15, kq = lane >> 4;
@@ -1824,15 +1831,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const bf16_t* wp[NCB];
 #pragma unroll
   for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
-  const bf16_t* xp0 = p.A + (long)min(r16, p.M - 1) * p.lda + kbeg + kq * 8;
+  const bf16_t* xp0 = p.A + (long)min(mrow0 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
-  const bool two = p.M > 16;
+  const bool two = p.M > 16 && p.sk_msplit <= 1;
   constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
   // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
   // loads is in flight instead of after the K loop: the row scale's partial sums, the RoPE position -> cos / sin rows, the
   // 16-bit residual, and (wave 0) the LoRA second source.  Each of these was one more dependent global-memory round trip
   // at the tail of a kernel that is a few microseconds long (decode step).
-  const int pm = wave * 16 + r16;          // (meaningful for wave < 2)
+  const int pm = mrow0 + wave * 16 + r16;  // (meaningful for wave < 2)
   const long pmm = pm < p.M ? pm : 0;
   float rs = 1.f;
   f32x4 rope_c = {1.f, 1.f, 1.f, 1.f}, rope_s = {0.f, 0.f, 0.f, 0.f};
@@ -1895,7 +1902,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if (32 * u < p.K2) {
-              l_a0[u] = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(r16, p.M - 1) * p.lda2 + 32 * u + kq * 8);
+              l_a0[u] = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(mrow0 + r16, p.M - 1) * p.lda2 + 32 * u + kq * 8);
               l_a1[u] = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + 32 * u + kq * 8);
 #pragma unroll
               for (int c = 0; c < NCB; ++c)
@@ -1945,7 +1952,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       }
       __syncthreads();
       if (wave == 0 && ks == 0) {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(lp_t + min(r16, p.M - 1) * 32 + kq * 8);
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(lp_t + min(mrow0 + r16, p.M - 1) * 32 + kq * 8);
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(lp_t + min(16 + r16, p.M - 1) * 32 + kq * 8);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
@@ -1968,7 +1975,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         }
       }
       for (int k = 64; k < p.K2; k += 32) {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(r16, p.M - 1) * p.lda2 + k + kq * 8);
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(mrow0 + r16, p.M - 1) * p.lda2 + k + kq * 8);
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(p.A2 + (long)min(16 + r16, p.M - 1) * p.lda2 + k + kq * 8);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
@@ -1990,7 +1997,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   // ---- wave mb (0 / 1) finishes token block mb: lane holds features 4 (lane >> 4) .. + 3 of every column block for
   // token m = 16 mb + (lane & 15); the partials are added in wave order
   const int mb = wave & 1;
-  const int m = mb * 16 + r16, nq = 4 * kq;
+  const int m = mrow0 + mb * 16 + r16, nq = 4 * kq;
   const bool rowok = m < p.M;
   const long mm = rowok ? m : 0;
   f32x4 v[NCB];
@@ -2143,7 +2150,12 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
     if ((long)nblk * S * 2 * NCB * 256 * 4 > p.sk_slab_bytes || nblk > p.sk_cnt_n) S = 1;
   }
   q.sk_split = S;
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(nblk * S), dim3(SK_WAVES * 64), 0, stream, q);
+  static const bool no_msplit = getenv("TCAVT_SK_NO_MSPLIT") != nullptr;  // (A/B switch)
+  // (only where the column blocks alone leave CUs idle -- o, down, q|k|v: 96-128 of 256; with more workgroups than CUs the
+  //  second read of every weight row costs more than the activation rows it saves: gate|up 25.8 -> 33.2 us, lm_head likewise)
+  const int msplit = (S == 1 && p.M > 16 && nblk % 8 == 0 && nblk <= 256 && !no_msplit) ? 2 : 1;
+  q.sk_msplit = msplit;
+  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(nblk * S * msplit), dim3(SK_WAVES * 64), 0, stream, q);
   TCAVT_CHECK_LAUNCH("gemm_bf16(skinny)");
   return TCAVT_OK;
 }
@@ -2264,6 +2276,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       p.ldw2 = a->ldw2;
     }
   }
+  p.sk_msplit = 1;
   p.sk_split = 1;
   p.sk_slab = nullptr;
   p.sk_cnt = nullptr;
@@ -2326,8 +2339,13 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       if (stream16) return f16 ? launch_skinny<EPI_NORM16, 1, true>(p, s) : launch_skinny<EPI_NORM16, 1, false>(p, s);
       return f16 ? launch_skinny<EPI_NORM, 1, true>(p, s) : launch_skinny<EPI_NORM, 1, false>(p, s);
     }
-    if (e0 == 0 && K2 == 0 && a->N % 16 == 0)
+    if (e0 == 0 && K2 == 0 && a->N % 16 == 0) {
+      // (lm_head with more than 16 rows: two column blocks per workgroup share the activation fragments -- with 16 columns
+      //  the 32 activation rows are twice the weight bytes of every step, and the launch is bound by the CUs' load paths)
+      if (a->M > 16 && a->N % 256 == 0 && a->N >= 8192)
+        return f16 ? launch_skinny<EPI_GENERIC, 2, true>(p, s) : launch_skinny<EPI_GENERIC, 2, false>(p, s);
       return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
+    }
   }
   if (epi & TCAVT_EPI_SILU_BWD) {  // dgrad of down_proj with d(silu(gate) * up) in the epilogue: the 4-wave kernel only
     TCAVT_CHECK_ARG(epi == TCAVT_EPI_SILU_BWD && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->K >= 128 &&
