@@ -936,7 +936,7 @@ typedef struct tcavt_decode_args {
   int64_t splitk_ws_bytes;
   void* lora_part;                 /* optional, B * H floats: layers 1.. take their LoRA down-projection from partial sums the
                                       previous layer's down-projection GEMM leaves here (tcavt_gemm_args.lora_part: one launch
-                                      per layer less); adapters of rank <= 8 only (lora_rank), NULL = a launch per layer */
+                                      per layer less); adapters of rank <= 8 only (lora_rank), B <= 32, NULL = a launch per layer */
   int32_t lora_rank;
   int32_t reserved3;
 } tcavt_decode_args;

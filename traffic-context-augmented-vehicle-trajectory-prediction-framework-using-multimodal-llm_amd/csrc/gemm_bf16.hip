@@ -1862,18 +1862,20 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       if (k == 0 && lp_in) {
         // t = lp_scale * sum of the lp_np partials the previous residual GEMM left: value (m, j) by thread m * 16 + j of
         // group g, groups of lp_np / G consecutive partials (G = a power of two that divides lp_np), combined in group order
-        const int nv = p.M * 16;
+        // (this workgroup's tokens: all M, or the 16-token block it owns when the token blocks are split, sk_msplit)
+        const int mtok = p.sk_msplit > 1 ? min(16, p.M - mrow0) : p.M;
+        const int nv = mtok * 16, nall = p.M * 16;
         int G = 1;
         while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
         const int tid = threadIdx.x;
         if (tid < G * nv) {
           const int g = tid / nv, v = tid - g * nv, per = p.lp_np / G;
-          const float* src = p.lp_part + (long)g * per * nv + v;
+          const float* src = p.lp_part + (long)g * per * nall + mrow0 * 16 + v;
           float acc_t = 0.f;
           for (int i = 0; i < per; i += 32) {  // (32 loads in flight: one round trip for M <= 8, lp_np = 128)
             float tv[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) tv[u] = src[(long)min(i + u, per - 1) * nv];
+            for (int u = 0; u < 32; ++u) tv[u] = src[(long)min(i + u, per - 1) * nall];
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc_t += i + u < per ? tv[u] : 0.f;
           }
@@ -1941,7 +1943,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   if constexpr (EPI == EPI_ROPE) {
     if (lp_in) {  // (uniform) fused LoRA down-projection: group sums -> t rows in LDS -> wave 0's B fragments, one 32-deep step
       __syncthreads();
-      const int nv = p.M * 16;
+      const int mtok = p.sk_msplit > 1 ? min(16, p.M - mrow0) : p.M;  // (t rows in LDS: local token index)
+      const int nv = mtok * 16;
       if ((int)threadIdx.x < nv) {
         int G = 1;
         while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
@@ -1952,8 +1955,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       }
       __syncthreads();
       if (wave == 0 && ks == 0) {
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(lp_t + min(mrow0 + r16, p.M - 1) * 32 + kq * 8);
-        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lp_t + min(16 + r16, p.M - 1) * 32 + kq * 8);
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(lp_t + min(r16, mtok - 1) * 32 + kq * 8);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(lp_t + min(16 + r16, mtok - 1) * 32 + kq * 8);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
           acc[c][0] = mfma16<F16>(l_w[0][c], a0, acc[c][0]);

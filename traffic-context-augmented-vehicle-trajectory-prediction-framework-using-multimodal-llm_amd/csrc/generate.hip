@@ -505,9 +505,8 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (!w.a_cat || (w.b_ext && a->t)), "llama_decode_step: layer %d: null weight", li);
     // LoRA down-projection: a launch of its own for layer 0 (and without a->lora_part); layers 1.. read the partial sums the
     // previous layer's down-projection GEMM wrote next to its residual epilogue
-    // (B <= 16: every q|k|v workgroup reads all B x 16 x H / 16 partial sums -- at B = 32 that is twice its weight bytes, and
-    // the launch saved is paid back: 1.860 vs 1.871 ms per step, against 1.18 vs 1.23 at B = 8)
-    const bool lp_ok = a->lora_part && a->lora_rank > 0 && a->lora_rank <= 8 && B <= 16;
+    // (a q|k|v workgroup reads the partial sums of its own tokens: all B for B <= 16, its 16-token block beyond)
+    const bool lp_ok = a->lora_part && a->lora_rank > 0 && a->lora_rank <= 8 && B <= 32;
     const bool t_fused = lp_ok && li > 0 && w.a_cat && a->layers[li - 1].w_d;
     if (w.a_cat && !t_fused) {
       tcavt_gemm_args g = {};
