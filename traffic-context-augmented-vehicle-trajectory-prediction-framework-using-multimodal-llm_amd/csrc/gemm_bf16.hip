@@ -1845,6 +1845,28 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   f32x4 rope_c = {1.f, 1.f, 1.f, 1.f}, rope_s = {0.f, 0.f, 0.f, 0.f};
   u32x2 old16[NCB];
   u32x4 l_a0[2], l_a1[2], l_w[2][NCB];
+  // Row scale of the fused RMSNorm (finishing waves): the H / 16 partial sums of a token are split over the four lanes that
+  // share it (kq), eight quads each and ALL requested before the first weight batch -- row_rscale's index-order loop was four
+  // dependent round trips at the head of a launch that lasts ten microseconds.  (Sum order: per lane in index order, then
+  // the four lanes; the tiled kernels add in index order throughout -- same value up to fp32 summation order.)
+  constexpr bool RSK = EPI == EPI_SILU || EPI == EPI_ROPE;
+  f32x4 rsq[RSK ? 8 : 1];
+  int rope_pos_v = 0;
+  if constexpr (RSK) {
+    if (wave < 2 && p.rs_part) {
+      const f32x4* q = reinterpret_cast<const f32x4*>(p.rs_part + pmm * p.rs_npart);
+      const int nq4 = p.rs_npart >> 2, per = (nq4 + 3) >> 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = kq * per + i;
+        rsq[i] = q[min(idx, nq4 - 1)];
+        if (i >= per || idx >= nq4) rsq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if constexpr (EPI == EPI_ROPE) {
+      if (wave < 2) rope_pos_v = p.rope_pos ? p.rope_pos[pmm] : (int)(pmm % p.rope_L);
+    }
+  }
   constexpr bool NORMF = EPI == EPI_NORM || EPI == EPI_NORM16;
   u32x2 lp_af[NORMF ? NCB : 1][NORMF ? 16 : 1];  // producer: this lane's 4 columns of the 16 adapter rows
   for (int k = 0; k < kper; k += 32 * U) {
@@ -1885,11 +1907,37 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     }
     if (k == 0 && wave < 2) {
       if constexpr (EPI == EPI_SILU || EPI == EPI_ROPE) {
-        if (p.rs_part) rs = row_rscale(p, pmm);
+        if (p.rs_part) {
+          const int nq4 = p.rs_npart >> 2, per = (nq4 + 3) >> 2;
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            ss += rsq[i][0];
+            ss += rsq[i][1];
+            ss += rsq[i][2];
+            ss += rsq[i][3];
+          }
+          if (per > 8) {  // (more than 128 partials per row: the rest in further batches)
+            const f32x4* q = reinterpret_cast<const f32x4*>(p.rs_part + pmm * p.rs_npart);
+            for (int i = 8; i < per; ++i) {
+              const int idx = kq * per + i;
+              if (idx < nq4) {
+                const f32x4 v4 = q[idx];
+                ss += v4[0];
+                ss += v4[1];
+                ss += v4[2];
+                ss += v4[3];
+              }
+            }
+          }
+          ss += __shfl_xor(ss, 16, 64);
+          ss += __shfl_xor(ss, 32, 64);
+          rs = rsqrtf(ss * p.rs_inv_h + p.rs_eps);
+        }
       }
       if constexpr (EPI == EPI_ROPE) {
         if (ncol[0] < p.rope_cols) {
-          const int pos = p.rope_pos ? p.rope_pos[pmm] : (int)(pmm % p.rope_L);
+          const int pos = rope_pos_v;
           const int d = (blk & 1) * 16 + 4 * kq;
           rope_c = *reinterpret_cast<const f32x4*>(p.cosT + pos * 32 + d);
           rope_s = *reinterpret_cast<const f32x4*>(p.sinT + pos * 32 + d);
