@@ -1834,7 +1834,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const bf16_t* xp0 = p.A + (long)min(mrow0 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bool two = p.M > 16 && p.sk_msplit <= 1;
-  constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
+  constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms in round 2, and again in round 3 for the residual forms alone: 1.155 vs 1.138; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
   // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
   // loads is in flight instead of after the K loop: the row scale's partial sums, the RoPE position -> cos / sin rows, the
   // 16-bit residual, and (wave 0) the LoRA second source.  Each of these was one more dependent global-memory round trip
