@@ -31,7 +31,10 @@ namespace tcavt {
 // 8 features per lane over the lane's keys, added over the 8 key groups by shuffles and over the KS waves in split order.
 // The new token's own key / value (row b of qkv, position pos[b]) are read from qkv and written to the cache by the
 // workgroup of the kv head's first query head: no separate append launch, and nothing written here is read back here.
-template <bool F16>
+// PFV: the first round of value rows is requested before the softmax statistics meet (its latency passes under the reductions
+// and the barrier).  Costs 32 registers, i.e. resident waves: a gain when the grid is one workgroup per CU (B = 8: 1.138 ->
+// 1.129 ms per step), a loss when several workgroups per CU hide each other's latencies anyway (B = 32: 1.45 -> 1.56).
+template <bool F16, bool PFV>
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ vc, const int* __restrict__ pos,
                                                            bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale,
@@ -93,6 +96,14 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
       }
     }
   }
+  u32x4 vr0[PFV ? 8 : 1];
+  if constexpr (PFV) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = min(j0 + i * 8 + g, jn);
+      vr0[i] = *reinterpret_cast<const u32x4*>((j == jn ? vnew : vb + (long)j * w) + c * 8);
+    }
+  }
   mx = wave_max(mx);
   float sum = 0.f;
   for (int j = j0 + lane; j < j1; j += 64) sum += __expf(s[j] - mx);
@@ -110,8 +121,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
     u32x4 vr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int j = min(jb + i * 8 + g, jn);
-      vr[i] = *reinterpret_cast<const u32x4*>((j == jn ? vnew : vb + (long)j * w) + c * 8);
+      if (PFV && jb == j0) {  // (uniform)
+        vr[i] = vr0[PFV ? i : 0];
+      } else {
+        const int j = min(jb + i * 8 + g, jn);
+        vr[i] = *reinterpret_cast<const u32x4*>((j == jn ? vnew : vb + (long)j * w) + c * 8);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -532,12 +547,13 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     bf16_t* kc = static_cast<bf16_t*>(a->k_cache) + li * per_layer;
     bf16_t* vc = static_cast<bf16_t*>(a->v_cache) + li * per_layer;
     // (the new token's k / v rows are appended to the cache by attn_decode_kernel itself)
-    if (dt == TCAVT_F16)
-      hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
-                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
-    else
-      hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv),
-                         kc, vc, a->pos, static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
+    {
+      const bool pfv = B * nq <= 512;  // (value-row prefetch: only while the grid is about one workgroup per CU)
+      auto kfn = dt == TCAVT_F16 ? (pfv ? attn_decode_kernel<true, true> : attn_decode_kernel<true, false>)
+                                 : (pfv ? attn_decode_kernel<false, true> : attn_decode_kernel<false, false>);
+      hipLaunchKernelGGL(kfn, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv), kc, vc, a->pos,
+                         static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
+    }
     TCAVT_CHECK_LAUNCH("attn_decode");
     {
       tcavt_gemm_args g = {};
