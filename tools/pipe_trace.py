@@ -16,6 +16,8 @@ with torch.device(dev):
     m = model.MultiModalTrajectoryModel.from_config(cfg)
 m.load_weights(make_weights(cfg, seed=1, backend="torch", device=dev))
 m.train(True)
+if os.environ.get("TCAVT_EXP_NO_LORA_DROPOUT"):  # (timing experiment: what the adapters' mask generation costs the step)
+    m.mllm.llama_wrapper.lora_dropout = 0.0
 b = synth.make_batch(cfg, 32, text_len=240, seed=100, ragged=True, min_text=128)
 g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 tr = training.Trainer(m, lr=5e-4, weight_decay=1e-4)
