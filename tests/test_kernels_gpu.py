@@ -423,7 +423,7 @@ def test_gemm_timing_experiment_codes_are_refused(gpu):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M", [1, 7, 16, 32])
+@pytest.mark.parametrize("M", [1, 7, 16, 20, 32])
 def test_skinny_gemm_matches_tile_kernels(gpu, M, dt):
     """The skinny form tcavt_gemm_bf16 selects for M <= 32 rows (decode step of text generation: weights streamed once,
     eight waves split K) against the tiled kernels (forced tile) on every epilogue the decode step uses: fused-RMSNorm
@@ -577,7 +577,7 @@ def test_skinny_gemm_split_k_across_workgroups(gpu, M, dt):
 
 @pytest.mark.parametrize("stream16", [True, False])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M", [1, 8, 13, 32])
+@pytest.mark.parametrize("M", [1, 8, 13, 20, 32])
 def test_skinny_gemm_lora_down_from_partial_sums(gpu, M, dt, stream16):
     """tcavt_gemm_args.lora_part (decode step): the down-projection GEMM's workgroups leave the partial dot products of their
     16 columns of the rounded residual stream with the next layer's adapter rows, and the q|k|v GEMM adds them up in place of
