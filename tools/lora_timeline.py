@@ -59,6 +59,9 @@ def main(path):
         busy = union_ms(other) * 1000 if other else 0.0
         print(f"  gap {gaps[i]:7.1f} us at +{(a['e'] - t0) / 1e6:6.2f} ms  after {short(a)}  before {short(b)}  "
               f"(other queues: {len(other)} kernels, {busy:.0f} us busy)")
+        if gaps[i] > 400:  # what the other queues run inside the big gaps
+            for r in sorted(other, key=lambda r: r["s"]):
+                print(f"        q{r['Queue_Id']} +{(r['s'] - a['e']) / 1e3:7.1f} us  {(r['e'] - r['s']) / 1e3:6.1f} us  {short(r)}")
 
 
 if __name__ == "__main__":
