@@ -630,6 +630,88 @@ typedef struct tcavt_llama_stack_args {
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * The LoRA-trainable variant's decoder backward as ONE call (modify_scripts/modify_train.py:512-528: lora_A / lora_B of
+ * q_proj, v_proj trainable, every base weight frozen; what loss.backward() does between the final hidden states and the
+ * adapters' .grad, and -- input_grad -- the decoder's input embeddings).  Per layer, last to first:
+ *   dgrad of down_proj with d(silu(gate) * up) in its epilogue (TCAVT_EPI_SILU_BWD, in place on the taped pre-activations)
+ *   -> dgrad of gate|up -> RMSNorm backward (post-attention norm; accumulates into the fp32 residual gradient g_h)
+ *   -> dgrad of o_proj -> attention backward (tcavt_attn_bwd_resident) -> g_t = s * g_qkv . B_ext
+ *   -> [leaf stream] adapter weight gradients (tcavt_lora_wgrad_a, row-scaled tcavt_wgrad_tn), written into the caller's
+ *      gradient tensors times scale[1]
+ *   -> adapters' input gradient (tcavt_lora_dgrad) -> dgrad of q|k|v -> RMSNorm backward (input norm).
+ * Requires the forward's tape with 16-bit streams, tape_att / tape_lse / tape_part (tcavt_llama_layer), L <= 256,
+ * 16 % (nq / nkv) == 0, M % 256 == 0, I % 256 == 0, H % 128 == 0, adapters of rank <= 16.  fp16 (dtype16 = TCAVT_F16): the incoming gradients g_final_a / b
+ * are bf16 and the walk runs under the power-of-two scale picked here (tcavt_grad_scale_pick into scale[0..1]); bf16: they are
+ * bf16 as well and scale must hold {1, 1}.  No allocation, no synchronisation; the leaf work is ordered against the main
+ * stream with the caller's events.  Weights: transposes of the forward's (dgrad operands, 16-bit): W^T stored [in][out].
+ * ---------------------------------------------------------------------- */
+typedef struct tcavt_llama_bwd_layer {
+  const void* w_dT;    /* [I][H]:   down_proj.weight^T */
+  const void* w_guT;   /* [H][2 I]: gate|up (interleaved rows of the forward's w_gu, post-attention gain folded in) transposed */
+  const void* w_oT;    /* [nq * 64][H] */
+  const void* w_qkvT;  /* [H][(nq + 2 nkv) * 64], input gain folded in */
+  const void* b_extT;  /* [64][(nq + 2 nkv) * 64]: B_ext^T */
+  const void* a_qT;    /* [H][64]: plain A_q^T in columns [0, r), zeros elsewhere */
+  const void* a_vT;    /* [H][64]: plain A_v^T in columns [16, 16 + r) */
+  const float* g1;     /* fp32 [H]: input_layernorm.weight */
+  const float* g2;     /* fp32 [H]: post_attention_layernorm.weight */
+  /* the forward's tape of this layer (tcavt_llama_layer.tape_*; h_in = the previous layer's tape_h_out, or the fused embeddings) */
+  const void* h_in;    /* 16-bit [M][H] */
+  const void* h_mid;   /* 16-bit [M][H] */
+  const void* qkv;     /* 16-bit [M + 64][(nq + 2 nkv) * 64] */
+  void* gu;            /* 16-bit [M][2 I]: overwritten with d(gate|up) */
+  const void* att;     /* 16-bit [M][nq * 64] */
+  const float* lse;    /* fp32 [B][nq][L] */
+  const float* part;   /* fp32 [M][npart] */
+  const void* t;       /* 16-bit [M][64] */
+  /* outputs: the adapters' gradients, fp32, OVERWRITTEN: lora_A [r][H] (leading dimension H), lora_B [out][r] (leading dimension r) */
+  float* g_Aq;
+  float* g_Av;
+  float* g_Bq;
+  float* g_Bv;
+} tcavt_llama_bwd_layer;
+
+typedef struct tcavt_llama_backward_args {
+  const tcavt_llama_bwd_layer* layers; /* HOST array of n_layers entries */
+  const void* h_last;                  /* 16-bit [M][H]: the last layer's tape_h_out (input of the final norm) */
+  const float* gamma_final;            /* fp32 [H] */
+  const void* g_final_a;               /* bf16 / 16-bit [M][H]: gradient of the post-final-norm hidden states */
+  const void* g_final_b;               /* optional second summand of it */
+  const float* rope_cos;               /* fp32 [L][32] */
+  const float* rope_sin;
+  const int32_t* kv_len;               /* int32 [B] */
+  float* scale;                        /* fp32 [2] */
+  uint32_t* scale_scratch;             /* one uint32, zero-initialised once */
+  /* scratch, caller-owned */
+  float* g_h;                          /* fp32 [M][H]: the residual gradient; on return dL/d(input embeddings) * scale[0] if input_grad */
+  void* g_hb;                          /* 16-bit [M][H] */
+  void* g_xn;                          /* 16-bit [M][H] */
+  void* g_xl;                          /* 16-bit [M][H] */
+  void* g_att;                         /* 16-bit [M][nq * 64] */
+  void* g_qkv0;                        /* 16-bit [M][(nq + 2 nkv) * 64] each (layer parity) */
+  void* g_qkv1;
+  void* g_t0;                          /* 16-bit [M][64] each */
+  void* g_t1;
+  float* dA;                           /* fp32 [64][H] */
+  float* dB;                           /* fp32 [(nq + 2 nkv) * 64][64] */
+  float* stats;                        /* fp32 [B * nq * L][4] */
+  /* leaf work: a second stream and four events (hipEvent_t: ready[0..1], done[0..1]); leaf_stream == NULL: on `stream` itself */
+  tcavt_stream_t leaf_stream;
+  void* const* events;
+  int32_t n_layers, B, L, H, I, nq, nkv, dtype16;
+  int32_t npart;                       /* partials per row in `part` */
+  int32_t lora_rank;
+  int32_t input_grad;                  /* != 0: also walk through layer 0's projections (g_h then holds the input gradient) */
+  int32_t reserved0;
+  float rms_eps, lora_scale;
+  float lora_dropout_p;                /* > 0: the forward's masks, sites lora_first_site + 2 l (q_proj), + 2 l + 1 (v_proj) */
+  uint32_t lora_first_site;
+  uint64_t dropout_seed;
+} tcavt_llama_backward_args;
+
+int tcavt_llama_stack_backward(const tcavt_llama_backward_args* args, tcavt_stream_t stream);
+
 /* Backward of tcavt_lora_down w.r.t. its input, both adapters and their masks in one pass (LoRA-trainable variant,
  * modify_scripts/modify_train.py:512-528):
  *   out[m][n] = mask_q[m][n] * sum_r g_t[m][r] A_q[r][n]  +  mask_v[m][n] * sum_r g_t[m][16 + r] A_v[r][n]

@@ -45,6 +45,8 @@ def _struct_fields(name):
 
 @pytest.mark.parametrize("cname,mirror", [("tcavt_gemm_args", "GemmArgs"), ("tcavt_llama_layer", "LlamaLayer"),
                                           ("tcavt_llama_stack_args", "LlamaStackArgs"),
+                                          ("tcavt_llama_bwd_layer", "LlamaBwdLayer"),
+                                          ("tcavt_llama_backward_args", "LlamaBackwardArgs"),
                                           ("tcavt_sample_params", "SampleParams"), ("tcavt_decode_args", "DecodeArgs"),
                                           ("tcavt_tlayer", "TLayer"), ("tcavt_tstack_args", "TStackArgs"),
                                           ("tcavt_cross_attn_args", "CrossAttnArgs"), ("tcavt_ltsf_args", "LtsfArgs"),

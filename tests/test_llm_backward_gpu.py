@@ -729,3 +729,50 @@ def test_lora_wgrad_a_one_pass_matches_the_composed_leaf(gpu, drop, dt, small_rm
     dB0 = torch.zeros(nqkv, 64, device=dev)
     ops.wgrad_tn(t_re, 0, 32, g_qkv, dB0, trans_out=True)
     assert rel_err(dB1[:, :32].cpu(), dB0[:, :32].cpu()) < 3 * tol
+
+
+@pytest.mark.parametrize("train_mode,front", [(True, False), (False, True)])
+def test_stage_level_decoder_backward_matches_the_python_composition(gpu, monkeypatch, train_mode, front):
+    """tcavt_llama_stack_backward (the whole walk through the frozen layers as one C call: dgrad GEMMs, norm / attention /
+    adapter kernels, the leaf stream's weight gradients) against the per-launch Python composition of the same entry points
+    (TCAVT_PY_LLM_BACKWARD=1), at a shape the fused forms serve (midi: H = 512, I = 1536, 8 / 2 heads, B = 2, L = 256), with the
+    forward's LoRA dropout masks (train mode) and with the input gradient continuing into the Q-Former (front)."""
+    from tcavt_amd import config, model, synth, training
+    from tcavt_amd.weights import make_weights
+
+    dev = gpu["device"]
+    cfg = config.midi()
+    with torch.device(dev):
+        m = model.MultiModalTrajectoryModel.from_config(cfg)
+    m.load_weights(make_weights(cfg, seed=5, backend="torch", device=dev))
+    m.train(train_mode)
+    b = synth.make_batch(cfg, 2, text_len=240, seed=21, ragged=True, min_text=100)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+    keys = ["traj_emb", "vision_emb", "lane_polygon", "lane_polygon_len", "target_traj", "norm_stat", "input_ids", "attention_mask", "labels"]
+    tr = training.Trainer(m, lr=1e-4, lora_trainable=True, train_mllm_front=front)
+    calls = []
+    real = tr.lbw._stage_call
+    monkeypatch.setattr(tr.lbw, "_stage_call", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def grads():
+        m._fwd_count = 0  # (the same dropout masks in both runs)
+        tr.forward_backward(*[g[k] for k in keys])
+        torch.cuda.synchronize()
+        return tr.book.grads.detach().clone()
+
+    g_c = grads()
+    assert calls, "the stage call must serve this shape"
+    monkeypatch.setenv("TCAVT_PY_LLM_BACKWARD", "1")
+    n = len(calls)
+    g_py = grads()
+    assert len(calls) == n
+    assert torch.isfinite(g_c).all()
+    lora = [nm for nm in tr.book.names if ".lora_" in nm]
+    assert len(lora) == 4 * cfg.llama.layers
+    for nm in tr.book.names:
+        o, cnt, _ = tr.book.offsets[nm]
+        a_, b_ = g_c[o:o + cnt], g_py[o:o + cnt]
+        if b_.abs().max() == 0:
+            assert a_.abs().max() == 0, nm
+            continue
+        assert rel_err(a_.cpu(), b_.cpu()) < 2e-4, nm  # (atomics' summation order in the weight gradients)

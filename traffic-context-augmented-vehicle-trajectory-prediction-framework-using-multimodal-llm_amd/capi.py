@@ -166,6 +166,32 @@ class LlamaStackArgs(ctypes.Structure):
     ]
 
 
+class LlamaBwdLayer(ctypes.Structure):
+    """Mirror of ``tcavt_llama_bwd_layer`` (include/tcavt.h)."""
+
+    _fields_ = [(n, c_void_p) for n in ("w_dT", "w_guT", "w_oT", "w_qkvT", "b_extT", "a_qT", "a_vT", "g1", "g2", "h_in", "h_mid",
+                                        "qkv", "gu", "att", "lse", "part", "t", "g_Aq", "g_Av", "g_Bq", "g_Bv")]
+
+
+class LlamaBackwardArgs(ctypes.Structure):
+    """Mirror of ``tcavt_llama_backward_args`` (include/tcavt.h)."""
+
+    _fields_ = [
+        ("layers", ctypes.POINTER(LlamaBwdLayer)),
+        ("h_last", c_void_p), ("gamma_final", c_void_p), ("g_final_a", c_void_p), ("g_final_b", c_void_p),
+        ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("kv_len", c_void_p), ("scale", c_void_p), ("scale_scratch", c_void_p),
+        ("g_h", c_void_p), ("g_hb", c_void_p), ("g_xn", c_void_p), ("g_xl", c_void_p), ("g_att", c_void_p),
+        ("g_qkv0", c_void_p), ("g_qkv1", c_void_p), ("g_t0", c_void_p), ("g_t1", c_void_p),
+        ("dA", c_void_p), ("dB", c_void_p), ("stats", c_void_p),
+        ("leaf_stream", c_void_p), ("events", ctypes.POINTER(c_void_p)),
+        ("n_layers", ctypes.c_int32), ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("I", ctypes.c_int32), ("nq", ctypes.c_int32), ("nkv", ctypes.c_int32), ("dtype16", ctypes.c_int32),
+        ("npart", ctypes.c_int32), ("lora_rank", ctypes.c_int32), ("input_grad", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
+        ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
+    ]
+
+
 class SampleParams(ctypes.Structure):
     """Mirror of ``tcavt_sample_params`` (include/tcavt.h)."""
 
@@ -285,6 +311,7 @@ _SIGNATURES = {
     "tcavt_ltsf_backward": [ctypes.POINTER(LtsfBwdArgs), c_int, c_void_p],
     "tcavt_tlayer_stack_backward": [ctypes.POINTER(TStackBwdArgs), c_void_p],
     "tcavt_rmsnorm16": [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "tcavt_llama_stack_backward": [ctypes.POINTER(LlamaBackwardArgs), c_void_p],
     "tcavt_events_create": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_events_destroy": [ctypes.POINTER(c_void_p), c_int],
     "tcavt_event_elapsed_ms": [c_void_p, c_void_p, ctypes.POINTER(c_float)],

@@ -1507,6 +1507,15 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
   }
 }
 
+// dst[i][j] = src[i][j] * (*scale): the adapters' gradients leave the scratch (and the backward's scale) for the caller's tensors
+__global__ __launch_bounds__(256) void scale_copy2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd,
+                                                           int rows, int cols, const float* __restrict__ scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const int i = (int)(idx / cols), j = (int)(idx - (long)i * cols);
+  dst[(long)i * ldd + j] = src[(long)i * lds_ + j] * (scale ? *scale : 1.f);
+}
+
 // ---------------------------------------------------------------------------
 // Power-of-two scale of the fp16 backward: S = 2^k with  max|g| * S  in [target / 2, target]  (g = the 16-bit gradient(s) the
 // backward starts from; bf16, so they cannot overflow themselves).  The backward is linear in g: every 16-bit gradient
@@ -1782,6 +1791,112 @@ extern "C" int tcavt_attn_bwd_resident(const void* qkv16, const void* dO16, cons
 
 extern "C" int tcavt_attn_bwd_resident_ok(int T, int nq, int nkv) {
   return T > 0 && T <= 256 && nkv > 0 && nq % nkv == 0 && ABQ_WAVES % (nq / nkv) == 0;
+}
+
+#define TCAVT_TRY(call)            \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != TCAVT_OK) return rc_; \
+  } while (0)
+
+extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(a && a->layers && a->h_last && a->gamma_final && a->g_final_a && a->rope_cos && a->rope_sin && a->kv_len && a->scale &&
+                      a->scale_scratch && a->g_h && a->g_hb && a->g_xn && a->g_xl && a->g_att && a->g_qkv0 && a->g_qkv1 && a->g_t0 &&
+                      a->g_t1 && a->dA && a->dB && a->stats,
+                  "llama_stack_backward: null pointer");
+  const int B = a->B, L = a->L, H = a->H, I = a->I, nq = a->nq, nkv = a->nkv, dt = a->dtype16, r = a->lora_rank;
+  TCAVT_CHECK_ARG(a->n_layers > 0 && B > 0 && L > 0 && is16(dt) && nkv > 0 && nq % nkv == 0 && r > 0 && r <= 16 && a->npart > 0,
+                  "llama_stack_backward: bad shape");
+  const int M = B * L, nqkv = (nq + 2 * nkv) * 64;
+  TCAVT_CHECK_ARG(tcavt_attn_bwd_resident_ok(L, nq, nkv) && M % 256 == 0 && I % 256 == 0 && H % 128 == 0,
+                  "llama_stack_backward: outside the fused forms (L <= 256, 16 %% (nq / nkv) == 0, M %% 256 == 0, I %% 256 == 0, H %% 128 == 0)");
+  TCAVT_CHECK_ARG(!a->leaf_stream || a->events, "llama_stack_backward: a leaf stream needs the four events");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipStream_t lf = a->leaf_stream ? static_cast<hipStream_t>(a->leaf_stream) : st;
+  const bool two = lf != st;
+  const bool f16 = dt == TCAVT_F16;
+  const int gdt = f16 ? TCAVT_BF16 : dt;  // type of the incoming gradients
+  if (f16) TCAVT_TRY(tcavt_grad_scale_pick(a->g_final_a, a->g_final_b, (int64_t)M * H, TCAVT_BF16, 256.f, a->scale, a->scale_scratch, stream));
+  const float* inv_s = a->scale + 1;
+  // final norm: g_h = d(rmsnorm)(h_last) . (g_final_a + g_final_b) * S,  g_hb = its 16-bit copy
+  TCAVT_TRY(tcavt_rmsnorm_bwd(a->h_last, a->gamma_final, a->g_final_a, a->g_final_b, a->rms_eps, a->g_h, a->g_hb, 0, M, H, gdt, dt,
+                              f16 ? a->scale : nullptr, dt, stream));
+  auto gemm = [&](const void* A, int lda, const void* W, int K, void* C, int N, float acc_scale) -> int {
+    tcavt_gemm_args g = {};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = acc_scale;
+    return tcavt_gemm_bf16(&g, stream);
+  };
+  auto hip_ok = [&](hipError_t rc, const char* what) -> int {
+    if (rc == hipSuccess) return TCAVT_OK;
+    set_error("llama_stack_backward: %s: %s", what, hipGetErrorString(rc));
+    return TCAVT_ERR_HIP;
+  };
+  bool leaf_used[2] = {false, false};
+  void* const g_qkv2[2] = {a->g_qkv0, a->g_qkv1};
+  void* const g_t2[2] = {a->g_t0, a->g_t1};
+  for (int li = a->n_layers - 1; li >= 0; --li) {
+    const tcavt_llama_bwd_layer& w = a->layers[li];
+    TCAVT_CHECK_ARG(w.w_dT && w.w_guT && w.w_oT && w.w_qkvT && w.b_extT && w.a_qT && w.a_vT && w.g1 && w.g2 && w.h_in && w.h_mid && w.qkv &&
+                        w.gu && w.att && w.lse && w.part && w.t && w.g_Aq && w.g_Av && w.g_Bq && w.g_Bv,
+                    "llama_stack_backward: layer %d: null pointer", li);
+    // ---- MLP half
+    {
+      tcavt_gemm_args g = {};
+      g.A = a->g_hb; g.lda = H; g.W = w.w_dT; g.ldw = H; g.C = w.gu; g.ldc = 2 * I; g.M = M; g.N = I; g.K = H;
+      g.out_dtype = dt; g.in_dtype = dt; g.silu_preact = w.gu; g.ld_preact = 2 * I; g.epilogue = TCAVT_EPI_SILU_BWD;
+      TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
+    }
+    TCAVT_TRY(gemm(w.gu, 2 * I, w.w_guT, 2 * I, a->g_xn, H, 0.f));
+    TCAVT_TRY(tcavt_rmsnorm_bwd(w.h_mid, w.g2, a->g_xn, nullptr, a->rms_eps, a->g_h, a->g_hb, 1, M, H, dt, dt, nullptr, dt, stream));
+    // ---- attention half
+    TCAVT_TRY(gemm(a->g_hb, H, w.w_oT, H, a->g_att, nq * 64, 0.f));
+    const int par = li & 1;
+    if (two && leaf_used[par])  // the leaf of layer li + 2 has read g_qkv / g_t of this parity
+      TCAVT_TRY(hip_ok(hipStreamWaitEvent(st, static_cast<hipEvent_t>(a->events[2 + par]), 0), "wait(done)"));
+    TCAVT_TRY(tcavt_attn_bwd_resident(w.qkv, a->g_att, w.att, w.lse, g_qkv2[par], a->stats, a->rope_cos, a->rope_sin, a->kv_len, B, L,
+                                      nq, nkv, 64, 0.125f, dt, stream));
+    TCAVT_TRY(gemm(g_qkv2[par], nqkv, w.b_extT, nqkv, g_t2[par], 64, a->lora_scale));
+    // ---- leaf: the adapters' weight gradients (nothing downstream reads them)
+    if (two) {
+      TCAVT_TRY(hip_ok(hipEventRecord(static_cast<hipEvent_t>(a->events[par]), st), "record(ready)"));
+      TCAVT_TRY(hip_ok(hipStreamWaitEvent(lf, static_cast<hipEvent_t>(a->events[par]), 0), "wait(ready)"));
+    }
+    {
+      const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
+      TCAVT_TRY(hip_ok(hipMemsetAsync(a->dA, 0, (size_t)64 * H * sizeof(float), lf), "memset(dA)"));
+      TCAVT_TRY(hip_ok(hipMemsetAsync(a->dB, 0, (size_t)nqkv * 64 * sizeof(float), lf), "memset(dB)"));
+      TCAVT_TRY(tcavt_lora_wgrad_a(w.h_in, w.part, a->npart, a->rms_eps, w.g1, g_t2[par], a->dA, H, M, H, a->lora_dropout_p,
+                                   a->dropout_seed, site, site + 1, dt, lf));
+      TCAVT_TRY(tcavt_wgrad_tn(w.t, 64, 0, 32, g_qkv2[par], nqkv, dt, a->dB, 64, M, nqkv, 1, dt, w.part, a->npart, H, a->rms_eps, lf));
+      struct Cp { const float* src; long lds_; float* dst; long ldd; int rows, cols; };
+      const Cp cps[4] = {{a->dA, H, w.g_Aq, H, r, H},
+                         {a->dA + (long)16 * H, H, w.g_Av, H, r, H},
+                         {a->dB, 64, w.g_Bq, r, nq * 64, r},
+                         {a->dB + (long)(nq + nkv) * 64 * 64 + 16, 64, w.g_Bv, r, nkv * 64, r}};
+      for (const Cp& c : cps) {
+        const long n = (long)c.rows * c.cols;
+        hipLaunchKernelGGL(scale_copy2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lf, c.src, c.lds_, c.dst, c.ldd, c.rows,
+                           c.cols, f16 ? inv_s : nullptr);
+      }
+      TCAVT_CHECK_LAUNCH("llama_stack_backward(adapter gradients)");
+    }
+    if (two) {
+      TCAVT_TRY(hip_ok(hipEventRecord(static_cast<hipEvent_t>(a->events[2 + par]), lf), "record(done)"));
+      leaf_used[par] = true;
+    }
+    if (li == 0 && !a->input_grad) break;
+    {
+      const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
+      TCAVT_TRY(tcavt_lora_dgrad(g_t2[par], w.a_qT, w.a_vT, a->g_xl, M, H, a->lora_dropout_p, a->dropout_seed, site, site + 1, dt, stream));
+    }
+    TCAVT_TRY(gemm(g_qkv2[par], nqkv, w.w_qkvT, nqkv, a->g_xn, H, 0.f));
+    TCAVT_TRY(tcavt_rmsnorm_bwd(w.h_in, w.g1, a->g_xn, a->g_xl, a->rms_eps, a->g_h, a->g_hb, 1, M, H, dt, dt, nullptr, dt, stream));
+  }
+  if (two)
+    for (int par = 0; par < 2; ++par)
+      if (leaf_used[par]) TCAVT_TRY(hip_ok(hipStreamWaitEvent(st, static_cast<hipEvent_t>(a->events[2 + par]), 0), "join(leaf)"));
+  return TCAVT_OK;
 }
 
 extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float grad_scale, float* scratch,

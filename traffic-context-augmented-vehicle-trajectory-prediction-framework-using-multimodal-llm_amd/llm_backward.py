@@ -19,12 +19,13 @@ pre-activations come from the forward (its SiLU epilogue writes a 16-bit copy in
 normed rows feeding the adapters are recomputed.
 Layer 0's input gradient is not formed: nothing below it is trainable.
 """
+import ctypes
 import math
 import os
 
 import torch
 
-from . import ops, streams
+from . import capi, ops, streams
 from .model import LORA_V
 
 
@@ -123,6 +124,59 @@ class LoraBackward:
         dtype = self.lw.storage if dtype is None else dtype
         return self.ws.get(f"llbw.{name}.{str(dtype)[6:]}", shape, dtype, self.book.grads.device, zero=zero)
 
+    def _stage_call_ok(self, tape, st, B, L, M, H, I, nq, nkv, r, fuse_silu, dev):
+        """Shapes / tapes the C++ stage call serves (everything the fp16-contract product path produces at L <= 256)."""
+        if dev.type != "cuda" or os.environ.get("TCAVT_PY_LLM_BACKWARD", "0") == "1" or not fuse_silu or H % 128 or r > 16:
+            return False
+        if any(os.environ.get(k) for k in ("TCAVT_ATTN_BWD_TWO_SWEEPS", "TCAVT_ATTN_BWD_NO_RESIDENT", "TCAVT_LORA_LEAF_UNFUSED")):
+            return False  # (A/B switches of the Python composition)
+        if not ops.attn_bwd_resident_ok(L, nq, nkv) or st not in (torch.float16, torch.bfloat16):
+            return False
+        return all(sv.h_in.dtype == st and getattr(sv, "lse", None) is not None and getattr(sv, "part", None) is not None
+                   and sv.t is not None for sv in tape.layers)
+
+    def _stage_call(self, tape, P, PT, g_final_a, g_final_b, scale, leaf, cos, sin, st, B, L, H, I, nq, nkv, r, s, eps, pre, buf):
+        lw, G = self.lw, self.book.g
+        nL = len(tape.layers)
+        arr = (capi.LlamaBwdLayer * nL)()
+        for li in range(nL):
+            d, dT, sv, c = P.layers[li], PT[li], tape.layers[li], arr[li]
+            c.w_dT, c.w_guT, c.w_oT, c.w_qkvT = dT.w_d.data_ptr(), dT.w_gu.data_ptr(), dT.w_o.data_ptr(), dT.w_qkv.data_ptr()
+            c.b_extT, c.a_qT, c.a_vT = dT.b_ext.data_ptr(), dT.a_q.data_ptr(), dT.a_v.data_ptr()
+            c.g1, c.g2 = d.g1.data_ptr(), d.g2.data_ptr()
+            c.h_in, c.h_mid, c.qkv, c.gu = sv.h_in.data_ptr(), sv.h_mid.data_ptr(), sv.qkv_padded.data_ptr(), sv.gu.data_ptr()
+            c.att, c.lse, c.part, c.t = sv.att.data_ptr(), sv.lse.data_ptr(), sv.part.data_ptr(), sv.t.data_ptr()
+            p = f"{pre}{li}.self_attn."
+            outs = [G[p + n] for n in ("q_proj.lora_A.weight", "v_proj.lora_A.weight", "q_proj.lora_B.weight", "v_proj.lora_B.weight")]
+            if any(not o.is_contiguous() or o.dtype != torch.float32 for o in outs):
+                raise capi.TcavtError("LoraBackward: the adapters' gradient tensors must be contiguous fp32")
+            c.g_Aq, c.g_Av, c.g_Bq, c.g_Bv = (o.data_ptr() for o in outs)
+        a = capi.LlamaBackwardArgs()
+        a.layers = arr
+        a.h_last, a.gamma_final = tape.h_last.data_ptr(), P.g_final.data_ptr()
+        a.g_final_a, a.g_final_b = g_final_a.data_ptr(), None if g_final_b is None else g_final_b.data_ptr()
+        a.rope_cos, a.rope_sin, a.kv_len = cos.data_ptr(), sin.data_ptr(), tape.kv_len.data_ptr()
+        if st != torch.float16:
+            scale.copy_(torch.ones(2, device=scale.device))
+        a.scale, a.scale_scratch = scale.data_ptr(), self._buf("scale_scratch", (1,), torch.int32, zero=True).data_ptr()
+        for k in ("g_h", "g_hb", "g_xn", "g_xl", "g_att", "dA", "dB"):
+            setattr(a, k, buf[k].data_ptr())
+        a.g_qkv0, a.g_qkv1, a.g_t0, a.g_t1 = buf["g_qkv"][0].data_ptr(), buf["g_qkv"][1].data_ptr(), buf["g_t"][0].data_ptr(), buf["g_t"][1].data_ptr()
+        a.stats = self._buf("at.stats", (B * nq * L, 4), torch.float32).data_ptr()
+        if leaf is not None:
+            if getattr(self, "_ev", None) is None:
+                self._ev = (ctypes.c_void_p * 4)()
+                capi.check(capi.lib().tcavt_events_create(self._ev, 4), "tcavt_events_create")
+            a.leaf_stream, a.events = leaf.cuda_stream, self._ev
+        a.n_layers, a.B, a.L, a.H, a.I, a.nq, a.nkv = nL, B, L, H, I, nq, nkv
+        a.dtype16, a.npart, a.lora_rank, a.input_grad = ops._DT[st], tape.layers[0].part.shape[1], r, int(self.input_grad)
+        a.rms_eps, a.lora_scale = eps, s
+        dspec = tape.layers[0].dspec
+        if dspec is not None:  # ((p, seed, site_q), (p, seed, site_v)) of layer 0: sites advance by two per layer
+            a.lora_dropout_p, a.dropout_seed, a.lora_first_site = dspec[0][0], dspec[0][1] & 0xFFFFFFFFFFFFFFFF, dspec[0][2]
+        capi.check(capi.lib().tcavt_llama_stack_backward(ctypes.byref(a), capi.stream_ptr()), "tcavt_llama_stack_backward")
+        self._keep = (arr, a)
+
     def run(self, g_final_a, g_final_b=None):
         """g_final_a (+ g_final_b): 16-bit [B*L, H] gradient of the post-final-norm hidden states (bf16 when the model's
         storage is fp16: they are what the backward's scale is picked from and must not overflow themselves).  Returns the
@@ -155,7 +209,6 @@ class LoraBackward:
         if scaled:
             if g_final_a.dtype != torch.bfloat16 or (g_final_b is not None and g_final_b.dtype != torch.bfloat16):
                 raise ValueError("LoraBackward.run: with fp16 storage the incoming gradient(s) must be bf16 (range)")
-            ops.grad_scale_pick(g_final_a, g_final_b, scale, self._buf("scale_scratch", (1,), torch.int32, zero=True))
         elif g_final_a.dtype != st:
             raise ValueError("LoraBackward.run: the incoming gradient must have the model's 16-bit storage type")
         inv_s = scale[1:2]
@@ -182,6 +235,15 @@ class LoraBackward:
         dA = self._buf("dA", (64, H), torch.float32)
         dB = self._buf("dB", (nqkv, 64), torch.float32)
 
+        if self._stage_call_ok(tape, st, B, L, M, H, I, nq, nkv, r, fuse_silu, dev):
+            # the whole walk as ONE C call (tcavt_llama_stack_backward: the loop below, issued from C++)
+            self._stage_call(tape, P, PT, g_final_a, g_final_b, scale, leaf, cos, sin, st, B, L, H, I, nq, nkv, r, s, eps, pre,
+                             dict(g_h=g_h, g_hb=g_hb, g_xn=g_xn, g_xl=g_xl, g_att=g_att, g_qkv=g_qkv2, g_t=g_t2, dA=dA, dB=dB))
+            if self.input_grad and scaled:
+                g_h.mul_(inv_s)
+            return g_h if self.input_grad else None
+        if scaled:
+            ops.grad_scale_pick(g_final_a, g_final_b, scale, self._buf("scale_scratch", (1,), torch.int32, zero=True))
         ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b, gx_bf16=g_hb,
                         gy_scale=scale[0:1] if scaled else None)
         for li in reversed(range(ll.layers)):
