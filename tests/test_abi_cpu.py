@@ -86,6 +86,22 @@ def test_argument_errors_are_reported_not_crashed():
     args.M, args.N, args.K = 8, 16, 60
     rc = capi.lib().tcavt_gemm_bf16(ctypes.byref(args), None)
     assert rc == 1 and b"multiple of 64" in capi.lib().tcavt_last_error()
+    # round-3 stage entries: shapes outside the resident forms and missing pointers are refused, not launched
+    assert capi.lib().tcavt_attn_bwd_resident_ok(256, 32, 8) == 1 and capi.lib().tcavt_attn_bwd_resident_ok(257, 32, 8) == 0
+    assert capi.lib().tcavt_attn_bwd_resident_ok(256, 12, 4) == 0  # (16 % 3 != 0)
+    rc = capi.lib().tcavt_attn_bwd_resident(64, 64, 64, 64, 64, 64, 64, 64, 64, 1, 300, 4, 1, 64, 0.125, capi.F16, None)
+    assert rc == 1 and b"outside the resident form" in capi.lib().tcavt_last_error()
+    bargs = capi.LlamaBackwardArgs()
+    rc = capi.lib().tcavt_llama_stack_backward(ctypes.byref(bargs), None)
+    assert rc == 1 and b"null" in capi.lib().tcavt_last_error()
+    # the decode step's LoRA partial sums belong to the skinny form (M <= 32)
+    args = capi.GemmArgs()
+    args.A = args.W = args.C = args.lora_part = 64
+    args.M, args.N, args.K = 64, 128, 256
+    args.lda = args.ldw = 256
+    args.ldc = 128
+    rc = capi.lib().tcavt_gemm_bf16(ctypes.byref(args), None)
+    assert rc == 1 and b"skinny form" in capi.lib().tcavt_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch):
