@@ -1869,6 +1869,31 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   }
   constexpr bool NORMF = EPI == EPI_NORM || EPI == EPI_NORM16;
   u32x2 lp_af[NORMF ? NCB : 1][NORMF ? 16 : 1];  // producer: this lane's 4 columns of the 16 adapter rows
+  // fused LoRA down-projection, consumer side: t = lp_scale * sum of the lp_np partials the previous residual GEMM left --
+  // value (m, j) by thread m * 16 + j of group g, groups of lp_np / G consecutive partials (G = a power of two that divides
+  // lp_np), combined in group order (this workgroup's tokens: all M, or the 16-token block it owns when the token blocks
+  // are split, sk_msplit).  The first 32 partials of a thread are requested HERE, before the first weight batch (they are
+  // back before it; added up under it), the rest (M > 8) in the same place as before
+  float lp_tv[EPI == EPI_ROPE ? 32 : 1];
+  const float* lp_src = nullptr;
+  int lp_per = 0, lp_nall = 0;
+  if constexpr (EPI == EPI_ROPE) {
+    if (lp_in) {
+      const int mtok = p.sk_msplit > 1 ? min(16, p.M - mrow0) : p.M;
+      const int nv = mtok * 16;
+      lp_nall = p.M * 16;
+      int G = 1;
+      while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
+      const int tid = threadIdx.x;
+      if (tid < G * nv) {
+        const int g = tid / nv, v = tid - g * nv;
+        lp_per = p.lp_np / G;
+        lp_src = p.lp_part + (long)g * lp_per * lp_nall + mrow0 * 16 + v;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) lp_tv[u] = lp_src[(long)min(u, lp_per - 1) * lp_nall];
+      }
+    }
+  }
   for (int k = 0; k < kper; k += 32 * U) {
     u32x4 wf[U][NCB], x0[U], x1[U];
 #pragma unroll
@@ -1881,28 +1906,18 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       }
     }
     if constexpr (EPI == EPI_ROPE) {
-      if (k == 0 && lp_in) {
-        // t = lp_scale * sum of the lp_np partials the previous residual GEMM left: value (m, j) by thread m * 16 + j of
-        // group g, groups of lp_np / G consecutive partials (G = a power of two that divides lp_np), combined in group order
-        // (this workgroup's tokens: all M, or the 16-token block it owns when the token blocks are split, sk_msplit)
-        const int mtok = p.sk_msplit > 1 ? min(16, p.M - mrow0) : p.M;
-        const int nv = mtok * 16, nall = p.M * 16;
-        int G = 1;
-        while (2 * G * nv <= SK_WAVES * 64 && p.lp_np % (2 * G) == 0) G *= 2;
-        const int tid = threadIdx.x;
-        if (tid < G * nv) {
-          const int g = tid / nv, v = tid - g * nv, per = p.lp_np / G;
-          const float* src = p.lp_part + (long)g * per * nall + mrow0 * 16 + v;
-          float acc_t = 0.f;
-          for (int i = 0; i < per; i += 32) {  // (32 loads in flight: one round trip for M <= 8, lp_np = 128)
-            float tv[32];
+      if (k == 0 && lp_src) {
+        float acc_t = 0.f;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) tv[u] = src[(long)min(i + u, per - 1) * nall];
+        for (int u = 0; u < 32; ++u) acc_t += u < lp_per ? lp_tv[u] : 0.f;
+        for (int i = 32; i < lp_per; i += 32) {
+          float tv[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc_t += i + u < per ? tv[u] : 0.f;
-          }
-          lp_sum[tid] = acc_t;
+          for (int u = 0; u < 32; ++u) tv[u] = lp_src[(long)min(i + u, lp_per - 1) * lp_nall];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) acc_t += i + u < lp_per ? tv[u] : 0.f;
         }
+        lp_sum[threadIdx.x] = acc_t;
       }
     }
     if (k == 0 && wave < 2) {
