@@ -34,7 +34,7 @@ extern "C" {
 
 typedef void* tcavt_stream_t; /* hipStream_t */
 
-#define TCAVT_ABI_VERSION 3
+#define TCAVT_ABI_VERSION 4
 
 #define TCAVT_OK 0
 #define TCAVT_ERR_ARG 1  /* shape / alignment / null-pointer contract violated */
@@ -160,7 +160,14 @@ typedef struct tcavt_gemm_args {
   int32_t rowscale_npart;
   int32_t rowscale_h;
   float rowscale_eps;
-  int32_t reserved1;
+  /* TCAVT_EPI_NORM_OUT, optional (0 means 1): SCALED 16-bit image of the residual stream.  Every 16-bit image of the stream
+   * (the stream itself when C == NULL, its copy norm_h16 otherwise) holds norm_scale * x, and norm_part the sums of squares
+   * of those scaled values:  C == NULL: h16 <- round(norm_scale * acc + h16);  C != NULL: C = acc + residual (unscaled fp32),
+   * norm_h16 = round(norm_scale * C).  A power of two <= 1 costs no precision (fp16 is a floating-point format) and moves the
+   * overflow limit of the image from 65504 to 65504 / norm_scale -- what real checkpoints' outlier channels need.  RMSNorm is
+   * scale-invariant up to its eps: the consumers (TCAVT_EPI_ROWSCALE, tcavt_rmsnorm16) are given rowscale_eps = eps *
+   * norm_scale^2 and need nothing else.  (tcavt_llama_stack_args.stream_scale does all of this for a decoder pass.) */
+  float norm_scale;
   /* TCAVT_EPI_ROPE, optional: int32 [M] device array, the position of row m (a decode step has one row per sample, each
    * at its own position; cos / sin tables then hold rope_L >= max position + 1 rows).  NULL: position = m % rope_L */
   const int32_t* rope_pos;
@@ -257,7 +264,9 @@ int tcavt_cast_f32_16(const float* x, void* out16, int64_t n, int dtype16, tcavt
 int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                      const float* vis_mod, const float* txt_mod, float* h, int B,
                      int Nq, int Lt, int H, int V, int* bad_id_flag, int table_dtype,
-                     void* h16, float* part, int npart, tcavt_stream_t stream);
+                     void* h16, float* part, int npart, float stream_scale /* 0 means 1: h16 = round(stream_scale * h),
+                     part = sums of squares of the scaled values (tcavt_llama_stack_args.stream_scale); h stays unscaled */,
+                     tcavt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * attention_mask -> per-sample valid key count of the fused sequence
@@ -617,7 +626,13 @@ typedef struct tcavt_llama_stack_args {
   int32_t kv_lmax;
   int32_t gemm_tile;               /* tcavt_gemm_args.tile for the four big projections (0 = auto) */
   int32_t npart_in;                /* partials per row in `part` on entry: must equal tcavt_norm_npart(M, H, I) */
-  int32_t reserved0;
+  float stream_scale;              /* 0 means 1.  A power of two <= 1: h16 and `part` arrive holding stream_scale * x (tcavt_embed_fuse /
+                                      tcavt_rownorm_prep with the same value) and every 16-bit image of the residual stream is kept at
+                                      that scale (tcavt_gemm_args.norm_scale): the overflow limit of an fp16 stream moves from 65504 to
+                                      65504 / stream_scale at no cost in precision.  The fused norms run with eps * stream_scale^2; the adapters'
+                                      un-normalised t = lora_scale * (stream_scale x) . A^T has the stream's range and stays at its scale:
+                                      the caller's b_ext must hold lora_B / stream_scale.  out_f32 / out16 are the true-scale final hidden
+                                      states.  Not with a tape (the backward reads the streams at scale 1) */
   float rms_eps, lora_scale;       /* lora_scale = alpha / r */
   float lora_dropout_p;            /* > 0: train mode; sites first_site + 2 l (q_proj), first_site + 2 l + 1 (v_proj) */
   uint32_t lora_first_site;
@@ -641,10 +656,12 @@ int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t
  *      gradient tensors times scale[1]
  *   -> adapters' input gradient (tcavt_lora_dgrad) -> dgrad of q|k|v -> RMSNorm backward (input norm).
  * Requires the forward's tape with 16-bit streams, tape_att / tape_lse / tape_part (tcavt_llama_layer), L <= 256,
- * 16 % (nq / nkv) == 0, M % 256 == 0, I % 256 == 0, H % 128 == 0, adapters of rank <= 16.  fp16 (dtype16 = TCAVT_F16): the incoming gradients g_final_a / b
- * are bf16 and the walk runs under the power-of-two scale picked here (tcavt_grad_scale_pick into scale[0..1]); bf16: they are
- * bf16 as well and scale must hold {1, 1}.  No allocation, no synchronisation; the leaf work is ordered against the main
- * stream with the caller's events.  Weights: transposes of the forward's (dgrad operands, 16-bit): W^T stored [in][out].
+ * 16 % (nq / nkv) == 0, M % 256 == 0, I % 256 == 0, H % 128 == 0, adapters of rank <= 16, head_dim 64.  dtype16 must be
+ * TCAVT_F16 (16-bit stream tapes exist for fp16 storage only; anything else is refused): the incoming gradients g_final_a / b
+ * are bf16 and the walk runs under the power-of-two scale picked here (tcavt_grad_scale_pick into scale[0..1]).  Every layer's
+ * pointers are checked before the first launch; should a launch fail in the middle of the walk, the caller's stream still
+ * joins the leaf stream before the error is returned.  No allocation, no synchronisation; the leaf work is ordered against the
+ * main stream with the caller's events.  Weights: transposes of the forward's (dgrad operands, 16-bit): W^T stored [in][out].
  * ---------------------------------------------------------------------- */
 typedef struct tcavt_llama_bwd_layer {
   const void* w_dT;    /* [I][H]:   down_proj.weight^T */
@@ -952,8 +969,9 @@ int tcavt_norm_npart(int M, int N, int K);
 /* x16 = 16-bit copy of x fp32 [M][H], part[M][npart] = (sum of squares of the row, 0, 0, ...): the h16 / part inputs of
  * tcavt_llama_stack_forward for embeddings that do not come from tcavt_embed_fuse (HF-style inputs_embeds call) */
 /* rounded_sums != 0: the sums are those of the rounded 16-bit values (the 16-bit residual stream, h == NULL) */
+/* stream_scale (0 means 1): x16 = round(stream_scale * x), sums of the scaled values (tcavt_llama_stack_args.stream_scale) */
 int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16, int rounded_sums,
-                       tcavt_stream_t stream);
+                       float stream_scale, tcavt_stream_t stream);
 
 /* RMSNorm of 16-bit rows x16 [M][H] (fp32 arithmetic; H % 256 == 0): out16 and / or out_f32 -- the final norm of the
  * 16-bit residual stream (HF modeling_llama.py:62-67 on the stream's stored values) */
@@ -1020,7 +1038,7 @@ typedef struct tcavt_decode_args {
                                       previous layer's down-projection GEMM leaves here (tcavt_gemm_args.lora_part: one launch
                                       per layer less); adapters of rank <= 8 only (lora_rank), B <= 32, NULL = a launch per layer */
   int32_t lora_rank;
-  int32_t reserved3;
+  float stream_scale;              /* as tcavt_llama_stack_args.stream_scale (0 means 1) */
 } tcavt_decode_args;
 
 int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/tcavt.h but not exported"
     assert sorted(capi.EXPORTED_SYMBOLS) == declared, "capi.py binds a different symbol set than the header declares"
-    assert capi.lib().tcavt_abi_version() == capi.ABI_VERSION == 3
+    assert capi.lib().tcavt_abi_version() == capi.ABI_VERSION == 4
 
 
 def _struct_fields(name):

@@ -63,11 +63,19 @@ def _worker(rank, world, port, case, outdir):
         tr.enable_diagnostics(False)
         assert sum(b["bytes"] for b in d["buckets"]) == 4 * tr.book.total and all(b["launches"] == 1 and b["mean_ms"] >= 0 for b in d["buckets"])
         assert d["hip_streams_in_use"] <= 5, d  # the five-stream budget of the pipelined step
-        tr.exchange = False  # the same-build single-rank comparison leg: gradients stay local
-        tr.forward_backward(*[g[k] for k in ARGS])
+        before = tr.book.params.detach().clone()
+        with tr.local_steps():  # the same-build single-rank comparison leg: gradients stay local ...
+            tr.forward_backward(*[g[k] for k in ARGS])
+            torch.cuda.synchronize()
+            local = tr.book.grads.detach().clone().cpu()
+            tr.optimizer_step()  # ... the replicas drift apart ...
+            torch.cuda.synchronize()
+            drift = tr.book.params.detach().clone()
         torch.cuda.synchronize()
-        local = tr.book.grads.detach().clone().cpu()
-        tr.exchange = True
+        after = tr.book.params.detach().cpu()  # ... and are one state again on exit (rank 0's); (gloo gathers CPU tensors)
+        both = [torch.zeros_like(after) for _ in range(world)]
+        dist.all_gather(both, after)
+        assert all(torch.equal(b, both[0]) for b in both) and not torch.equal(drift, before)
         torch.save({"grads": grads, "params": params, "loss": loss, "diag": d, "local": local}, os.path.join(outdir, f"rank{rank}.pt"))
         dist.barrier()
     finally:

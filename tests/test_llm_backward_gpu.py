@@ -499,8 +499,22 @@ def test_full_modify_train_gradients_match_autograd(gpu, train_mode):
         cos = (got @ ref / (got.norm() * ref.norm())).item()
         print(f"[modify_train set, train_mode={train_mode}] {name}: rel {rel:.2e}, cosine {cos:.5f}")
         # fp16 (scaled) gradient chain through the decoder layers, bf16 through the Q-Former layers, vs fp32 autograd of the
-        # fp16-contract graph: 3 x the measured 9.6e-3 (eval arithmetic) / 3.1e-2 (train mode, same masks)
-        assert rel < (0.1 if train_mode else 3e-2) and cos > 0.999, (name, rel, cos)
+        # fp16-contract graph: 1.5 x the measured 9.6e-3 (eval arithmetic) / 3.1e-2 (train mode, same masks)
+        assert rel < (5e-2 if train_mode else 1.5e-2) and cos > 0.999, (name, rel, cos)
+        # ... and PER PARAMETER: inside a concatenated group a small tensor with a wrong mask site or a missing 1 / rms would
+        # hide behind the large ones (a wrong site decorrelates the gradient: cosine ~ 0.9 at p = 0.1; a missing factor shows in rel)
+        worst = (0.0, 1.0, None)
+        for k in ks:
+            r_, g_ = W[k].grad.reshape(-1).double(), tr.book.g[k].cpu().reshape(-1).double()
+            if r_.norm() == 0:
+                assert g_.norm() == 0, k
+                continue
+            rel_k = ((g_ - r_).norm() / r_.norm()).item()
+            cos_k = (g_ @ r_ / (g_.norm() * r_.norm())).item()
+            if rel_k > worst[0]:
+                worst = (rel_k, cos_k, k)
+            assert rel_k < (0.12 if train_mode else 4e-2) and cos_k > 0.993, (k, rel_k, cos_k)
+        print(f"    worst parameter: {worst[2]}: rel {worst[0]:.2e}, cosine {worst[1]:.5f}")
     w0 = m.mllm.qformer.query_tokens.detach().clone()
     tr.optimizer_step()
     l1, _ = tr.forward_backward(*args)

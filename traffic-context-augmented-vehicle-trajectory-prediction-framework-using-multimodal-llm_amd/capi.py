@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libtcavt_hip.so")
 if os.environ.get("TCAVT_LIB") == "exp":  # tools/ only: the -DTCAVT_EXPERIMENTS build (python -m tcavt_amd.build --experiments)
     LIB_PATH = os.path.join(_HERE, "libtcavt_hip_exp.so")
 
-ABI_VERSION = 3  # TCAVT_ABI_VERSION of include/tcavt.h
+ABI_VERSION = 4  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_NORM_OUT, EPI_ROWSCALE, EPI_SILU_BWD = 128, 256, 512
@@ -53,7 +53,7 @@ class GemmArgs(ctypes.Structure):
         ("silu_preact", c_void_p), ("ld_preact", c_int64),
         ("norm_h16", c_void_p), ("norm_part", c_void_p), ("rowscale_part", c_void_p),
         ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
-        ("reserved1", ctypes.c_int32),
+        ("norm_scale", ctypes.c_float),
         ("rope_pos", c_void_p),
         ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
         ("norm_res16", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
@@ -159,7 +159,7 @@ class LlamaStackArgs(ctypes.Structure):
         ("events", ctypes.POINTER(c_void_p)),
         ("n_layers", ctypes.c_int32), ("B", ctypes.c_int32), ("L", ctypes.c_int32), ("H", ctypes.c_int32),
         ("I", ctypes.c_int32), ("nq", ctypes.c_int32), ("nkv", ctypes.c_int32), ("dtype16", ctypes.c_int32),
-        ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32), ("npart_in", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32), ("npart_in", ctypes.c_int32), ("stream_scale", ctypes.c_float),
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
         ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
         ("nonfinite_flag", c_void_p),
@@ -208,7 +208,7 @@ class DecodeArgs(ctypes.Structure):
         "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
         ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p),
-        ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("reserved3", c_int)]
+        ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("stream_scale", ctypes.c_float)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)
@@ -222,7 +222,7 @@ _SIGNATURES = {
     "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_cast_f32_16": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                         c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
+                         c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p],
     "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,
                            ctypes.c_uint32, c_void_p],
     "tcavt_set_dropout_epoch": [c_void_p],
@@ -302,7 +302,7 @@ _SIGNATURES = {
     "tcavt_norm_npart": [c_int, c_int, c_int],
     "tcavt_lora_down": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint32,
                         ctypes.c_uint32, c_int, c_void_p],
-    "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "tcavt_allreduce_flat": [c_void_p, c_int64, c_void_p, c_void_p],
     "tcavt_tlayer_stack_forward": [ctypes.POINTER(TStackArgs), c_void_p],
     "tcavt_cross_attn_forward": [ctypes.POINTER(CrossAttnArgs), c_void_p],

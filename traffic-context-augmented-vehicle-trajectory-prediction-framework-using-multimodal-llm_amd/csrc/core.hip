@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
                                                          const float* __restrict__ txt_mod,
                                                          float* __restrict__ h, int B, int Nq, int Lt,
                                                          int H, int V, int* bad_flag, bf16_t* __restrict__ h16,
-                                                         float* __restrict__ part, int npart) {
+                                                         float* __restrict__ part, int npart, float sscale) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int L = Nq + Lt;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
   float ss = 0.f;  // sum of squares of the row (first decoder layer's fused RMSNorm)
   auto emit = [&](int c, f32x4 o) {
     if (out) *reinterpret_cast<f32x4*>(out + c) = o;
+    o *= sscale;  // (scaled 16-bit image of the stream: tcavt_llama_stack_args.stream_scale; 1 by default, exact for powers of two)
     if (out16) {
       const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
       *reinterpret_cast<u32x2*>(out16 + c) = w;
@@ -254,13 +255,14 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
 // the rows do not come from tcavt_embed_fuse or a TCAVT_EPI_NORM_OUT epilogue (inputs_embeds given by the caller).
 template <bool F16>
 __global__ __launch_bounds__(256) void rownorm_prep_kernel(const float* __restrict__ x, bf16_t* __restrict__ x16,
-                                                           float* __restrict__ part, long M, int H, int npart, int rounded) {
+                                                           float* __restrict__ part, long M, int H, int npart, int rounded,
+                                                           float sscale) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float ss = 0.f;
   for (int c = lane * 4; c < H; c += 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + row * H + c);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + row * H + c) * sscale;
     const u32x2 w = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
     *reinterpret_cast<u32x2*>(x16 + row * H + c) = w;
     if (rounded) v = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
@@ -510,8 +512,10 @@ extern "C" int tcavt_cast_f32_16(const float* x, void* out_bf16, int64_t n, int 
 extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                                 const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
                                 int Lt, int H, int V, int* bad_id_flag, int table_dtype, void* h16, float* part,
-                                int npart, tcavt_stream_t stream) {
+                                int npart, float stream_scale, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && (h || h16) && bad_id_flag, "embed_fuse: null pointer");
+  TCAVT_CHECK_ARG(stream_scale >= 0.f && stream_scale <= 1.f, "embed_fuse: stream_scale must be in (0, 1] (0 means 1)");
+  const float sscale = stream_scale == 0.f ? 1.f : stream_scale;
   TCAVT_CHECK_ARG(is16(table_dtype), "embed_fuse: table_dtype must be TCAVT_BF16 or TCAVT_F16");
   TCAVT_CHECK_ARG((h16 == nullptr) == (part == nullptr) && (!part || npart > 0), "embed_fuse: h16 and part go together (npart > 0)");
   TCAVT_CHECK_ARG(B > 0 && Nq >= 0 && Lt >= 0 && Nq + Lt > 0 && H % 8 == 0 && V > 0, "embed_fuse: bad shape");
@@ -519,26 +523,28 @@ extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, cons
   if (table_dtype == TCAVT_F16)
     hipLaunchKernelGGL(embed_fuse_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale);
   else
     hipLaunchKernelGGL(embed_fuse_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale);
   TCAVT_CHECK_LAUNCH("embed_fuse");
   return TCAVT_OK;
 }
 
 extern "C" int tcavt_rownorm_prep(const float* x, void* x16, float* part, int64_t M, int H, int npart, int dtype16,
-                                  int rounded_sums, tcavt_stream_t stream) {
+                                  int rounded_sums, float stream_scale, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(x && x16 && part && M > 0 && H > 0 && H % 4 == 0 && npart > 0 && is16(dtype16), "rownorm_prep: bad args");
+  TCAVT_CHECK_ARG(stream_scale >= 0.f && stream_scale <= 1.f, "rownorm_prep: stream_scale must be in (0, 1] (0 means 1)");
+  const float sscale = stream_scale == 0.f ? 1.f : stream_scale;
   TCAVT_CHECK_ARG(aligned16(x) && aligned16(x16), "rownorm_prep: unaligned pointer");
   const dim3 grid((unsigned)((M + 3) / 4)), block(256);
   if (dtype16 == TCAVT_F16)
     hipLaunchKernelGGL(rownorm_prep_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), x,
-                       static_cast<bf16_t*>(x16), part, (long)M, H, npart, rounded_sums);
+                       static_cast<bf16_t*>(x16), part, (long)M, H, npart, rounded_sums, sscale);
   else
     hipLaunchKernelGGL(rownorm_prep_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), x,
-                       static_cast<bf16_t*>(x16), part, (long)M, H, npart, rounded_sums);
+                       static_cast<bf16_t*>(x16), part, (long)M, H, npart, rounded_sums, sscale);
   TCAVT_CHECK_LAUNCH("rownorm_prep");
   return TCAVT_OK;
 }

@@ -80,7 +80,13 @@ struct GemmP {
   int sk_cnt_n;
   int* nf_flag;           // NORM_OUT: receives nf_tag (CAS from 0) when a partial sum / rounded element is not finite
   int nf_tag;
+  float norm_scale;       // NORM_OUT: the 16-bit image of the stream (and its partial sums) holds norm_scale * x (tcavt_gemm_args.norm_scale)
 };
+
+// a * s + b, one rounding (s = 1: exactly a + b, so the default scale leaves every result bit for bit as it was)
+__device__ __forceinline__ f32x4 fma4(const f32x4& a, float s, const f32x4& b) {
+  return __builtin_elementwise_fma(a, f32x4{s, s, s, s}, b);
+}
 
 // a non-finite partial sum of squares (inf: a rounded element overflowed; NaN: inf / NaN came in from upstream)
 __device__ __forceinline__ void flag_nonfinite(const GemmP& p, float ss) {
@@ -292,8 +298,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
                 unswap_pair16(oldw[j][k], o[0], o[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                  f32x4 v = acc[2 * k + h][j];
-                  v += f32x4{from16_lo<F16>(o[h][0]), from16_hi<F16>(o[h][0]), from16_lo<F16>(o[h][1]), from16_hi<F16>(o[h][1])};
+                  const f32x4 v = fma4(acc[2 * k + h][j], p.norm_scale,
+                                       f32x4{from16_lo<F16>(o[h][0]), from16_hi<F16>(o[h][0]), from16_lo<F16>(o[h][1]), from16_hi<F16>(o[h][1])});
                   w[h] = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
                   const float r0 = from16_lo<F16>(w[h][0]), r1 = from16_hi<F16>(w[h][0]), r2 = from16_lo<F16>(w[h][1]),
                               r3 = from16_hi<F16>(w[h][1]);
@@ -343,9 +349,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           float ss = 0.f;
 #pragma unroll
           for (int i = g * 4; i < g * 4 + 4; ++i) {
-            f32x4 v = acc[i][j];
             const u32x2 o = old[j][i];
-            v += f32x4{from16_lo<F16>(o[0]), from16_hi<F16>(o[0]), from16_lo<F16>(o[1]), from16_hi<F16>(o[1])};
+            const f32x4 v = fma4(acc[i][j], p.norm_scale,
+                                 f32x4{from16_lo<F16>(o[0]), from16_hi<F16>(o[0]), from16_lo<F16>(o[1]), from16_hi<F16>(o[1])});
             const u32x2 w = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
             if (rowok && colok) *reinterpret_cast<u32x2*>(hrow + i * 16) = w;
             const float r0 = from16_lo<F16>(w[0]), r1 = from16_hi<F16>(w[0]), r2 = from16_lo<F16>(w[1]), r3 = from16_hi<F16>(w[1]);
@@ -393,10 +399,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           float ss = 0.f;
 #pragma unroll
           for (int i = g * 4; i < g * 4 + 4; ++i) {
-            const f32x4 v = acc[i][j] + rv[j][i];
+            const f32x4 vt = acc[i][j] + rv[j][i];
+            const f32x4 v = vt * p.norm_scale;  // (the 16-bit copy and its sums of squares are kept at norm_scale; 1: unchanged)
             const u32x2 w = u32x2{pack16x2<F16>(v[0], v[1]), pack16x2<F16>(v[2], v[3])};
             if (rowok && colok) {
-              *reinterpret_cast<f32x4*>(crow + i * 16) = v;
+              *reinterpret_cast<f32x4*>(crow + i * 16) = vt;
               *reinterpret_cast<u32x2*>(hrow + i * 16) = w;
             }
             if constexpr (F16) ovf |= half_is_inf2(w[0]) | half_is_inf2(w[1]);  // the fp32 value may be fine, its fp16 copy not
@@ -2125,21 +2132,22 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       f32x4 o = v[c];
       const long off = mm * p.ldc + n0 + c * 16 + nq;
       if constexpr (EPI == EPI_NORM16) {  // 16-bit residual stream: in place, sums of the rounded values (see gemm_epilogue)
+        f32x4 oldv = {0.f, 0.f, 0.f, 0.f};
         if (res) {
           const u32x2 old = old16[c];
-          o += f32x4{from16_lo<F16>(old[0]), from16_hi<F16>(old[0]), from16_lo<F16>(old[1]), from16_hi<F16>(old[1])};
+          oldv = f32x4{from16_lo<F16>(old[0]), from16_hi<F16>(old[0]), from16_lo<F16>(old[1]), from16_hi<F16>(old[1])};
         }
+        o = fma4(o, p.norm_scale, oldv);
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
         if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
         o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
         hq[c] = o;
       } else {
         if (res) o += *reinterpret_cast<const f32x4*>(p.residual + mm * p.ldr + n0 + c * 16 + nq);
+        if (rowok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
+        o *= p.norm_scale;  // (the 16-bit copy and the sums below are kept at norm_scale)
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
-        if (rowok) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = o;
-          *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
-        }
+        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
         hq[c] = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
       }
       ss += o[0] * o[0];
@@ -2357,6 +2365,11 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   }
   p.nf_flag = (epi & TCAVT_EPI_NORM_OUT) ? a->nonfinite_flag : nullptr;
   p.nf_tag = a->nonfinite_tag;
+  p.norm_scale = 1.f;
+  if (epi & TCAVT_EPI_NORM_OUT) {
+    TCAVT_CHECK_ARG(a->norm_scale >= 0.f && a->norm_scale <= 1.f, "gemm_bf16: norm_scale must be in (0, 1] (0 means 1)");
+    if (a->norm_scale != 0.f) p.norm_scale = a->norm_scale;
+  }
   p.rs_part = nullptr;
   p.rope_pos = (epi & TCAVT_EPI_ROPE) ? a->rope_pos : nullptr;
   p.rs_npart = 0;

@@ -506,11 +506,16 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   const int nqkv = (nq + 2 * nkv) * 64;
   const int np_in = norm_out_npart(B, H, I), np_post = norm_out_npart(B, H, nq * 64);  // see csrc/stack.hip
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // scaled 16-bit image of the residual stream, as in tcavt_llama_stack_forward (the prefill that filled the cache ran at the same scale
+  // or not: keys / values are true-scale either way)
+  TCAVT_CHECK_ARG(a->stream_scale >= 0.f && a->stream_scale <= 1.f, "llama_decode_step: stream_scale must be in (0, 1] (0 means 1)");
+  const float ss_ = a->stream_scale == 0.f ? 1.f : a->stream_scale;
+  const float eps_s = a->rms_eps * ss_ * ss_;
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
   // (a->h == NULL: the residual stream is the 16-bit h16 itself, as in tcavt_llama_stack_forward)
   TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->txt_mod /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
-                             a->bad_id_flag, dt, a->h16, a->part, np_in, stream));
+                             a->bad_id_flag, dt, a->h16, a->part, np_in, ss_, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
   const int KS = std::min(16, (a->kv_lmax + 63) / 64);  // key splits (waves) per query head: one 64-key round each up to 1024 keys
   const size_t lds = ((size_t)a->kv_lmax + (size_t)KS * 66) * sizeof(float);
@@ -526,7 +531,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     if (w.a_cat && !t_fused) {
       tcavt_gemm_args g = {};
       g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
-      g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;
+      g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;  // (t stays at the stream's scale: b_ext carries 1 / stream_scale)
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
@@ -540,7 +545,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->rope_L; g.rope_cols = (nq + nkv) * 64;
       g.rope_pos = a->pos;
-      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = eps_s;
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
@@ -560,7 +565,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H;
       g.M = B; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
-      g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -570,7 +575,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
       g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
-      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = eps_s;
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
@@ -579,7 +584,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H;
       g.M = B; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
-      g.norm_h16 = a->h16; g.norm_part = a->part;
+      g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       if (lp_ok && li + 1 < a->n_layers && a->layers[li + 1].a_cat) {
         g.lora_part = a->lora_part; g.lora_part_a = a->layers[li + 1].a_cat; g.lora_part_lda = H;
@@ -588,7 +593,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
   }
-  if (a->h == nullptr) TCAVT_TRY(tcavt_rmsnorm16(a->h16, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, dt, stream));
+  if (a->h == nullptr) TCAVT_TRY(tcavt_rmsnorm16(a->h16, a->gamma_final, eps_s, a->x16, nullptr, B, H, dt, stream));
   else TCAVT_TRY(tcavt_rmsnorm(a->h, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, nullptr, 0.f, 0, 0, dt, stream));
   // lm_head: tied to the embedding table (Llama-3.2-1B: tie_word_embeddings)
   tcavt_gemm_args g = {};

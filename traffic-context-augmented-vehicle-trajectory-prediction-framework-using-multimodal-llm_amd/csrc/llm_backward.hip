@@ -1507,13 +1507,32 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
   }
 }
 
-// dst[i][j] = src[i][j] * (*scale): the adapters' gradients leave the scratch (and the backward's scale) for the caller's tensors
-__global__ __launch_bounds__(256) void scale_copy2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd,
-                                                           int rows, int cols, const float* __restrict__ scale) {
+// The four adapter gradients of one layer leave the two scratch matrices (dA [64][H]: rows 0.. = A_q, 16.. = A_v; dB [nqkv][64]:
+// q rows x columns 0.., v rows x columns 16..) for the caller's tensors, times *scale, in ONE launch that also zeroes the
+// scratch for the next layer's atomically accumulated sums (was: two memsets + four scale-and-copy launches per layer on the
+// leaf queue, 96 launches per step).
+__global__ __launch_bounds__(256) void adapter_grads_out_kernel(float* __restrict__ dA, float* __restrict__ dB, float* __restrict__ gAq,
+                                                                float* __restrict__ gAv, float* __restrict__ gBq, float* __restrict__ gBv,
+                                                                int H, int nqkv, int q_rows, int v_row0, int r,
+                                                                const float* __restrict__ scale) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)rows * cols) return;
-  const int i = (int)(idx / cols), j = (int)(idx - (long)i * cols);
-  dst[(long)i * ldd + j] = src[(long)i * lds_ + j] * (scale ? *scale : 1.f);
+  const long nA = (long)64 * H;
+  const float sc = scale ? *scale : 1.f;
+  if (idx < nA) {
+    const int i = (int)(idx / H), j = (int)(idx - (long)i * H);
+    const float v = dA[idx];
+    dA[idx] = 0.f;
+    if (i < r) gAq[(long)i * H + j] = v * sc;
+    else if (i >= 16 && i < 16 + r) gAv[(long)(i - 16) * H + j] = v * sc;
+    return;
+  }
+  const long k = idx - nA;
+  if (k >= (long)nqkv * 64) return;
+  const int i = (int)(k >> 6), j = (int)(k & 63);
+  const float v = dB[k];
+  dB[k] = 0.f;
+  if (i < q_rows && j < r) gBq[(long)i * r + j] = v * sc;
+  else if (i >= v_row0 && j >= 16 && j < 16 + r) gBv[(long)(i - v_row0) * r + (j - 16)] = v * sc;
 }
 
 // ---------------------------------------------------------------------------
@@ -1807,10 +1826,21 @@ extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tc
   const int B = a->B, L = a->L, H = a->H, I = a->I, nq = a->nq, nkv = a->nkv, dt = a->dtype16, r = a->lora_rank;
   TCAVT_CHECK_ARG(a->n_layers > 0 && B > 0 && L > 0 && is16(dt) && nkv > 0 && nq % nkv == 0 && r > 0 && r <= 16 && a->npart > 0,
                   "llama_stack_backward: bad shape");
+  // fp16 tapes only: the 16-bit residual-stream tapes this walk reads exist for fp16 storage alone (bf16 storage keeps fp32
+  // streams, whose backward is the per-launch composition of llm_backward.py); head_dim 64, adapters in 16-column groups
+  TCAVT_CHECK_ARG(dt == TCAVT_F16, "llama_stack_backward: dtype16 must be TCAVT_F16 (16-bit stream tapes exist for fp16 storage only)");
   const int M = B * L, nqkv = (nq + 2 * nkv) * 64;
   TCAVT_CHECK_ARG(tcavt_attn_bwd_resident_ok(L, nq, nkv) && M % 256 == 0 && I % 256 == 0 && H % 128 == 0,
                   "llama_stack_backward: outside the fused forms (L <= 256, 16 %% (nq / nkv) == 0, M %% 256 == 0, I %% 256 == 0, H %% 128 == 0)");
   TCAVT_CHECK_ARG(!a->leaf_stream || a->events, "llama_stack_backward: a leaf stream needs the four events");
+  // every layer's pointers are checked BEFORE anything is launched: an argument error must not leave half a walk enqueued
+  // (adapter gradients half-written, the leaf stream forked and never joined -- under a hipGraph capture an unjoined stream)
+  for (int li = 0; li < a->n_layers; ++li) {
+    const tcavt_llama_bwd_layer& w = a->layers[li];
+    TCAVT_CHECK_ARG(w.w_dT && w.w_guT && w.w_oT && w.w_qkvT && w.b_extT && w.a_qT && w.a_vT && w.g1 && w.g2 && w.h_in && w.h_mid && w.qkv &&
+                        w.gu && w.att && w.lse && w.part && w.t && w.g_Aq && w.g_Av && w.g_Bq && w.g_Bv,
+                    "llama_stack_backward: layer %d: null pointer", li);
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipStream_t lf = a->leaf_stream ? static_cast<hipStream_t>(a->leaf_stream) : st;
   const bool two = lf != st;
@@ -1833,13 +1863,14 @@ extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tc
     return TCAVT_ERR_HIP;
   };
   bool leaf_used[2] = {false, false};
+  bool scratch_zeroed = false;
   void* const g_qkv2[2] = {a->g_qkv0, a->g_qkv1};
   void* const g_t2[2] = {a->g_t0, a->g_t1};
+  // (the walk is a lambda so that a failure in the middle of it -- a launch error; the arguments were checked above -- still
+  //  reaches the join below: the caller's stream then waits for whatever the leaf stream was given)
+  auto walk = [&]() -> int {
   for (int li = a->n_layers - 1; li >= 0; --li) {
     const tcavt_llama_bwd_layer& w = a->layers[li];
-    TCAVT_CHECK_ARG(w.w_dT && w.w_guT && w.w_oT && w.w_qkvT && w.b_extT && w.a_qT && w.a_vT && w.g1 && w.g2 && w.h_in && w.h_mid && w.qkv &&
-                        w.gu && w.att && w.lse && w.part && w.t && w.g_Aq && w.g_Av && w.g_Bq && w.g_Bv,
-                    "llama_stack_backward: layer %d: null pointer", li);
     // ---- MLP half
     {
       tcavt_gemm_args g = {};
@@ -1864,21 +1895,17 @@ extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tc
     }
     {
       const uint32_t site = a->lora_first_site + 2u * (uint32_t)li;
-      TCAVT_TRY(hip_ok(hipMemsetAsync(a->dA, 0, (size_t)64 * H * sizeof(float), lf), "memset(dA)"));
-      TCAVT_TRY(hip_ok(hipMemsetAsync(a->dB, 0, (size_t)nqkv * 64 * sizeof(float), lf), "memset(dB)"));
+      if (!scratch_zeroed) {  // (once per walk: adapter_grads_out_kernel leaves the scratch zero for the next layer)
+        TCAVT_TRY(hip_ok(hipMemsetAsync(a->dA, 0, (size_t)64 * H * sizeof(float), lf), "memset(dA)"));
+        TCAVT_TRY(hip_ok(hipMemsetAsync(a->dB, 0, (size_t)nqkv * 64 * sizeof(float), lf), "memset(dB)"));
+        scratch_zeroed = true;
+      }
       TCAVT_TRY(tcavt_lora_wgrad_a(w.h_in, w.part, a->npart, a->rms_eps, w.g1, g_t2[par], a->dA, H, M, H, a->lora_dropout_p,
                                    a->dropout_seed, site, site + 1, dt, lf));
       TCAVT_TRY(tcavt_wgrad_tn(w.t, 64, 0, 32, g_qkv2[par], nqkv, dt, a->dB, 64, M, nqkv, 1, dt, w.part, a->npart, H, a->rms_eps, lf));
-      struct Cp { const float* src; long lds_; float* dst; long ldd; int rows, cols; };
-      const Cp cps[4] = {{a->dA, H, w.g_Aq, H, r, H},
-                         {a->dA + (long)16 * H, H, w.g_Av, H, r, H},
-                         {a->dB, 64, w.g_Bq, r, nq * 64, r},
-                         {a->dB + (long)(nq + nkv) * 64 * 64 + 16, 64, w.g_Bv, r, nkv * 64, r}};
-      for (const Cp& c : cps) {
-        const long n = (long)c.rows * c.cols;
-        hipLaunchKernelGGL(scale_copy2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lf, c.src, c.lds_, c.dst, c.ldd, c.rows,
-                           c.cols, f16 ? inv_s : nullptr);
-      }
+      const long n_out = (long)64 * H + (long)nqkv * 64;
+      hipLaunchKernelGGL(adapter_grads_out_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, lf, a->dA, a->dB, w.g_Aq, w.g_Av,
+                         w.g_Bq, w.g_Bv, H, nqkv, nq * 64, (nq + nkv) * 64, r, f16 ? inv_s : nullptr);
       TCAVT_CHECK_LAUNCH("llama_stack_backward(adapter gradients)");
     }
     if (two) {
@@ -1893,10 +1920,23 @@ extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tc
     TCAVT_TRY(gemm(g_qkv2[par], nqkv, w.w_qkvT, nqkv, a->g_xn, H, 0.f));
     TCAVT_TRY(tcavt_rmsnorm_bwd(w.h_in, w.g1, a->g_xn, a->g_xl, a->rms_eps, a->g_h, a->g_hb, 1, M, H, dt, dt, nullptr, dt, stream));
   }
-  if (two)
-    for (int par = 0; par < 2; ++par)
-      if (leaf_used[par]) TCAVT_TRY(hip_ok(hipStreamWaitEvent(st, static_cast<hipEvent_t>(a->events[2 + par]), 0), "join(leaf)"));
   return TCAVT_OK;
+  };
+  const int rc_walk = walk();
+  int rc_join = TCAVT_OK;
+  if (two) {
+    if (rc_walk != TCAVT_OK) {
+      // the failing layer may have forked the leaf stream without recording its `done` event: one more record covers
+      // everything that stream was given, and the join below waits for it
+      if (hipEventRecord(static_cast<hipEvent_t>(a->events[2]), lf) == hipSuccess) leaf_used[0] = true;
+    }
+    for (int par = 0; par < 2; ++par)
+      if (leaf_used[par] && hipStreamWaitEvent(st, static_cast<hipEvent_t>(a->events[2 + par]), 0) != hipSuccess && rc_walk == TCAVT_OK) {
+        set_error("llama_stack_backward: join(leaf) failed");
+        rc_join = TCAVT_ERR_HIP;
+      }
+  }
+  return rc_walk != TCAVT_OK ? rc_walk : rc_join;
 }
 
 extern "C" int tcavt_clip_grad_norm(float* g, int64_t n, float max_norm, float grad_scale, float* scratch,

@@ -208,6 +208,12 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
   const int np_in = norm_out_npart(M, H, I), np_post = norm_out_npart(M, H, nq * 64);
   TCAVT_CHECK_ARG(a->npart_in == np_in, "llama_stack_forward: npart_in = %d, but h16 / part must carry tcavt_norm_npart(M, H, I) = %d partials per row", a->npart_in, np_in);
   const float scale = 0.125f;  // 1 / sqrt(head_dim 64)
+  // scaled 16-bit image of the residual stream (stream_scale: include/tcavt.h): h16 / part arrive at that scale, the residual
+  // epilogues keep it, the fused norms see eps * s^2 (RMSNorm of s x with that eps IS RMSNorm of x); the adapters' t = lora_scale *
+  // (s x) . A^T stays at the stream's scale as well (un-normalised, it has the stream's range) and the caller's b_ext carries 1 / s
+  TCAVT_CHECK_ARG(a->stream_scale >= 0.f && a->stream_scale <= 1.f, "llama_stack_forward: stream_scale must be in (0, 1] (0 means 1)");
+  const float ss_ = a->stream_scale == 0.f ? 1.f : a->stream_scale;
+  const float eps_s = a->rms_eps * ss_ * ss_;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* h = a->h;
   const void* x16 = a->h16;  // the 16-bit stream (or 16-bit copy of the fp32 stream) the current layer reads
@@ -216,6 +222,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     TCAVT_CHECK_ARG(w.w_qkv && w.w_o && w.w_gu && w.w_d && (w.a_cat == nullptr) == (w.b_ext == nullptr),
                     "llama_stack_forward: layer %d: null weight", li);
     const bool tape = w.tape_h_mid != nullptr;
+    if (tape) TCAVT_CHECK_ARG(ss_ == 1.f, "llama_stack_forward: a tape keeps the streams at scale 1 (stream_scale must be 0 or 1)");
     if (tape) TCAVT_CHECK_ARG(w.tape_h_out && w.tape_qkv && w.tape_gu && (!w.a_cat || w.tape_t), "llama_stack_forward: layer %d: incomplete tape", li);
     void* qkv = tape ? w.tape_qkv : a->qkv;
     void* t = tape && w.a_cat ? w.tape_t : a->t;
@@ -249,7 +256,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       if (w.a_cat) { g.A2 = t; g.lda2 = 64; g.W2 = w.b_ext; g.ldw2 = 64; g.K2 = 64; }
       g.epilogue = TCAVT_EPI_ROPE | TCAVT_EPI_ROWSCALE;
       g.rope_cos = a->rope_cos; g.rope_sin = a->rope_sin; g.rope_L = a->L; g.rope_cols = (nq + nkv) * 64;
-      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_in; g.rowscale_h = H; g.rowscale_eps = eps_s;
       ev.rec(0);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
       ev.rec(1);
@@ -275,7 +282,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.residual = h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;  // (stream16: C = residual = NULL)
       if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_mid; g.norm_res16 = x16; }
       else g.norm_h16 = a->h16;
-      g.norm_part = a->part;
+      g.norm_part = a->part; g.norm_scale = ss_;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       ev.rec(4);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -287,7 +294,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.A = stream16 ? x_mid : a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
       g.M = M; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt; g.tile = a->gemm_tile;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
-      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = a->rms_eps;
+      g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = eps_s;
       if (tape) { g.silu_preact = w.tape_gu; g.ld_preact = 2 * I; }
       ev.rec(6);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -301,7 +308,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       g.residual = h_mid; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_out; g.norm_res16 = x_mid; }
       else g.norm_h16 = a->h16;
-      g.norm_part = a->part;
+      g.norm_part = a->part; g.norm_scale = ss_;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       ev.rec(8);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -311,7 +318,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
     x16 = x_out;
   }
   // final RMSNorm: its fp32 result is hidden_states[-1] (scripts/train.py:553), the 16-bit copy feeds the head's K / V projections
-  if (stream16) return tcavt_rmsnorm16(x16, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, dt, stream);
+  if (stream16) return tcavt_rmsnorm16(x16, a->gamma_final, eps_s, a->out16, a->out_f32, M, H, dt, stream);  // (s x, eps s^2: the norm of x)
   return tcavt_rmsnorm(h, a->gamma_final, a->rms_eps, a->out16, a->out_f32, M, H, nullptr, 0.f, 0, 0, dt, stream);
 }
 

@@ -270,3 +270,90 @@ class DistributedStridedSampler:
 
     def __len__(self):
         return self.per_rank
+
+
+class FedBatch(dict):
+    """A collated batch whose tensors live on the device: the dict custom_collate_fn returns (tensor entries moved, lists of
+    numbers as tensors, strings kept), plus `ready` -- the event of the copy that filled it -- and `slot`."""
+    ready = None
+    slot = -1
+
+
+class DeviceFeeder:
+    """Host -> device feeding of the training loop (scripts/train.py:1153-1166).
+
+    The reference moves seven tensors of every batch with blocking ``.to(device)`` calls from pageable memory at the head of
+    the step.  Here a batch goes through a ring of `slots` (>= 3) staging sets: pinned host buffers, then
+    ``copy_(non_blocking=True)`` on a side stream, and the step is told WHEN its inputs are ready (``FedBatch.ready``, an
+    event) instead of waiting for them on the host: ``Trainer.step(..., inputs_ready=fed.ready)``.  With the pipelined decoder
+    (training.Trainer, frozen-MLLM variant) three batches are alive at once -- step i's head and backward, step i + 1's
+    decoder, and the copy of batch i + 2 -- hence the ring; a slot is overwritten only after ``release()`` of the batch that
+    used it (an event on the caller's stream: everything that step enqueued has read its inputs by then).
+
+    No stream of its own: the copies go to slot 2 of the side-stream pool, in front of the Q-Former prefetch of the same
+    batch (tcavt_amd.streams: the pipelined step keeps its cross-step overlap only while at most five HIP streams are in
+    use -- DESIGN.md section 6 -- and ~1.4 MB per step need no queue of their own)."""
+
+    TENSOR_KEYS = ("traj_emb", "target_traj", "vision_emb", "lane_polygon", "input_ids", "attention_mask", "labels")
+    LIST_KEYS = (("lane_polygon_len", torch.int32), ("norm_stat", torch.float32))
+
+    def __init__(self, device, slots=3, stream=None):
+        from . import streams
+
+        if slots < 3:
+            raise ValueError("DeviceFeeder: at least three slots (two batches in flight + the one being copied)")
+        self.device = torch.device(device)
+        self.stream = stream if stream is not None else streams.side_stream(self.device, 2)
+        self._slots = [None] * slots
+        self._free = [None] * slots
+        self._count = 0
+        self.bytes_per_batch = 0
+
+    def _host_tensors(self, batch):
+        out = {}
+        for k in self.TENSOR_KEYS:
+            out[k] = batch[k] if torch.is_tensor(batch[k]) else torch.as_tensor(batch[k])
+        for k, dt in self.LIST_KEYS:
+            v = batch[k]
+            out[k] = (v if torch.is_tensor(v) else torch.tensor([list(r) for r in v] if k == "norm_stat" else list(v))).to(dt)
+        return out
+
+    def put(self, batch):
+        """Stage one collated batch (host tensors / lists) and start its copy; returns the FedBatch at once."""
+        k = self._count % len(self._slots)
+        self._count += 1
+        host = self._host_tensors(batch)
+        slot = self._slots[k]
+        if slot is None or any(slot["pin"][n].shape != t.shape or slot["pin"][n].dtype != t.dtype for n, t in host.items()):
+            if slot is not None:
+                slot["ev"].synchronize()
+                for t in slot["dev"].values():
+                    t.record_stream(torch.cuda.current_stream(self.device))  # (a step enqueued earlier may still read it)
+            slot = self._slots[k] = {
+                "pin": {n: torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for n, t in host.items()},
+                "dev": {n: torch.empty(t.shape, dtype=t.dtype, device=self.device) for n, t in host.items()}, "ev": None}
+        elif slot["ev"] is not None:
+            slot["ev"].synchronize()  # the previous copy OUT of this pinned set (len(slots) batches ago: long done)
+        for n, t in host.items():
+            slot["pin"][n].copy_(t)
+        self.bytes_per_batch = sum(t.numel() * t.element_size() for t in host.values())
+        if self._free[k] is not None:
+            self.stream.wait_event(self._free[k])  # the step that last used these device tensors has read them
+        with torch.cuda.stream(self.stream):
+            for n in host:
+                slot["dev"][n].copy_(slot["pin"][n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        slot["ev"] = ev
+        fed = FedBatch(slot["dev"])
+        for n in ("context_str", "answer_str", "track_id"):
+            if n in batch:
+                fed[n] = batch[n]
+        fed.ready, fed.slot = ev, k
+        return fed
+
+    def release(self, fed):
+        """Call after the step that consumes `fed` has been enqueued (on the stream it was enqueued on)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._free[fed.slot] = ev

@@ -130,8 +130,8 @@ class LoraBackward:
             return False
         if any(os.environ.get(k) for k in ("TCAVT_ATTN_BWD_TWO_SWEEPS", "TCAVT_ATTN_BWD_NO_RESIDENT", "TCAVT_LORA_LEAF_UNFUSED")):
             return False  # (A/B switches of the Python composition)
-        if not ops.attn_bwd_resident_ok(L, nq, nkv) or st not in (torch.float16, torch.bfloat16):
-            return False
+        if not ops.attn_bwd_resident_ok(L, nq, nkv) or st != torch.float16 or self.lw.shape.head_dim != 64:
+            return False  # (the stage call walks fp16 stream tapes with head_dim 64; anything else: the composition below)
         return all(sv.h_in.dtype == st and getattr(sv, "lse", None) is not None and getattr(sv, "part", None) is not None
                    and sv.t is not None for sv in tape.layers)
 
@@ -156,8 +156,6 @@ class LoraBackward:
         a.h_last, a.gamma_final = tape.h_last.data_ptr(), P.g_final.data_ptr()
         a.g_final_a, a.g_final_b = g_final_a.data_ptr(), None if g_final_b is None else g_final_b.data_ptr()
         a.rope_cos, a.rope_sin, a.kv_len = cos.data_ptr(), sin.data_ptr(), tape.kv_len.data_ptr()
-        if st != torch.float16:
-            scale.copy_(torch.ones(2, device=scale.device))
         a.scale, a.scale_scratch = scale.data_ptr(), self._buf("scale_scratch", (1,), torch.int32, zero=True).data_ptr()
         for k in ("g_h", "g_hb", "g_xn", "g_xl", "g_att", "dA", "dB"):
             setattr(a, k, buf[k].data_ptr())

@@ -12,9 +12,11 @@ Differences from the reference that are deliberate and documented in DESIGN.md:
   * ``lm_head`` + cross-entropy of the reference's LLM call are dead work (its caller keeps
     only ``hidden_states[-1]``, train.py:553) and are not computed: ``outputs.loss`` and
     ``outputs.logits`` are ``None``;
-  * the tokenizer branch of ``LlamaMultiModal.forward`` (train.py:556-575) needs a
-    tokenizer that does not exist offline and raises ``NotImplementedError``;
-  * eval-mode arithmetic only (dropout = identity) in this round.
+  * the tokenizer branch of ``LlamaMultiModal.forward`` (train.py:556-575) runs when a tokenizer
+    object is attached (``model.mllm.tokenizer``; none can be fetched offline) and raises
+    ``NotImplementedError`` otherwise;
+  * train-mode dropout draws its masks in-kernel from Philox (csrc/philox.hpp): same placement
+    as the reference's dropout modules, not torch's random stream.
 """
 import contextlib
 import math
@@ -554,6 +556,22 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self.save_for_backward = False
         self.tape = None
         self._prep_T = None
+        # Scaled 16-bit image of the residual stream (tcavt_llama_stack_args.stream_scale): a power of two <= 1.  The 16-bit
+        # stream (or the 16-bit copy of an fp32 stream) holds stream_scale * x, which moves the overflow limit of fp16 storage from
+        # 65504 to 65504 / stream_scale at no cost in precision -- real checkpoints carry outlier channels far above the bulk
+        # (MultiModalTrajectoryModel.set_storage("auto") picks it after a flagged first pass).  1.0: the plain contract.
+        self.stream_scale = 1.0
+        # fp16 operands with an fp32 residual stream (h != NULL in tcavt_llama_stack_args): the stream itself has no range limit,
+        # its 16-bit copy is the only fp16 image (10 instead of 4 bytes per element through the residual epilogues)
+        self.wide_stream = False
+
+    def set_stream_contract(self, stream_scale=1.0, wide_stream=False):
+        """See stream_scale / wide_stream above.  The packed adapters carry 1 / stream_scale (b_ext): re-packed when it changes."""
+        if float(stream_scale) != self.stream_scale and self.use_lora:
+            if self._prep_T is not None:
+                raise RuntimeError("stream_scale cannot change once the backward's operands exist (LoRA-trainable variant: scale 1 only)")
+            self._invalidate()
+        self.stream_scale, self.wide_stream = float(stream_scale), bool(wide_stream)
 
     # ---- packed device-side weights -------------------------------------------------
     def _prepare(self):
@@ -593,8 +611,9 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 g1_all[nL - 1 - li, 0].copy_(d.g1)
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
-                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
-                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
+                # (b_ext carries 1 / stream_scale: t is kept at the stream's scale, tcavt_llama_stack_args.stream_scale)
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach() / self.stream_scale)
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach() / self.stream_scale)
             d.w_o = to16(a.o_proj.weight)
             d.w_gu = to16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()) * d.g2[None, :])
             d.w_d = to16(lyr.mlp.down_proj.weight)
@@ -681,15 +700,15 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             aq, bq, av, bv = stacked
             P.a_all[:, :r].copy_(aq * P.g1_all)
             P.a_all[:, LORA_V:LORA_V + r].copy_(av * P.g1_all)
-            P.b_all[:, : nq * hd, :r].copy_(bq)
-            P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv)
+            P.b_all[:, : nq * hd, :r].copy_(bq / self.stream_scale)
+            P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv / self.stream_scale)
         else:
             for li, lyr in enumerate(self.llama_model.model.layers):
                 a, d = lyr.self_attn, P.layers[li]
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
-                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
-                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach() / self.stream_scale)
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach() / self.stream_scale)
         if self._prep_T is not None:
             self._refresh_lora_T(stacked)
 
@@ -714,7 +733,7 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         stream lives in norm_inputs()[0] only and the residual epilogues add to it in place; with one (the LoRA-trainable
         variant) every epilogue writes the updated stream to its layer's own 16-bit buffer, which the backward reads --
         the forward arithmetic is the frozen path's either way.  bf16 storage (round 1's contract) keeps fp32 streams."""
-        return self.storage == torch.float16
+        return self.storage == torch.float16 and not self.wide_stream
 
     def norm_npart(self, M):
         """Partials per row the first fused norm of a pass over M rows reads (what embed_fuse / rownorm_prep must write)."""
@@ -827,6 +846,10 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         args.npart_in = self.norm_npart(M)
         args.rms_eps = ll.rms_eps
         args.lora_scale = (self.lora_alpha / self.lora_r) if self.use_lora else 0.0
+        if self.stream_scale != 1.0:
+            if self.save_for_backward:
+                raise capi.TcavtError("decoder_stack: the tape of the LoRA-trainable variant keeps the streams at scale 1 (stream_scale)")
+            args.stream_scale = float(self.stream_scale)
         ops.llama_stack_forward(args)
         del keep
 
@@ -837,11 +860,11 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         if self.stream16:
             h = None
             ops.rownorm_prep(inputs_embeds.reshape(B * L, H).float().contiguous(), *self.norm_inputs(B * L, dev),
-                             npart=self.norm_npart(B * L), rounded_sums=True)
+                             npart=self.norm_npart(B * L), rounded_sums=True, stream_scale=self.stream_scale)
         else:
             h = self._ws.get("ll.h", (B * L, H), torch.float32, dev)
             h.copy_(inputs_embeds.reshape(B * L, H))
-            ops.rownorm_prep(h, *self.norm_inputs(B * L, dev), npart=self.norm_npart(B * L))
+            ops.rownorm_prep(h, *self.norm_inputs(B * L, dev), npart=self.norm_npart(B * L), stream_scale=self.stream_scale)
         kv_len = torch.empty(B, dtype=torch.int32, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ops.mask_to_kvlen(attention_mask.to(torch.int64).contiguous(), 0, kv_len, flag)
@@ -941,9 +964,15 @@ class LlamaMultiModal(nn.Module, _Prepared):
         (MultiModalTrajectoryModel.pipeline_decoder) alternates them, the head of pass i still reads one while pass i + 1
         writes the other."""
         if input_ids is None or attention_mask is None:
-            raise NotImplementedError(
-                "the tokenizer branch (train.py:556-575) needs a tokenizer that cannot be fetched offline; "
-                "pass input_ids/attention_mask as custom_collate_fn produces them")
+            # tokenizer branch (train.py:556-575): context_str alone, tokenised with padding + truncation, no labels
+            if self.tokenizer is None or context_str is None:
+                raise NotImplementedError(
+                    "the tokenizer branch (train.py:556-575) needs a tokenizer that cannot be fetched offline: attach one "
+                    "(model.tokenizer = ...) or pass input_ids/attention_mask as custom_collate_fn produces them")
+            enc = self.tokenizer(context_str, return_tensors="pt", padding=True, truncation=True)
+            input_ids = enc["input_ids"].to(vision_embs.device)
+            attention_mask = enc["attention_mask"].to(vision_embs.device)
+            labels = None
         B, Lt = input_ids.shape
         dev, H, ws = vision_embs.device, self.llama_hidden_size, self._ws
         P = self._prepared()
@@ -966,7 +995,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
         flags = ws.get("mm.flags", (3,), torch.int32, dev, zero=True)
         h16, part = LW.norm_inputs(B * L, dev)
         ops.embed_fuse(LW._prepared().table, input_ids.contiguous(), img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part,
-                       npart=LW.norm_npart(B * L))
+                       npart=LW.norm_npart(B * L), stream_scale=LW.stream_scale)
         if dev.type == "cuda" and self._pf_stream is not None:
             self._img_consumed = torch.cuda.Event()
             self._img_consumed.record()
@@ -1053,7 +1082,8 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 h = None if LW.stream16 else ws.get("gen.h", (B * L, H), torch.float32, dev)
                 flags = ws.get("mm.flags", (3,), i32, dev, zero=True)
                 h16, part = LW.norm_inputs(B * L, dev)
-                ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part, npart=LW.norm_npart(B * L))
+                ops.embed_fuse(PL.table, input_ids, img, P.vis, P.txt, h, flags[0:1], h16=h16, part=part, npart=LW.norm_npart(B * L),
+                               stream_scale=LW.stream_scale)
                 kv_len = ws.get("gen.kvlen", (B,), i32, dev)
                 ops.mask_to_kvlen(attention_mask.to(i64).contiguous(), Nq, kv_len, flags[1:2])
                 self._last_flags = flags
@@ -1107,6 +1137,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     a.n_layers, a.B, a.H, a.I, a.nq, a.nkv, a.V = ll.layers, B, H, ll.inter, ll.n_q_heads, ll.n_kv_heads, ll.vocab
                     a.dtype16 = capi.F16 if st == torch.float16 else capi.BF16
                     a.rms_eps, a.lora_scale = ll.rms_eps, (LW.lora_alpha / LW.lora_r) if LW.use_lora else 0.0
+                    a.stream_scale = float(LW.stream_scale)
 
                     def one_step():
                         ops.llama_decode_step(a)
@@ -1526,6 +1557,7 @@ class MultiModalTrajectoryModel(nn.Module):
         # Train-mode dropout (the MC-dropout K-candidate protocol, test.py:1301-1342): active when the module
         # is in .train() mode; every forward uses seed dropout_seed + number of forwards so far.
         self.dropout_seed, self._fwd_count = 0x5EED, 0
+        self._auto_range, self.range_contract = None, None  # set_storage("auto")
 
     @classmethod
     def from_config(cls, cfg: ModelConfig):
@@ -1557,16 +1589,61 @@ class MultiModalTrajectoryModel(nn.Module):
             if isinstance(m, _Prepared):
                 m._invalidate()
 
-    def set_storage(self, dtype):
+    # stream contracts set_storage("auto") walks through, in order, until a pass raises no range flag: the plain 16-bit stream,
+    # the same stream kept at 2^-k (overflow limit 65504 * 2^k; fp16 is a floating-point format, so the scale costs nothing
+    # until values fall below 6.1e-5 * 2^k and go subnormal -- hence the smallest k that passes), and last an fp32 stream
+    # whose 16-bit copy is kept at the smallest scale (10 instead of 4 bytes per element through the residual epilogues).
+    AUTO_LADDER = ((1.0, False), (2.0 ** -2, False), (2.0 ** -4, False), (2.0 ** -6, False), (2.0 ** -8, False),
+                   (2.0 ** -10, False), (2.0 ** -10, True))
+
+    def set_storage(self, dtype, stream_scale=None, wide_stream=None):
         """16-bit storage type of every GEMM operand of the model (weights copies and activations): torch.float16 (the
-        default, see _Prepared.storage) or torch.bfloat16.  Packed copies are rebuilt on the next forward."""
+        default, see _Prepared.storage) or torch.bfloat16.  Packed copies are rebuilt on the next forward.
+
+        "auto": fp16, with the decoder's residual-stream contract chosen on the first forward: the pass runs on the plain
+        16-bit stream; if its range flag comes back set (tcavt_llama_stack_args.nonfinite_flag: some 16-bit value left
+        +-65504) the same batch is re-run down AUTO_LADDER until a pass is clean, and the model keeps that contract
+        (self.range_contract says which; one host sync per trial, on the first forward only).  Real Llama checkpoints carry
+        outlier channels orders of magnitude above the bulk of the stream; the synthetic weights here stay at ~10.
+        stream_scale / wide_stream set a contract by hand (LlamaWithCrossAttnPEFT.stream_scale / .wide_stream)."""
+        auto = isinstance(dtype, str) and dtype == "auto"
+        if auto:
+            dtype = torch.float16
         if dtype not in (torch.float16, torch.bfloat16):
-            raise ValueError("storage must be torch.float16 or torch.bfloat16")
+            raise ValueError('storage must be torch.float16, torch.bfloat16 or "auto"')
         for m in self.modules():
             if isinstance(m, _Prepared):
                 m.storage = dtype
                 m._invalidate()
+        lw = self.mllm.llama_wrapper
+        lw.set_stream_contract(1.0 if stream_scale is None else float(stream_scale), bool(wide_stream) if wide_stream is not None else False)
+        if lw.stream_scale <= 0.0 or lw.stream_scale > 1.0 or math.frexp(lw.stream_scale)[0] != 0.5:
+            raise ValueError("stream_scale must be a power of two in (0, 1]")
+        self._auto_range = "pending" if auto else None
+        self.range_contract = None
         return self
+
+    def _calibrate_range(self, vision_embs, context_str, input_ids, attention_mask, labels):
+        """First forward under set_storage("auto"): trial passes of the MLLM down AUTO_LADDER (see set_storage)."""
+        lw = self.mllm.llama_wrapper
+        trials = []
+        for scale, wide in self.AUTO_LADDER:
+            lw.set_stream_contract(scale, wide)
+            with torch.no_grad():
+                self.mllm(vision_embs, context_str, input_ids=input_ids, attention_mask=attention_mask, labels=labels, return_bf16=True)
+            flags = self.mllm._last_flags
+            tag = int(flags[2].item())  # (host sync: calibration only)
+            flags[2:3].zero_()
+            trials.append((scale, wide, tag))
+            if tag == 0:
+                break
+        self._auto_range = None
+        self.range_contract = SimpleNamespace(stream_scale=lw.stream_scale, wide_stream=lw.wide_stream, trials=trials,
+                                              clean=trials[-1][2] == 0)
+        if not self.range_contract.clean:
+            # nothing on the ladder helps: the overflow is not in the residual stream (act / q|k|v / attention output), or the
+            # inputs are not finite -- back to the plain contract; check_flags() reports it as before
+            lw.set_stream_contract(1.0, False)
 
     @property
     def storage(self):
@@ -1601,6 +1678,8 @@ class MultiModalTrajectoryModel(nn.Module):
         sub = (lambda b: dctx.sub(b)) if dctx is not None else (lambda b: None)
         self.lane_polygon_encoder.dctx, self.mllm.qformer.dctx, self.mllm.llama_wrapper.dctx = sub(0), sub(1), sub(2)
         self.ltsf.dctx = self.ltsf.attn_block.dctx = sub(3)
+        if getattr(self, "_auto_range", None) == "pending" and dev.type == "cuda" and self._llm_cache is None:
+            self._calibrate_range(vision_embs, context_str, input_ids, attention_mask, labels)
         # The lane-polygon encoder and the LLM-independent half of the LTSF (token projection, N-Linear
         # encoder, self-attention block) are chains of small launches that leave most CUs idle; they run
         # on a side stream, concurrently with the Q-Former / decoder stack, and join before the LTSF head.

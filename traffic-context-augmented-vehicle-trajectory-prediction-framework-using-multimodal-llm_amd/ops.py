@@ -315,9 +315,10 @@ def norm_npart(M, N, K):
     return int(lib().tcavt_norm_npart(int(M), int(N), int(K)))
 
 
-def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=None, npart=None):
+def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=None, npart=None, stream_scale=1.0):
     """h16 / part (both or neither): the 16-bit copy of h and its rows' partial sums of squares [rows, H / 64] -- the
-    inputs of the first decoder layer's fused RMSNorm (tcavt_llama_stack_forward)."""
+    inputs of the first decoder layer's fused RMSNorm (tcavt_llama_stack_forward).  stream_scale: h16 and part hold
+    stream_scale * h (tcavt_llama_stack_args.stream_scale)."""
     _req16(table, "embed.table")
     _req(ids, torch.int64, "embed.ids")
     _req(img, torch.float32, "embed.img")
@@ -342,7 +343,8 @@ def embed_fuse(table, ids, img, vis_mod, txt_mod, h, bad_flag, h16=None, part=No
         _need(h16, B * (Nq + Lt) * H, "embed.h16")
         _need(part, B * (Nq + Lt) * npart, "embed.part")
     check(lib().tcavt_embed_fuse(ptr(table), ptr(ids), ptr(img), ptr(vis_mod), ptr(txt_mod), ptr(h), B, Nq, Lt, H,
-                                 V, ptr(bad_flag), _DT[table.dtype], ptr(h16), ptr(part), npart if h16 is not None else 0, stream_ptr()),
+                                 V, ptr(bad_flag), _DT[table.dtype], ptr(h16), ptr(part), npart if h16 is not None else 0, float(stream_scale),
+                                 stream_ptr()),
           "tcavt_embed_fuse")
 
 
@@ -1001,7 +1003,7 @@ def rmsnorm16(x16, gamma, eps, out16=None, out_f32=None):
     return out16 if out_f32 is None else out_f32
 
 
-def rownorm_prep(x, x16, part, npart=None, rounded_sums=False):
+def rownorm_prep(x, x16, part, npart=None, rounded_sums=False, stream_scale=1.0):
     """x16 = 16-bit copy of x [M, H]; part [M, npart] = (row's sum of squares, 0, ...): inputs of a fused RMSNorm.
     rounded_sums: sums of the rounded values (16-bit residual stream)."""
     _req(x, torch.float32, "rownorm_prep.x")
@@ -1011,7 +1013,8 @@ def rownorm_prep(x, x16, part, npart=None, rounded_sums=False):
     npart = npart or H // 64
     _need(x16, M * H, "rownorm_prep.x16")
     _need(part, M * npart, "rownorm_prep.part")
-    check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], int(bool(rounded_sums)), stream_ptr()),
+    check(lib().tcavt_rownorm_prep(ptr(x), ptr(x16), ptr(part), M, H, npart, _DT[x16.dtype], int(bool(rounded_sums)), float(stream_scale),
+                                   stream_ptr()),
           "tcavt_rownorm_prep")
 
 

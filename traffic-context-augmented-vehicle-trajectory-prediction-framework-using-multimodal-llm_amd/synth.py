@@ -112,6 +112,30 @@ def make_batch(cfg: ModelConfig, batch: int, text_len: int = 240, seed: int = 0,
     }
 
 
+def batch_to_samples(batch):
+    """A collated batch (make_batch) taken apart into the per-sample dicts MultiModalTrajectoryDataset.__getitem__ returns
+    (scripts/train.py:281-299): trajectories [T, 2], ids / mask / labels cut to the row's valid length -- so that
+    data.custom_collate_fn(batch_to_samples(b)) reproduces b (used to feed a step from the host: bench.py --feed host)."""
+    import torch
+
+    out = []
+    for i in range(batch["traj_emb"].shape[0]):
+        n = max(1, int(batch["attention_mask"][i].sum()))
+        out.append({
+            "traj_emb": torch.from_numpy(np.ascontiguousarray(batch["traj_emb"][i].T)),
+            "target_traj": torch.from_numpy(np.ascontiguousarray(batch["target_traj"][i].T)),
+            "vision_emb": torch.from_numpy(batch["vision_emb"][i]),
+            "lane_polygon": torch.from_numpy(batch["lane_polygon"][i]),
+            "lane_polygon_len": int(batch["lane_polygon_len"][i]),
+            "norm_stat": tuple(float(v) for v in batch["norm_stat"][i]),
+            "context_str": f"A1: synthetic vehicle {i}.", "answer_str": "", "track_id": f"syn{i:04d}",
+            "input_ids": torch.from_numpy(batch["input_ids"][i, :n].copy()),
+            "attention_mask": torch.from_numpy(batch["attention_mask"][i, :n].copy()),
+            "labels": torch.from_numpy(batch["labels"][i, :n].copy()),
+        })
+    return out
+
+
 class SyntheticTokenizer:
     """Deterministic stand-in for the HF tokenizer the reference fetches by name (scripts/train.py:1056; no network here).
 
@@ -142,9 +166,24 @@ class SyntheticTokenizer:
     def encode(self, text):
         return [self.piece_id(p) for p in self._split.findall(text) if not p.isspace()]
 
-    def __call__(self, text, truncation=False, max_length=None, return_tensors=None, add_special_tokens=False, **kw):
+    def __call__(self, text, truncation=False, max_length=None, return_tensors=None, add_special_tokens=False,
+                 padding=False, **kw):
         import torch
 
+        if isinstance(text, (list, tuple)):
+            # batch form (train.py:557, 590-598): right-padded to the longest row with pad_token_id, mask 0 on the padding
+            rows = [self.encode(t) for t in text]
+            if truncation and max_length is not None:
+                rows = [r[:max_length] for r in rows]
+            n = max((len(r) for r in rows), default=0)
+            if not padding and any(len(r) != n for r in rows):
+                raise ValueError("rows of different lengths need padding=True")
+            ids = torch.full((len(rows), n), self.pad_token_id, dtype=torch.long)
+            mask = torch.zeros((len(rows), n), dtype=torch.long)
+            for i, r in enumerate(rows):
+                ids[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+                mask[i, :len(r)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
         ids = self.encode(text)
         if truncation and max_length is not None:
             ids = ids[:max_length]

@@ -122,10 +122,14 @@ class Trainer:
             model._side = model.ltsf._kv_stream = model.mllm._pf_stream = None  # (re-drawn from the pool on next use)
             if self.world == 1:
                 self._fake_dp = torch.cuda.Stream(device=dev)
-        self.exchange = True   # False: skip the gradient exchange (bench.py's same-build single-rank comparison leg)
+        # Measurement only (bench.py's same-build single-rank comparison leg): local_steps() switches the gradient exchange off
+        # for a few steps and re-synchronises the replicas afterwards -- without the exchange every rank steps on its own
+        # gradients and the replicas drift apart, which nothing else would ever repair (only gradients are exchanged)
+        self._exchange = True
         self.diag = None       # enable_diagnostics(): per-bucket all-reduce timings of the steps that follow
         self._ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # device-side step counters of the gated optimizer
         self._last_loss = None
+        self._skipped_seen = 0  # check_flags(): gated-optimizer skips already reported
         # hipGraph replay of the whole step (capture()): the optimizer's step count and the dropout epoch live on the device
         self.device_step = False
         self._finite = torch.zeros(1, dtype=torch.float32, device=dev)  # an always-finite "loss" for the un-gated loop
@@ -133,6 +137,24 @@ class Trainer:
         if self.world > 1 and sync_initial_state:
             self.broadcast_state()
         model.invalidate_prepared()
+
+    def local_steps(self):
+        """Context manager (measurement only): inside it the gradient exchange is skipped -- each rank steps on its own
+        gradients, scaled by 1 / world as usual.  On exit rank 0's parameters and optimizer moments are broadcast again, so
+        the data-parallel job continues from ONE state (what the ranks did inside is discarded everywhere but on rank 0)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            self._exchange = False
+            try:
+                yield self
+            finally:
+                self._exchange = True
+                if self.world > 1:
+                    torch.cuda.synchronize()
+                    self.broadcast_state()
+        return ctx()
 
     def broadcast_state(self, src=0):
         """Rank `src`'s model parameters (frozen ones included) and optimizer moments to every rank: ranks that built or
@@ -152,7 +174,7 @@ class Trainer:
         """SUM all-reduce of grads[lo:hi], launched from the current stream (the one that completed the bucket); the mean is
         taken by the clip / AdamW kernels.  torch.distributed runs it on the process group's own RCCL stream, ordered after
         the current stream, and makes the current stream wait for it."""
-        if (self.world == 1 and self._fake_dp is None) or not self.exchange:
+        if (self.world == 1 and self._fake_dp is None) or not self._exchange:
             return
         view = self.book.grads[lo:hi]
         if self.diag is not None and self._fake_dp is None:
@@ -175,23 +197,27 @@ class Trainer:
 
     # ---- one optimisation step -----------------------------------------------------------------
     def forward_backward(self, x, vision_embs, lane_polygon_batch, lane_polygon_len, y, norm_stat, input_ids,
-                         attention_mask, labels=None, next_vision_embs=None, inputs_ready=None):
+                         attention_mask, labels=None, next_vision_embs=None, inputs_ready=None, next_ready=None):
         """zero_grad + forward + backward (+ bucketed all-reduce); gradients end up in ``self.book.g``.
         next_vision_embs (optional): the next batch's vision embeddings, already resident -- its frozen Q-Former is
         enqueued on a side stream between this step's forward and backward (model.prefetch) and runs under this step's
         decoder; results are identical with or without it.
         inputs_ready: see MultiModalTrajectoryModel.forward (pipelined decoder of the frozen-MLLM variant: an event /
-        True lets this step's decoder start under the previous step's head, backward and optimizer)."""
+        True lets this step's decoder start under the previous step's head, backward and optimizer).  An event (the copy that
+        uploaded the batch: data.DeviceFeeder) is also waited for by the caller's stream, which reads the head's inputs.
+        next_ready: the same for next_vision_embs (the event of ITS upload), handed to the Q-Former prefetch."""
         m = self.model
         with torch.no_grad():
             self.book.grads.zero_()  # optimizer.zero_grad()
+            if isinstance(inputs_ready, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(inputs_ready)
             m.inputs_ready = inputs_ready
             loss, decoded = m(x, vision_embs, None, lane_polygon_batch, lane_polygon_len, y=y, norm_stat=norm_stat,
                               input_ids=input_ids, attention_mask=attention_mask, labels=labels)
             ns = norm_stat if torch.is_tensor(norm_stat) else torch.tensor([list(n) for n in norm_stat])
             ns = ns.to(device=x.device, dtype=torch.float32).contiguous()
             if next_vision_embs is not None and not self.train_mllm_front:
-                m.prefetch(next_vision_embs)  # before the backward: its leaf work shares the prefetch stream's queue
+                m.prefetch(next_vision_embs, ready=next_ready)  # before the backward: its leaf work shares the prefetch stream's queue
             B, L = input_ids.shape[0], m.mllm.qformer.num_query_tokens + input_ids.shape[1]
             fh_b = m.last.final_hidden_bf16  # [B * L + 64 zeroed pad rows, H]
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
@@ -353,9 +379,22 @@ class Trainer:
         }
 
     def check_flags(self):
-        """Raise if any forward since the last check saw input_ids outside the vocabulary or a mask that is not a
-        right-padded prefix (the kernels only SET the device flags; one host sync here)."""
+        """Raise if any forward since the last check saw input_ids outside the vocabulary, a mask that is not a right-padded
+        prefix or a 16-bit value outside its range (the kernels only SET the device flags; one host sync here) -- and WARN when the
+        gated optimizer has skipped updates since the last check (modify_train.py:1190-1196 skips a step on a non-finite loss;
+        here a non-finite gradient norm does the same, e.g. an fp16 gradient that left the half range under the step's
+        power-of-two scale: every step skipped is a step not trained, and nothing else would say so)."""
         self.model.mllm.check_flags()
+        if self.skip_nonfinite or self.device_step:
+            applied, skipped = self.optimizer_counters()
+            if skipped > self._skipped_seen:
+                import warnings
+
+                warnings.warn(f"Trainer: {skipped - self._skipped_seen} optimizer update(s) skipped since the last check "
+                              f"({skipped} of {applied + skipped} in all): non-finite loss or gradient norm -- with fp16 storage try "
+                              "model.set_storage(torch.bfloat16) (bf16 tapes and gradients: no range limit, 8 significant bits)",
+                              RuntimeWarning, stacklevel=2)
+                self._skipped_seen = skipped
 
     def step(self, *args, **kw):
         out = self.forward_backward(*args, **kw)

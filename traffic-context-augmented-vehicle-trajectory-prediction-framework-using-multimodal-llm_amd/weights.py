@@ -163,6 +163,27 @@ def make_weights(cfg: ModelConfig, seed: int = 0, backend: str = "numpy", device
     return g.out
 
 
+def plant_outliers(weights, cfg: ModelConfig, magnitude: float, channels=None):
+    """Weight variant with two OUTLIER hidden channels in the decoder's residual stream.
+
+    Real Llama checkpoints (scripts/train.py:427-431 loads one) carry a few hidden channels whose activations sit orders of
+    magnitude above the bulk of the stream, nearly constant over the tokens; the N(0, sigma) weights of make_weights never
+    do (largest |stream| ~ 10).  Here both modality embeddings (train.py:497-498: added to EVERY fused-sequence token) get
+    +magnitude in one channel and -0.7 magnitude in another, so every token's residual stream starts -- and, the residual
+    adds being small beside it, stays -- at that level in those channels.  The parameters themselves are fp32 in the HIP path
+    too (embed_fuse adds them in fp32), so a magnitude beyond fp16's 65504 is a statement about ACTIVATION range only.
+    Used by the range tests (tests/test_range_gpu.py: 3e4 fits the plain fp16 stream, 2e5 needs set_storage("auto"))."""
+    H = cfg.llama.hidden
+    c0, c1 = channels or (H // 5, (3 * H) // 4 + 1)
+    out = dict(weights)
+    for k in ("mllm.vision_modality_embedding", "mllm.text_modality_embedding"):
+        v = out[k].clone() if hasattr(out[k], "clone") else np.array(out[k], copy=True)
+        v[..., c0] = magnitude
+        v[..., c1] = -0.7 * magnitude
+        out[k] = v
+    return out
+
+
 def is_lora_key(name):
     return ".lora_A." in name or ".lora_B." in name
 
