@@ -392,7 +392,7 @@ def test_gemm_w4_persistent_stream(gpu):
 
     dev = gpu["device"]
     M, N = 4096, 4608
-    for K in (64, 192):
+    for K in (64, 192, 320):
         g = torch.Generator(device="cpu").manual_seed(K)
         a = _bf(torch.randn(M, K, generator=g)).to(dev)
         w = _bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
@@ -401,6 +401,16 @@ def test_gemm_w4_persistent_stream(gpu):
             r8 = ops.gemm_bf16(a, w, out_dtype=dt, tile=256, **kw)
             r4 = ops.gemm_bf16(a, w, out_dtype=dt, tile=257, **kw)
             assert torch.equal(r8, r4), (K, sorted(kw))
+            # the two-barrier deep-prefetch form (272) walks its tiles as one K-tile stream too (round 4; K >= 128: the
+            # look-ahead reaches two K-tiles ahead) -- except with the generic epilogue, which stays one workgroup per tile
+            r4d = ops.gemm_bf16(a, w, out_dtype=dt, tile=272, **kw)
+            assert torch.equal(r8, r4d), (K, sorted(kw), "deep")
+        # fp16 operands, the decoder's forms: SiLU * up with the fused row scale stays covered by the model-level tests; here
+        # the in-place 16-bit residual epilogue through the persistent deep form against the one-barrier form
+        a16, w16 = a.float().half(), w.float().half()
+        r_a = ops.gemm_bf16(a16, w16, out_dtype=torch.float16, tile=257, silu_mul=True)
+        r_b = ops.gemm_bf16(a16, w16, out_dtype=torch.float16, tile=272, silu_mul=True)
+        assert torch.equal(r_a, r_b), (K, "fp16 silu deep")
         ref = a.float() @ w.float().T
         assert _rel(ops.gemm_bf16(a, w, out_dtype=torch.float32, tile=257), ref) < 2e-6
 

@@ -92,7 +92,7 @@ def test_outliers_beyond_fp16_flag_the_plain_stream_and_auto_picks_a_contract_th
     m.mllm.check_flags()
     e_dec, e_fh = rel_err(dec.cpu(), dec32), rel_err(m.last.final_hidden.float().cpu(), fh32)
     print(f"[range case 2] fp32 stream, 16-bit copy at 2^-4: decoded vs fp32 {e_dec:.2e}, final_hidden {e_fh:.2e}")
-    assert e_dec < 1e-3 and e_fh < 1e-3
+    assert e_dec < 1e-3 and e_fh < 2e-3
 
 
 @pytest.mark.parametrize("case", ["tiny_6_12_lora_ragged", "tiny_18_30_nolora_ragged"])

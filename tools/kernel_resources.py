@@ -14,7 +14,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-std=c++
 
 
 def demangle(names):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+    import shutil
+
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
+    if tool is None:
+        return names
+    out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True)
     return out.stdout.splitlines() if out.returncode == 0 else names
 
 

@@ -1232,6 +1232,13 @@ __device__ __forceinline__ void mfma_agpr(f32x4& c, const bf16x8& a, const bf16x
 // instead of global_load ... lds (64-bit per-lane address, two VALU ops per piece).
 // BN = 256: 2 x 2 waves of 128 x 128.  BN = 192: 4 x 1 waves of 64 x 192 (4 x 12 MFMA tiles, 192 accumulator
 // registers) for N = 3072 (fused q|k|v): 512 tiles = two full waves of 256 CUs instead of 384 = one and a half.
+// Instantiations that may run persistently (one workgroup per CU walking its tiles as one K-tile stream): not the buffer-load
+// experiment; not RoPE (falls apart into 1.7 KB of scratch with it); not the generic epilogue in the two-barrier DEEP form
+// (DBG & 64: 924 bytes of scratch with it -- the backward's long-K dgrad GEMMs are one tile per CU anyway).
+constexpr bool w4_pers_ok(int epi, int dbg, bool buf) {
+  return !buf && epi != EPI_ROPE && !((dbg & 64) && epi == EPI_GENERIC);
+}
+
 template <int EPI, int B2R, int DBG = 0, bool BUF = false, int BN = 256, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   constexpr int BM = 256, NW = 4;
@@ -1265,7 +1272,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   // Persistent form (p.pers_tiles > 0): this workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... as ONE stream of
   // K-tiles -- the look-ahead of the pipeline (fragments of the next K-tile, DMA of the next two) simply continues into
   // the next output tile, so its first operands arrive while this tile's epilogue runs (no per-tile prologue).
-  constexpr bool PERS_OK = !BUF && !DEEP && EPI != EPI_ROPE;  // (the RoPE instantiation falls apart into scratch with it: 1.7 KB)
+  // (round 4: the two-barrier DEEP form walks its tiles as one K-tile stream as well -- it used to start every output tile with a
+  //  burst prologue, which is what it lost to the one-barrier form at K = 2048, 8 tiles per CU)
+  constexpr bool PERS_OK = w4_pers_ok(EPI, DBG, BUF);
   const bool pers = PERS_OK && p.pers_tiles > 0;
   const int total_tiles = pers ? p.pers_tiles : (int)gridDim.x;
   int vb = blockIdx.x;
@@ -1431,12 +1440,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
         }
         if constexpr (DEEP) {
           if (idx == 0) {
-            const int tt = min(t + 2, nt - 1);
-            second2 = HASK2 && tt >= nt1;
+            into_next2 = PERS_OK && has_next && t + 2 >= nt;   // the look-ahead crosses into the next output tile
+            const int tt = into_next2 ? t + 2 - nt : min(t + 2, nt - 1);  // clamp: see tsrc
+            second2 = HASK2 && !into_next2 && tt >= nt1;
             koff2 = (second2 ? tt - nt1 : tt) * 64;
           }
-          if (idx == 3) sn2.a = (second2 ? srcA2 : srcA) + koff2;
-          if (idx == 6) sn2.w = (second2 ? srcW2 : srcW) + koff2;
+          if (idx == 3) sn2.a = (into_next2 ? nxtA : second2 ? srcA2 : srcA) + koff2;
+          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + koff2;
           if (idx == 9) {
             sn2.sa = second2 ? stepA2 : stepA;
             sn2.sw = second2 ? stepW2 : stepW;
@@ -1518,7 +1528,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   for (;;) {
     for (int t = 0; t < nt; ++t) ktile(T_{}, T_{}, t);
     // the accumulators are read by VALU next: cover the MFMA write latency the compiler cannot see behind the asm
-    if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ... and pin every accumulator read behind those nops: an empty volatile asm that redefines the register is
     // ordered after the s_nop asm, and the epilogue's v_accvgpr_read depends on it (without this the scheduler is
@@ -1550,7 +1559,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
     __builtin_amdgcn_sched_barrier(0);
     gemm_epilogue<TM, TN, EPI, true, F16>(p, acc, em0 + wm * TM * 16, en0 + wn * TN * 16, lane,
                                           (RS && p.rs_part) ? rs_base + rs_sel * 256 + wm * TM * 16 : nullptr);
-    if (!cont) break;
+    if (!cont) {
+      if constexpr (DEEP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA (the clamped re-fetches) may outlive the workgroup
+      break;
+    }
     rs_sel ^= 1;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -1629,7 +1641,7 @@ static int launch_w4(const GemmP& p0, hipStream_t stream) {
   int wgs = tiles;
   p.pers_tiles = 0;
   // (the two-K-tile look-ahead may reach into the NEXT output tile only: at least two K-tiles per tile)
-  if (!BUF && !(DBG & 64) && EPI != EPI_ROPE && !no_pers && n_cu >= 8 && tiles > n_cu && p.K + p.K2 >= 128) {
+  if (w4_pers_ok(EPI, DBG, BUF) && !no_pers && n_cu >= 8 && tiles > n_cu && p.K + p.K2 >= 128) {
     p.pers_tiles = tiles;
     wgs = n_cu;
   }
@@ -2457,7 +2469,9 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       }
       // long K (down projection, K = 8192): the two-barrier form with a whole K-tile of DMA in flight (190 vs 200 us);
       // neutral to slightly worse at K = 2048
-      if (tile == 257 && !(epi & TCAVT_EPI_ROPE) && a->K >= 4096) tile = 272;
+      // (TCAVT_GEMM_DEEP_MINK=<K>: A/B switch for the threshold)
+      static const int deep_mink = [] { const char* e = getenv("TCAVT_GEMM_DEEP_MINK"); return e ? atoi(e) : 4096; }();
+      if (tile == 257 && !(epi & TCAVT_EPI_ROPE) && a->K >= deep_mink) tile = 272;
     }
   }
   if (epi & TCAVT_EPI_SILU_MUL) {
