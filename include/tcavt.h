@@ -630,9 +630,9 @@ typedef struct tcavt_llama_stack_args {
                                       tcavt_rownorm_prep with the same value) and every 16-bit image of the residual stream is kept at
                                       that scale (tcavt_gemm_args.norm_scale): the overflow limit of an fp16 stream moves from 65504 to
                                       65504 / stream_scale at no cost in precision.  The fused norms run with eps * stream_scale^2; the adapters'
-                                      un-normalised t = lora_scale * (stream_scale x) . A^T has the stream's range and stays at its scale:
-                                      the caller's b_ext must hold lora_B / stream_scale.  out_f32 / out16 are the true-scale final hidden
-                                      states.  Not with a tape (the backward reads the streams at scale 1) */
+                                      un-normalised t = lora_scale * (stream_scale x) . A^T is at the stream's scale like the main term of the
+                                      q|k|v accumulator, and the row scale takes it out of both.  out_f32 / out16 are the true-scale final
+                                      hidden states.  Not with a tape (the backward reads the streams at scale 1) */
   float rms_eps, lora_scale;       /* lora_scale = alpha / r */
   float lora_dropout_p;            /* > 0: train mode; sites first_site + 2 l (q_proj), first_site + 2 l + 1 (v_proj) */
   uint32_t lora_first_site;
@@ -1001,9 +1001,16 @@ typedef struct tcavt_sample_params {
  * penalty and the n-gram ban look at (prompt ids + generated); *step (device int32): index of the token being chosen --
  * out_tokens[b][*step] receives it, cur_tok[b] too, the history grows by it, pos[b] += 1 when advance_pos != 0,
  * finished[b] is set on EOS, and *step is incremented at the end. */
+/* workspace (optional; tcavt_sample_workspace_bytes(B) bytes, 16-byte aligned, its first 64 + 4 B bytes ZEROED ONCE by the caller:
+ * every call leaves them zero): the two-stage form -- B x 16 workgroups process and pre-select slices of the vocabulary that
+ * they hold in registers, one workgroup per sample merges, ranks and draws; *step is advanced by the same launch.  The token
+ * selected is the one the one-stage form (workspace NULL: one workgroup per sample, three passes over the row) selects.
+ * Calls that share a workspace must be stream-ordered. */
+int64_t tcavt_sample_workspace_bytes(int B);
 int tcavt_sample_logits(float* logits, int B, int V, int64_t* history, int hist_cap, int32_t* hist_len,
                         const tcavt_sample_params* params, int32_t* step, int64_t* cur_tok, int32_t* pos,
-                        int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos, tcavt_stream_t stream);
+                        int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos, void* workspace,
+                        int64_t workspace_bytes, tcavt_stream_t stream);
 
 /* out16[b] = src16[b * L + kv_len[b] - 1]: 16-bit rows of width H */
 int tcavt_gather_last(const void* src16, const int32_t* kv_len, void* out16, int B, int L, int H, tcavt_stream_t stream);

@@ -298,7 +298,7 @@ def llama_decoder(W, cfg, embeds, attn_mask, r, collect=None, drop=_ident):
             xq = hb if drop is _ident else r(drop(hb), "xn")
             xv = hb if drop is _ident else r(drop(hb), "xn")
             # (t is un-normalised -- the row scale multiplies the whole accumulator -- so it has the stream's range and is kept
-            #  at the stream's scale: rounded as ss * t, the packed lora_B carrying 1 / ss)
+            #  at the stream's scale: rounded as ss * t, like the main term ss * x W^T of the accumulator it joins)
             tq = r(ss * s * (xq @ r(W[P + "self_attn.q_proj.lora_A.weight"] * g1, "w").T), "t") / ss
             tv = r(ss * s * (xv @ r(W[P + "self_attn.v_proj.lora_A.weight"] * g1, "w").T), "t") / ss
             q = q + tq @ r(W[P + "self_attn.q_proj.lora_B.weight"], "w").T

@@ -120,3 +120,53 @@ def test_eos_pads_the_rest_and_sampling_is_reproducible(gpu):
     c = m.mllm.generate_batch(g["vision_emb"], None, do_sample=True, seed=6, **kw).cpu()
     assert torch.equal(a, b) and not torch.equal(a, c)  # a pure function of the seed; graph replay == eager
     assert ((a >= 0) & (a < cfg.llama.vocab)).all()
+
+
+@pytest.mark.parametrize("V", [512, 128256, 50000])
+def test_two_stage_token_selection_equals_the_one_stage_form(gpu, V):
+    """tcavt_sample_logits with a workspace (B x 16 slice workgroups + one merging workgroup per sample, round 4) selects the
+    SAME token and leaves the same processed logits and device state as the one-workgroup form, on rows built to be awkward:
+    heavy ties at the top, a constant row (every slice's threshold bin overflows -> the per-sample fallback), a row with three
+    finite scores, a row that is all -inf but one, penalties and bans that hit tokens in different slices; sampling and greedy."""
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(V)
+    R = 6
+    base = torch.randn(R, V, generator=g) * 3.0
+    base[1] = torch.round(base[1] * 2) / 2                      # many exact ties, also at the k-th value
+    base[2] = 1.25                                              # constant: overflow of every slice list
+    base[3] = float("-inf"); base[3, [5, V // 2, V - 1]] = torch.tensor([0.5, 2.0, 2.0])
+    base[4] = float("-inf"); base[4, V - 3] = -7.0
+    base[5, V // 3: V // 3 + 300] = base[5].max() + 1.0         # a plateau at the top wider than top_k
+    cap = 40
+    hist0 = torch.randint(0, V, (R, cap), generator=g)
+    hist0[:, 30:] = 0
+    hist0[0, :30] = torch.arange(30) % 7 + (V - 8)              # repeats + 3-gram matches in the last slice
+    hl0 = torch.full((R,), 30, dtype=torch.int32)
+    for do_sample, top_k, rep, ngram in ((1, 40, 1.2, 3), (1, 1, 1.0, 0), (1, 256, 1.3, 2), (0, 40, 1.2, 3), (0, 40, 1.0, 0)):
+        res = []
+        for two_stage in (False, True):
+            logits = base.clone().to(dev)
+            hist = hist0.clone().to(dev)
+            hist_len = hl0.clone().to(dev)
+            step = torch.full((1,), 3, dtype=torch.int32, device=dev)
+            cur = torch.zeros(R, dtype=torch.int64, device=dev)
+            pos = torch.zeros(R, dtype=torch.int32, device=dev)
+            fin = torch.zeros(R, dtype=torch.int32, device=dev)
+            out = torch.full((R, 8), -1, dtype=torch.int64, device=dev)
+            sp = capi.SampleParams(0.9, 0.9, rep, top_k, ngram, do_sample, -1, 0, 1234)
+            wsp = ops.sample_workspace(R, dev) if two_stage else None
+            for _ in range(2):  # two calls in a row: the workspace's control words are left re-armed, *step advances once per call
+                ops.sample_logits(logits, hist, hist_len, sp, step, cur, pos, fin, out, advance_pos=True, workspace=wsp)
+            torch.cuda.synchronize()
+            res.append((logits.cpu(), hist.cpu(), hist_len.cpu(), step.item(), cur.cpu(), pos.cpu(), out.cpu()))
+            if two_stage:
+                assert int(wsp[:64 + 4 * R].sum().item()) == 0  # ticket and overflow words back to zero
+        a, b = res
+        assert a[3] == b[3] == 5
+        for x, y, nm in zip(a, b, ("logits", "history", "hist_len", "step", "cur", "pos", "out")):
+            if nm == "logits":
+                assert torch.equal(torch.isinf(x), torch.isinf(y)) and torch.equal(torch.nan_to_num(x, neginf=0.0), torch.nan_to_num(y, neginf=0.0)), (do_sample, top_k)
+            elif nm != "step":
+                assert torch.equal(x, y), (nm, do_sample, top_k, rep, ngram)

@@ -296,7 +296,8 @@ _SIGNATURES = {
                     c_int, c_float, c_void_p],
     "tcavt_llama_stack_forward": [ctypes.POINTER(LlamaStackArgs), c_void_p],
     "tcavt_sample_logits": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, ctypes.POINTER(SampleParams), c_void_p, c_void_p,
-                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p],
+    "tcavt_sample_workspace_bytes": [c_int],
     "tcavt_gather_last": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_llama_decode_step": [ctypes.POINTER(DecodeArgs), c_void_p],
     "tcavt_norm_npart": [c_int, c_int, c_int],
@@ -318,7 +319,7 @@ _SIGNATURES = {
     "tcavt_adamw_gated": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                           c_float, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPES = {"tcavt_last_error": ctypes.c_char_p}
+_RESTYPES = {"tcavt_last_error": ctypes.c_char_p, "tcavt_sample_workspace_bytes": c_int64}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

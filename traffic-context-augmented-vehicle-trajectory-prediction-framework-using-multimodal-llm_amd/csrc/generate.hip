@@ -194,11 +194,218 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {  // (
   return v > bv || (v == bv && i < bi);
 }
 
+// ---------------------------------------------------------------------------
+// Two-stage form (round 4; tcavt_sample_logits with a workspace): one workgroup per sample walks 128 256 logits in three
+// dependent passes -- 64 us on 8 of 256 CUs at B = 8, latency bound.  Stage 1 cuts every sample's vocabulary into SMP_G
+// contiguous slices, one workgroup each (B x 16 workgroups): the slice's processors (a token's penalty / ban is applied by the
+// workgroup that owns the token), then the slice's <= 8 scores per thread live in REGISTERS and the three passes (max / min,
+// histogram, collection) cost no further memory traffic; out come the slice's candidates -- everything at or above the slice's
+// own top-k threshold bin -- and the smallest of them, lb: at least k scores of the slice are >= lb, so the sample's k-th
+// largest score is >= lb too.  Stage 2 (sample_kernel with `pre`) keeps the candidates >= max over the slices of lb (a superset
+// of the global top-k and of every tie with the k-th value), and ranks / keeps / draws exactly as the one-stage form does:
+// the selected token is the same.  A slice whose threshold bin overflows its list (e.g. constant logits) raises ovf[b] and the
+// sample falls back to the three passes of the one-stage form (its processors are done).
+// ---------------------------------------------------------------------------
+constexpr int SMP_G = 16;      // slices (stage-1 workgroups) per sample
+constexpr int SMP_LCAP = 512;  // candidates per slice
+constexpr int SMP_E4 = 4;      // f32x4 registers per thread: slices of up to 4 * 1024 * 4 scores (V <= 262 144)
+
+struct SliceWs {  // views into the caller's workspace (tcavt_sample_logits: layout and size)
+  int* ticket;    // [1]   stage 2: workgroups that have read *step (the last one increments it); zero between calls
+  int* ovf;       // [B]   a slice of the sample overflowed its list; zero between calls
+  int* cand_n;    // [B][G]
+  float* lb;      // [B][G]
+  float* cand_v;  // [B][G][SMP_LCAP]
+  int* cand_i;    // [B][G][SMP_LCAP]
+};
+
+__global__ __launch_bounds__(SMP_T) void sample_slice_kernel(float* __restrict__ logits, int V, const long* __restrict__ history,
+                                                             int hist_cap, const int* __restrict__ hist_len, SampleP sp, SliceWs ws) {
+  __shared__ int hist_bins[SMP_BINS];
+  __shared__ float lv[SMP_LCAP];
+  __shared__ int li[SMP_LCAP];
+  __shared__ float rv[SMP_T / 64], rm[SMP_T / 64];
+  __shared__ int ri[SMP_T / 64];
+  __shared__ float s_max, s_min;
+  __shared__ int s_bi, list_n, thr_bin;
+  const int b = blockIdx.x / SMP_G, g = blockIdx.x % SMP_G, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* x = logits + (long)b * V;
+  const long* hist = history + (long)b * hist_cap;
+  const int hl = min(hist_len[b], hist_cap);
+  const int V4 = V >> 2, chunk4 = (V4 + SMP_G - 1) / SMP_G;
+  const int lo4 = g * chunk4, hi4 = min(lo4 + chunk4, V4);
+  const long lo = 4L * lo4, hi = 4L * hi4;
+  // ---- processors, for the tokens this slice owns (same arithmetic and order as the one-stage form: penalty, then ban)
+  if (sp.rep_penalty != 1.f) {
+    const bool in_lds = hl <= SMP_LCAP;
+    if (in_lds) {
+      for (int i = tid; i < hl; i += SMP_T) li[i] = (int)min(max(hist[i], -1L), 0x7fffffffL);
+      __syncthreads();
+    }
+    for (int i = tid; i < hl; i += SMP_T) {
+      const long t = hist[i];
+      bool first = t >= lo && t < hi;
+      if (in_lds) {
+        for (int j = 0; j < i && first; ++j) first = li[j] != (int)t;
+      } else {
+        for (int j = 0; j < i && first; ++j) first = hist[j] != t;
+      }
+      if (first) {
+        const float s_ = x[t];
+        x[t] = s_ < 0.f ? s_ * sp.rep_penalty : s_ / sp.rep_penalty;
+      }
+    }
+    __syncthreads();
+  }
+  const int ng = sp.no_repeat_ngram;
+  if (ng > 0 && hl + 1 >= ng) {
+    for (int i = tid; i + ng - 1 < hl; i += SMP_T) {
+      bool match = true;
+      for (int k = 0; k < ng - 1 && match; ++k) match = hist[i + k] == hist[hl - (ng - 1) + k];
+      const long t = hist[i + ng - 1];
+      if (match && t >= lo && t < hi) x[t] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  // ---- the slice, in registers (scaled by 1 / temperature when sampling: the order of the scores is what counts)
+  const float sc = sp.do_sample ? 1.f / sp.temperature : 1.f;
+  f32x4 v4[SMP_E4];
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+#pragma unroll
+  for (int e = 0; e < SMP_E4; ++e) {
+    const int i4 = lo4 + tid + e * SMP_T;
+    v4[e] = i4 < hi4 ? x4[i4] * sc : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // (a padding -inf never precedes a real entry: its index is larger)
+  }
+  // best (value desc, index asc) and smallest finite score of the slice
+  float bv = -INFINITY, lmin = INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int e = 0; e < SMP_E4; ++e) {
+    const int i4 = lo4 + tid + e * SMP_T;
+    if (i4 < hi4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = v4[e][c];
+        const int i = 4 * i4 + c;
+        if (better(v, i, bv, bi)) { bv = v; bi = i; }
+        if (v > -INFINITY) lmin = fminf(lmin, v);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  lmin = -wave_max(-lmin);
+  if (lane == 0) { rv[wv] = bv; ri[wv] = bi; rm[wv] = lmin; }
+  __syncthreads();
+  if (tid == 0) {
+    float v = rv[0], m_ = rm[0];
+    int i = ri[0];
+    for (int k = 1; k < SMP_T / 64; ++k) {
+      if (better(rv[k], ri[k], v, i)) { v = rv[k]; i = ri[k]; }
+      m_ = fminf(m_, rm[k]);
+    }
+    s_max = v; s_bi = i; s_min = m_;
+    list_n = 0;
+  }
+  for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
+  __syncthreads();
+  const long slot0 = ((long)b * SMP_G + g) * SMP_LCAP;
+  if (!sp.do_sample) {  // greedy: the slice's first maximum
+    if (tid == 0) {
+      ws.cand_v[slot0] = s_max;
+      ws.cand_i[slot0] = s_bi;
+      ws.cand_n[b * SMP_G + g] = 1;
+      ws.lb[b * SMP_G + g] = -INFINITY;
+    }
+    return;
+  }
+  const float gmax = s_max;
+  if (!(gmax > -INFINITY)) {  // (uniform) nothing finite in this slice
+    if (tid == 0) { ws.cand_n[b * SMP_G + g] = 0; ws.lb[b * SMP_G + g] = -INFINITY; }
+    return;
+  }
+  const float bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - s_min, 1e-20f);
+  const int k = min(max(sp.top_k, 1), SMP_CAP);
+#pragma unroll
+  for (int e = 0; e < SMP_E4; ++e) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = (gmax - v4[e][c]) * bscale;
+      if (d < (float)SMP_BINS) atomicAdd(&hist_bins[(int)d], 1);  // (-inf: d = +inf, skipped)
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {  // first bin at which the running count reaches k (as in the one-stage form)
+    constexpr int PER = SMP_BINS / 64;
+    int loc = 0;
+#pragma unroll 8
+    for (int t_ = 0; t_ < PER; ++t_) loc += hist_bins[lane * PER + ((t_ + lane) & (PER - 1))];
+    int pre = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(pre, o, 64);
+      if (lane >= o) pre += up;
+    }
+    const bool hit = pre >= k && pre - loc < k;
+    if (__builtin_amdgcn_ballot_w64(hit) == 0ull) {
+      if (lane == 0) thr_bin = -1;  // fewer than k finite scores in the slice: all of them are candidates, no bound
+    } else if (hit) {
+      int cum = pre - loc, tb = lane * PER;
+      for (int t_ = 0; t_ < PER; ++t_) {
+        cum += hist_bins[lane * PER + t_];
+        if (cum >= k) { tb = lane * PER + t_; break; }
+      }
+      thr_bin = cum <= SMP_LCAP ? tb : -2;  // -2: the threshold bin overflows the slice's list
+    }
+  }
+  __syncthreads();
+  const int tb = thr_bin;
+  if (tb == -2) {  // (uniform)
+    if (tid == 0) { atomicOr(&ws.ovf[b], 1); ws.cand_n[b * SMP_G + g] = 0; ws.lb[b * SMP_G + g] = -INFINITY; }
+    return;
+  }
+  const float lim = tb < 0 ? (float)SMP_BINS : (float)(tb + 1);
+  float mymin = INFINITY;
+#pragma unroll
+  for (int e = 0; e < SMP_E4; ++e) {
+    const int i4 = lo4 + tid + e * SMP_T;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = v4[e][c];
+      if ((gmax - v) * bscale < lim) {
+        const int slot = atomicAdd(&list_n, 1);
+        if (slot < SMP_LCAP) { lv[slot] = v; li[slot] = 4 * i4 + c; }
+        mymin = fminf(mymin, v);
+      }
+    }
+  }
+  mymin = -wave_max(-mymin);
+  if (lane == 0) rm[wv] = mymin;
+  __syncthreads();
+  const int n = min(list_n, SMP_LCAP);  // (tb >= 0: list_n = the running count at the threshold bin <= SMP_LCAP; tb < 0: < k <= SMP_CAP)
+  for (int t_ = tid; t_ < n; t_ += SMP_T) {
+    ws.cand_v[slot0 + t_] = lv[t_];
+    ws.cand_i[slot0 + t_] = li[t_];
+  }
+  if (tid == 0) {
+    float m_ = rm[0];
+    for (int w_ = 1; w_ < SMP_T / 64; ++w_) m_ = fminf(m_, rm[w_]);
+    ws.cand_n[b * SMP_G + g] = n;
+    ws.lb[b * SMP_G + g] = tb >= 0 ? m_ : -INFINITY;  // (>= k scores of the slice are >= the smallest collected one)
+  }
+}
+
+// `pre` (ws.cand_v != nullptr): stage 2 of the two-stage form -- the processors are done and the candidates come from the slices
 __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logits, int V, long* __restrict__ history,
                                                        int hist_cap, int* __restrict__ hist_len, SampleP sp,
                                                        int* __restrict__ step_p, long* __restrict__ cur_tok,
                                                        int* __restrict__ pos, int* __restrict__ finished,
-                                                       long* __restrict__ out_tokens, int out_cap, int advance_pos) {
+                                                       long* __restrict__ out_tokens, int out_cap, int advance_pos, SliceWs ws,
+                                                       int n_samples) {
   __shared__ float cv[SMP_CAP];
   __shared__ int ci[SMP_CAP];
   __shared__ float rv[SMP_T / 64];
@@ -215,8 +422,16 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   long* hist = history + (long)b * hist_cap;
   const int hl = min(hist_len[b], hist_cap);
   const int step = *step_p;
+  const bool pre = ws.cand_v != nullptr;
+  __shared__ int s_ovf;
+  if (pre) {
+    if (tid == 0) s_ovf = ws.ovf[b];
+    __syncthreads();
+    if (tid == 0 && s_ovf) ws.ovf[b] = 0;  // (re-armed for the next call)
+  }
+  const bool pre_ok = pre && s_ovf == 0;  // (uniform) the slices' candidates are complete
   // ---- repetition penalty: once per distinct token of the history (scatter semantics of the reference processor)
-  if (sp.rep_penalty != 1.f) {
+  if (!pre && sp.rep_penalty != 1.f) {
     // (the history is staged in LDS when it fits: thread i compares its token with all earlier ones)
     const bool in_lds = hl <= SMP_LIST;
     if (in_lds) {
@@ -240,7 +455,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   }
   // ---- no-repeat n-gram: ban every token that would complete an n-gram already in the history
   const int ng = sp.no_repeat_ngram;
-  if (ng > 0 && hl + 1 >= ng) {
+  if (!pre && ng > 0 && hl + 1 >= ng) {
     for (int i = tid; i + ng - 1 < hl; i += SMP_T) {
       bool match = true;
       for (int k = 0; k < ng - 1 && match; ++k) match = hist[i + k] == hist[hl - (ng - 1) + k];
@@ -302,7 +517,25 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     __syncthreads();
   };
   long tok;
-  if (!sp.do_sample) {  // greedy: arg-max of the processed scores, first maximum wins (torch.argmax)
+  if (!sp.do_sample && pre_ok) {  // greedy, two-stage form: the best of the slices' first maxima
+    if (tid < 64) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+      if (tid < SMP_G && ws.cand_n[b * SMP_G + tid] > 0) {
+        bv = ws.cand_v[((long)b * SMP_G + tid) * SMP_LCAP];
+        bi = ws.cand_i[((long)b * SMP_G + tid) * SMP_LCAP];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+      }
+      if (tid == 0) besti = bi;
+    }
+    __syncthreads();
+    tok = besti;
+  } else if (!sp.do_sample) {  // greedy: arg-max of the processed scores, first maximum wins (torch.argmax)
     next_best(INFINITY, -1, 1.f, false);
     tok = besti;
   } else {
@@ -312,12 +545,38 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     // (top_k + the rest of the threshold bin; insertion order does not matter, the selection below orders by
     // (value, index)).  The list is then ordered by top_k rounds of a wave-level arg-max over <= SMP_LIST entries.
     const float invT = 1.f / sp.temperature;
-    next_best(INFINITY, -1, invT, true);  // (1): the maximum and, in the same pass, the smallest finite score
-    const float gmax = bestv;
-    // bin width from the spread of the finite scores: SMP_BINS bins between the maximum and the minimum
-    const float bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - minv, 1e-20f);
-    __syncthreads();
     const int k = min(max(sp.top_k, 1), SMP_CAP);
+    bool have_list = false;  // (uniform)
+    if (pre_ok) {
+      // two-stage form: every slice's candidates at or above the largest of the slices' bounds (>= k scores of ONE slice lie at
+      // or above its bound, so the sample's k-th largest score does too: nothing below it can be kept)
+      if (tid == 0) { list_n = 0; keep_n = 0; }
+      float lmax = -INFINITY;
+      for (int g_ = 0; g_ < SMP_G; ++g_) lmax = fmaxf(lmax, ws.lb[b * SMP_G + g_]);
+      __syncthreads();
+      for (int g_ = 0; g_ < SMP_G; ++g_) {
+        const int n_g = ws.cand_n[b * SMP_G + g_];
+        const long s0 = ((long)b * SMP_G + g_) * SMP_LCAP;
+        for (int t_ = tid; t_ < n_g; t_ += SMP_T) {
+          const float v = ws.cand_v[s0 + t_];
+          if (v >= lmax) {
+            const int slot = atomicAdd(&list_n, 1);
+            if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = ws.cand_i[s0 + t_]; }
+          }
+        }
+      }
+      __syncthreads();
+      have_list = list_n <= SMP_LIST;  // (more: the three passes below, over the already processed logits)
+      if (tid == 0 && have_list) thr_bin = 0;
+      __syncthreads();
+    }
+    float gmax = 0.f, bscale = 0.f;
+    if (!have_list) {
+    next_best(INFINITY, -1, invT, true);  // (1): the maximum and, in the same pass, the smallest finite score
+    gmax = bestv;
+    // bin width from the spread of the finite scores: SMP_BINS bins between the maximum and the minimum
+    bscale = (float)(SMP_BINS - 1) / fmaxf(gmax - minv, 1e-20f);
+    __syncthreads();
     for (int i = tid; i < SMP_BINS; i += SMP_T) hist_bins[i] = 0;
     if (tid == 0) { list_n = 0; keep_n = 0; }
     __syncthreads();
@@ -353,17 +612,20 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       }
     }
     __syncthreads();
+    }  // (!have_list)
     int n = 0;
     if (thr_bin >= 0) {
-      const float lim = (float)(thr_bin + 1);
-      walk([&](float raw, int i) {
-        const float v = raw * invT;
-        if ((gmax - v) * bscale < lim) {
-          const int slot = atomicAdd(&list_n, 1);
-          if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = i; }
-        }
-      });
-      __syncthreads();
+      if (!have_list) {
+        const float lim = (float)(thr_bin + 1);
+        walk([&](float raw, int i) {
+          const float v = raw * invT;
+          if ((gmax - v) * bscale < lim) {
+            const int slot = atomicAdd(&list_n, 1);
+            if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = i; }
+          }
+        });
+        __syncthreads();
+      }
       const int ln = min(list_n, SMP_LIST);
       // order the list by RANK: entry t precedes rank(t) others in (value desc, index asc) order -- indices are distinct, so
       // the ranks are a permutation -- and goes to slot rank(t).  Every thread reads the same list entry at a time (LDS
@@ -444,8 +706,14 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
     }
     if (advance_pos) pos[b] += 1;
   }
-  if (b == 0 && tid == 0) {
-    __threadfence();
+  if (pre && tid == 0) {
+    // *step is advanced here instead of by a launch of its own: every workgroup has read it by the time it takes its ticket,
+    // and the one that draws the last ticket writes step + 1 and re-arms the counter
+    const int t_ = __hip_atomic_fetch_add(ws.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t_ == n_samples - 1) {
+      __hip_atomic_store(ws.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *step_p = step + 1;
+    }
   }
 }
 
@@ -461,10 +729,15 @@ using namespace tcavt;
     if (rc_ != TCAVT_OK) return rc_; \
   } while (0)
 
+extern "C" int64_t tcavt_sample_workspace_bytes(int B) {
+  if (B <= 0) return 0;
+  return 64 + (((int64_t)B * 4 + 63) & ~(int64_t)63) + (int64_t)B * SMP_G * 8 + (int64_t)B * SMP_G * SMP_LCAP * 8;
+}
+
 extern "C" int tcavt_sample_logits(float* logits, int B, int V, int64_t* history, int hist_cap, int32_t* hist_len,
                                    const tcavt_sample_params* sp, int32_t* step, int64_t* cur_tok, int32_t* pos,
-                                   int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos,
-                                   tcavt_stream_t stream) {
+                                   int32_t* finished, int64_t* out_tokens, int out_cap, int advance_pos, void* workspace,
+                                   int64_t workspace_bytes, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(logits && history && hist_len && sp && step && cur_tok && pos && finished && out_tokens && B > 0 && V > 0 &&
                       hist_cap > 0 && out_cap > 0,
                   "sample_logits: bad args");
@@ -477,10 +750,27 @@ extern "C" int tcavt_sample_logits(float* logits, int B, int V, int64_t* history
   p.eos = sp->eos_token_id; p.pad = sp->pad_token_id;
   p.seed_lo = (unsigned int)(sp->seed & 0xffffffffu); p.seed_hi = (unsigned int)(sp->seed >> 32);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  // two-stage form when the caller lends a workspace and the rows can be cut into 16-byte-aligned slices that fit the registers
+  SliceWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int64_t need = tcavt_sample_workspace_bytes(B);
+  const int chunk4 = ((V >> 2) + SMP_G - 1) / SMP_G;
+  if (workspace && workspace_bytes >= need && (V & 3) == 0 && aligned16(logits) && chunk4 <= SMP_E4 * SMP_T) {
+    TCAVT_CHECK_ARG(aligned16(workspace), "sample_logits: workspace must be 16-byte aligned");
+    char* w = static_cast<char*>(workspace);
+    ws.ticket = reinterpret_cast<int*>(w);
+    ws.ovf = reinterpret_cast<int*>(w + 64);
+    size_t off = 64 + (((size_t)B * 4 + 63) & ~(size_t)63);
+    ws.cand_n = reinterpret_cast<int*>(w + off); off += (size_t)B * SMP_G * 4;
+    ws.lb = reinterpret_cast<float*>(w + off); off += (size_t)B * SMP_G * 4;
+    ws.cand_v = reinterpret_cast<float*>(w + off); off += (size_t)B * SMP_G * SMP_LCAP * 4;
+    ws.cand_i = reinterpret_cast<int*>(w + off);
+    hipLaunchKernelGGL(sample_slice_kernel, dim3(B * SMP_G), dim3(SMP_T), 0, st, logits, V, reinterpret_cast<const long*>(history), hist_cap,
+                       hist_len, p, ws);
+  }
   hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(SMP_T), 0, st, logits, V, reinterpret_cast<long*>(history), hist_cap,
                      hist_len, p, step, reinterpret_cast<long*>(cur_tok), pos, finished, reinterpret_cast<long*>(out_tokens),
-                     out_cap, advance_pos);
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+                     out_cap, advance_pos, ws, B);
+  if (!ws.cand_v) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
   TCAVT_CHECK_LAUNCH("sample_logits");
   return TCAVT_OK;
 }
@@ -531,7 +821,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     if (w.a_cat && !t_fused) {
       tcavt_gemm_args g = {};
       g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
-      g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;  // (t stays at the stream's scale: b_ext carries 1 / stream_scale)
+      g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;  // (t is at the stream's scale, like the main term of the accumulator)
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }

@@ -210,7 +210,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
   const float scale = 0.125f;  // 1 / sqrt(head_dim 64)
   // scaled 16-bit image of the residual stream (stream_scale: include/tcavt.h): h16 / part arrive at that scale, the residual
   // epilogues keep it, the fused norms see eps * s^2 (RMSNorm of s x with that eps IS RMSNorm of x); the adapters' t = lora_scale *
-  // (s x) . A^T stays at the stream's scale as well (un-normalised, it has the stream's range) and the caller's b_ext carries 1 / s
+  // (s x) . A^T is at the stream's scale as well, so the whole q|k|v accumulator is s (x W^T + t B^T) and the row scale undoes s
   TCAVT_CHECK_ARG(a->stream_scale >= 0.f && a->stream_scale <= 1.f, "llama_stack_forward: stream_scale must be in (0, 1] (0 means 1)");
   const float ss_ = a->stream_scale == 0.f ? 1.f : a->stream_scale;
   const float eps_s = a->rms_eps * ss_ * ss_;

@@ -284,26 +284,30 @@ class DeviceFeeder:
 
     The reference moves seven tensors of every batch with blocking ``.to(device)`` calls from pageable memory at the head of
     the step.  Here a batch goes through a ring of `slots` (>= 3) staging sets: pinned host buffers, then
-    ``copy_(non_blocking=True)`` on a side stream, and the step is told WHEN its inputs are ready (``FedBatch.ready``, an
-    event) instead of waiting for them on the host: ``Trainer.step(..., inputs_ready=fed.ready)``.  With the pipelined decoder
+    ``copy_(non_blocking=True)``, and the step is told WHEN its inputs are ready (``FedBatch.ready``, an event) instead of
+    waiting for them on the host: ``Trainer.step(..., inputs_ready=fed.ready)``.  With the pipelined decoder
     (training.Trainer, frozen-MLLM variant) three batches are alive at once -- step i's head and backward, step i + 1's
-    decoder, and the copy of batch i + 2 -- hence the ring; a slot is overwritten only after ``release()`` of the batch that
-    used it (an event on the caller's stream: everything that step enqueued has read its inputs by then).
+    decoder, and the copy of batch i + 2 -- hence the ring.
 
-    No stream of its own: the copies go to slot 2 of the side-stream pool, in front of the Q-Former prefetch of the same
-    batch (tcavt_amd.streams: the pipelined step keeps its cross-step overlap only while at most five HIP streams are in
-    use -- DESIGN.md section 6 -- and ~1.4 MB per step need no queue of their own)."""
+    The copies are enqueued on the CALLER'S stream (the stream the steps are enqueued on): put(batch i + 1) is called before
+    step i is enqueued, so on the card the copy runs after step i - 1's optimizer and before step i's head -- while the decoder
+    of step i is busy on its own stream and the caller's stream would be idle anyway (~1.4 MB, nine small copies).  Stream
+    order is then all the protection a slot needs: whatever read the slot three batches ago was enqueued, or joined, on the
+    same stream before.  No stream of its own and no stream-side wait for a late event: HIP folds its streams onto four
+    hardware queues, a stream that waits for "the step three batches back has finished" holds its hardware queue until then,
+    and whichever stream shares that queue stands still with it (measured with the copies on a side stream behind such a
+    wait: 42.7 instead of 15.1 ms per step); and the pipelined step keeps its cross-step overlap only while at most five
+    streams are in use.  A `stream` may still be given (e.g. a loader thread's own); its copies then wait
+    for ``release()`` of the slot's previous user on the HOST."""
 
     TENSOR_KEYS = ("traj_emb", "target_traj", "vision_emb", "lane_polygon", "input_ids", "attention_mask", "labels")
     LIST_KEYS = (("lane_polygon_len", torch.int32), ("norm_stat", torch.float32))
 
     def __init__(self, device, slots=3, stream=None):
-        from . import streams
-
         if slots < 3:
             raise ValueError("DeviceFeeder: at least three slots (two batches in flight + the one being copied)")
         self.device = torch.device(device)
-        self.stream = stream if stream is not None else streams.side_stream(self.device, 2)
+        self.stream = stream  # None: the caller's current stream at put() time
         self._slots = [None] * slots
         self._free = [None] * slots
         self._count = 0
@@ -332,18 +336,19 @@ class DeviceFeeder:
             slot = self._slots[k] = {
                 "pin": {n: torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for n, t in host.items()},
                 "dev": {n: torch.empty(t.shape, dtype=t.dtype, device=self.device) for n, t in host.items()}, "ev": None}
-        elif slot["ev"] is not None:
+        if slot["ev"] is not None:
             slot["ev"].synchronize()  # the previous copy OUT of this pinned set (len(slots) batches ago: long done)
+        if self.stream is not None and self._free[k] is not None:
+            self._free[k].synchronize()  # own stream: HOST wait for the slot's previous user (see the class docstring)
         for n, t in host.items():
             slot["pin"][n].copy_(t)
         self.bytes_per_batch = sum(t.numel() * t.element_size() for t in host.values())
-        if self._free[k] is not None:
-            self.stream.wait_event(self._free[k])  # the step that last used these device tensors has read them
-        with torch.cuda.stream(self.stream):
+        st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
             for n in host:
                 slot["dev"][n].copy_(slot["pin"][n], non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(self.stream)
+            ev.record(st)
         slot["ev"] = ev
         fed = FedBatch(slot["dev"])
         for n in ("context_str", "answer_str", "track_id"):

@@ -566,11 +566,9 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         self.wide_stream = False
 
     def set_stream_contract(self, stream_scale=1.0, wide_stream=False):
-        """See stream_scale / wide_stream above.  The packed adapters carry 1 / stream_scale (b_ext): re-packed when it changes."""
-        if float(stream_scale) != self.stream_scale and self.use_lora:
-            if self._prep_T is not None:
-                raise RuntimeError("stream_scale cannot change once the backward's operands exist (LoRA-trainable variant: scale 1 only)")
-            self._invalidate()
+        """See stream_scale / wide_stream above.  Nothing is re-packed: with the stream's image at s x the whole q|k|v accumulator
+        is s (x W^T + t B^T) -- the adapters' un-normalised t = lora_scale (s x) A^T simply stays at the stream's scale too --
+        and the fused norm's row scale 1 / (s rms) takes the s out again."""
         self.stream_scale, self.wide_stream = float(stream_scale), bool(wide_stream)
 
     # ---- packed device-side weights -------------------------------------------------
@@ -611,9 +609,8 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
                 g1_all[nL - 1 - li, 0].copy_(d.g1)
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
-                # (b_ext carries 1 / stream_scale: t is kept at the stream's scale, tcavt_llama_stack_args.stream_scale)
-                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach() / self.stream_scale)
-                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach() / self.stream_scale)
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
             d.w_o = to16(a.o_proj.weight)
             d.w_gu = to16(interleave_gate_up(lyr.mlp.gate_proj.weight.detach(), lyr.mlp.up_proj.weight.detach()) * d.g2[None, :])
             d.w_d = to16(lyr.mlp.down_proj.weight)
@@ -700,15 +697,15 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
             aq, bq, av, bv = stacked
             P.a_all[:, :r].copy_(aq * P.g1_all)
             P.a_all[:, LORA_V:LORA_V + r].copy_(av * P.g1_all)
-            P.b_all[:, : nq * hd, :r].copy_(bq / self.stream_scale)
-            P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv / self.stream_scale)
+            P.b_all[:, : nq * hd, :r].copy_(bq)
+            P.b_all[:, (nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(bv)
         else:
             for li, lyr in enumerate(self.llama_model.model.layers):
                 a, d = lyr.self_attn, P.layers[li]
                 d.a_cat[:r].copy_(a.q_proj.lora_A.weight.detach() * d.g1[None, :])
                 d.a_cat[LORA_V:LORA_V + r].copy_(a.v_proj.lora_A.weight.detach() * d.g1[None, :])
-                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach() / self.stream_scale)
-                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach() / self.stream_scale)
+                d.b_ext[: nq * hd, :r].copy_(a.q_proj.lora_B.weight.detach())
+                d.b_ext[(nq + nkv) * hd:, LORA_V:LORA_V + r].copy_(a.v_proj.lora_B.weight.detach())
         if self._prep_T is not None:
             self._refresh_lora_T(stacked)
 
@@ -1108,7 +1105,11 @@ class LlamaMultiModal(nn.Module, _Prepared):
                                        int(no_repeat_ngram_size), int(bool(do_sample)),
                                        -1 if eos_token_id is None else int(eos_token_id), int(pad_token_id),
                                        int(seed) & 0xFFFFFFFFFFFFFFFF)
-                ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=False)
+                # two-stage token selection (B x 16 workgroups + one per sample; TCAVT_SAMPLE_ONE_STAGE=1: the one-workgroup form, A/B)
+                sws = None
+                if os.environ.get("TCAVT_SAMPLE_ONE_STAGE", "0") != "1":
+                    sws = ws.get("gen.sample_ws", (int(capi.lib().tcavt_sample_workspace_bytes(B)),), torch.uint8, dev, zero=True)
+                ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=False, workspace=sws)
                 if N > 1:
                     cos, sin = LW._rope_tables(Lmax, dev)
                     a = capi.DecodeArgs()
@@ -1141,7 +1142,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
 
                     def one_step():
                         ops.llama_decode_step(a)
-                        ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=True)
+                        ops.sample_logits(logits, history, hist_len, sp, step, cur, pos, finished, out, advance_pos=True, workspace=sws)
 
                     one_step()  # token 2 eagerly (also the warm-up of every kernel form the step uses)
                     if N > 2:

@@ -913,9 +913,18 @@ def lora_dgrad(g_t, a_qT, a_vT, out, dropout=None, site_v=None):
                                  (site + 1) if site_v is None else int(site_v), _DT[g_t.dtype], stream_ptr()), "tcavt_lora_dgrad")
 
 
-def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finished, out_tokens, advance_pos):
-    """Logits processors + token selection (tcavt_sample_logits); every tensor is device state that the call advances."""
+def sample_workspace(B, device):
+    """Workspace of the two-stage token selection for B samples (tcavt_sample_workspace_bytes): uint8, zeroed once here; every
+    call leaves its control words zero.  Calls that share it must be stream-ordered."""
+    return torch.zeros(int(lib().tcavt_sample_workspace_bytes(int(B))), dtype=torch.uint8, device=device)
+
+
+def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finished, out_tokens, advance_pos, workspace=None):
+    """Logits processors + token selection (tcavt_sample_logits); every tensor is device state that the call advances.
+    workspace (sample_workspace(B, device)): the two-stage form -- B x 16 workgroups instead of B; same tokens."""
     B, V = logits.shape
+    if workspace is not None:
+        _req(workspace, torch.uint8, "sample_logits.workspace")
     _req(logits, torch.float32, "sample_logits.logits")
     for t, dt, n, nm in ((history, torch.int64, B, "history"), (hist_len, torch.int32, B, "hist_len"), (step, torch.int32, 1, "step"),
                          (cur_tok, torch.int64, B, "cur_tok"), (pos, torch.int32, B, "pos"), (finished, torch.int32, B, "finished"),
@@ -926,7 +935,8 @@ def sample_logits(logits, history, hist_len, params, step, cur_tok, pos, finishe
         raise capi.TcavtError("sample_logits: history / out_tokens need one row per sample")
     check(lib().tcavt_sample_logits(ptr(logits), B, V, ptr(history), history.shape[1], ptr(hist_len), ctypes.byref(params),
                                     ptr(step), ptr(cur_tok), ptr(pos), ptr(finished), ptr(out_tokens), out_tokens.shape[1],
-                                    int(advance_pos), stream_ptr()), "tcavt_sample_logits")
+                                    int(advance_pos), ptr(workspace), workspace.numel() if workspace is not None else 0,
+                                    stream_ptr()), "tcavt_sample_logits")
 
 
 def gather_last(src16, kv_len, out16, B, L, H):
