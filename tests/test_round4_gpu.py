@@ -95,3 +95,24 @@ def test_steps_fed_from_the_host_do_not_alias(gpu):
         assert torch.equal(ha[i], hb[i]), f"step {i}: the MLLM saw another batch's inputs"
     assert not torch.equal(ha[0], ha[1])
     assert np.allclose(la, lb, rtol=5e-3) and rel_err(pa.cpu(), pb.cpu()) < 1e-3
+
+
+def test_copy_batch_from_pinned_host_memory(gpu):
+    """tcavt_copy_batch: up to 16 (device <- pinned host) copies in one kernel launch; sizes that are not multiples of 16 bytes."""
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(4)
+    shapes = [((32, 2, 18), torch.float32), ((32, 18, 512), torch.float32), ((32,), torch.int32), ((32, 4), torch.float32),
+              ((32, 240), torch.int64), ((7,), torch.int32), ((3, 5), torch.float16), ((1,), torch.int64)]
+    srcs = []
+    for shp, dt in shapes:
+        t = torch.randint(-1000, 1000, shp, generator=g).to(dt) if dt in (torch.int32, torch.int64) else torch.randn(shp, generator=g).to(dt)
+        srcs.append(t.pin_memory())
+    dsts = [torch.zeros(s.shape, dtype=s.dtype, device=dev) for s in srcs]
+    ops.copy_batch(dsts, srcs)
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d.cpu(), s)
+    with pytest.raises(capi.TcavtError):
+        ops.copy_batch(dsts[:1], [torch.zeros(5)])  # size mismatch / not pinned

@@ -221,6 +221,7 @@ _SIGNATURES = {
                       ctypes.c_uint32, c_int, c_void_p],
     "tcavt_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_cast_f32_16": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "tcavt_copy_batch": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "tcavt_embed_fuse": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                          c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p],
     "tcavt_softmax_rows": [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64,

@@ -623,7 +623,8 @@ extern "C" int tcavt_attn_causal_gqa_stamped(const void* qkv, void* out, const i
   auto kfn = attn_causal_gqa_kernel<512, true, true>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
   hipLaunchKernelGGL(kfn, dim3(B * nkv), dim3(512), lds, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(qkv),
-                     static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes, stamps);
+                     static_cast<bf16_t*>(out), kv_len, L, Lp, nq, nkv, scale * 1.4426950408889634f, ot_bytes, stamps,
+                     static_cast<float*>(nullptr));
   TCAVT_CHECK_LAUNCH("attn_causal_gqa_stamped");
   return TCAVT_OK;
 }

@@ -509,6 +509,55 @@ extern "C" int tcavt_cast_f32_16(const float* x, void* out_bf16, int64_t n, int 
   return TCAVT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Batched host -> device copy AS A KERNEL: up to 16 (dst, src, bytes) items in one launch, src = pinned (device-mapped) host
+// memory read over the host link by the copying lanes.  Why not hipMemcpyAsync: the training loop uploads a ~1.4 MB batch per
+// step (scripts/train.py:1153-1166) from a host that runs a whole step ahead of the card; a copy-engine transfer that is ordered
+// behind pending work of its stream made the host WAIT inside hipMemcpyAsync until that work had drained (measured: the fed step
+// 28-42 ms instead of 15 ms, the card idle half of the time), whereas a kernel is just one more launch in the queue.  At this
+// size the link's latency, not its bandwidth, is what the copy costs (tens of microseconds, on a stream that is idle then).
+// ---------------------------------------------------------------------------
+struct CopyBatch {
+  void* dst[16];
+  const void* src[16];
+  long bytes[16];
+};
+
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch b) {
+  const int it = blockIdx.y;
+  const long n = b.bytes[it];
+  char* d = static_cast<char*>(b.dst[it]);
+  const char* s_ = static_cast<const char*>(b.src[it]);
+  const long n16 = n >> 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    reinterpret_cast<u32x4*>(d)[i] = reinterpret_cast<const u32x4*>(s_)[i];
+  const long tail0 = n16 << 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n - tail0) d[tail0 + gid] = s_[tail0 + gid];
+}
+
+extern "C" int tcavt_copy_batch(void* const* dst, const void* const* src, const int64_t* bytes, int n, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(dst && src && bytes && n > 0 && n <= 16, "copy_batch: 1 .. 16 items");
+  CopyBatch b;
+  long most = 0;
+  for (int i = 0; i < 16; ++i) {
+    const bool on = i < n;
+    b.dst[i] = on ? dst[i] : nullptr;
+    b.src[i] = on ? src[i] : nullptr;
+    b.bytes[i] = on ? (long)bytes[i] : 0;
+    if (on) {
+      TCAVT_CHECK_ARG(dst[i] && src[i] && bytes[i] >= 0 && aligned16(dst[i]) && aligned16(src[i]), "copy_batch: item %d: null / unaligned / negative", i);
+      most = bytes[i] > most ? bytes[i] : most;
+    }
+  }
+  long blocks = (most / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+  hipLaunchKernelGGL(copy_batch_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), b);
+  TCAVT_CHECK_LAUNCH("copy_batch");
+  return TCAVT_OK;
+}
+
 extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, const float* img,
                                 const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
                                 int Lt, int H, int V, int* bad_id_flag, int table_dtype, void* h16, float* part,

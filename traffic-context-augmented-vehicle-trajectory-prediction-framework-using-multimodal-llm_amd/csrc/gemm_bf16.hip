@@ -211,8 +211,32 @@ __device__ __forceinline__ void unswap_pair16(const u32x4& v, u32x2& a, u32x2& b
 // the 4-wave kernel computes them once per output tile while the first operands are in flight); otherwise they are
 // summed here from the partials, all TM rows' loads in flight together.
 // LEGACY (experiments build only, A/B): 1 = the 8-byte-access epilogues of rounds 1-2
-template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false, int LEGACY = 0>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][TM], int m_base, int n_base, int lane,
+// (the accumulator argument is the kernel's own f32x4 [TN][TM] array, or -- experiments build -- a view that hands out quads of a
+//  differently shaped accumulator file; pin_acc re-pins the registers behind element (i, j) in front of a row's arithmetic)
+template <int TN, int TM>
+__device__ __forceinline__ void pin_acc(f32x4 (&acc)[TN][TM], int i, int j) {
+  asm volatile("" : "+a"(acc[i][j]));
+}
+#ifdef TCAVT_EXPERIMENTS
+struct Acc32View {  // TIMING ONLY: quad ((i & 1) * 2 + (j & 1)) of the 32x32 accumulator [i / 2][j / 2] (not where that MFMA leaves (i, j))
+  f32x16 (&a)[4][4];
+  struct Row {
+    f32x16 (&a)[4][4];
+    int i;
+    __device__ __forceinline__ f32x4 operator[](int j) const {
+      const f32x16& t = a[i >> 1][j >> 1];
+      const int q = (i & 1) * 2 + (j & 1);
+      return f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+    }
+  };
+  __device__ __forceinline__ Row operator[](int i) const { return Row{a, i}; }
+};
+__device__ __forceinline__ void pin_acc(Acc32View& v, int i, int j) {
+  if ((i & 1) == 0 && (j & 1) == 0) asm volatile("" : "+a"(v.a[i >> 1][j >> 1]));
+}
+#endif
+template <int TM, int TN, int EPI, bool WHOLE_ONLY = false, bool F16 = false, int LEGACY = 0, class ACC>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, ACC& acc, int m_base, int n_base, int lane,
                                               const float* rs_lds = nullptr) {
   constexpr int OUT16 = F16 ? TCAVT_F16 : TCAVT_BF16;
   float rsv[TM];
@@ -288,7 +312,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
             const long m = m_base + j * 16 + ml;
             bf16_t* hrow = p.norm_h16 + m * p.ldc + n_base;
 #pragma unroll
-            for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (see the SiLU epilogue: no hoisted accumulator reads)
+            for (int i = 0; i < TN; ++i) pin_acc(acc, i, j);  // (see the SiLU epilogue: no hoisted accumulator reads)
 #pragma unroll
             for (int g = 0; g < TN / 4; ++g) {
               float ss = 0.f;
@@ -480,7 +504,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
       if (j + DW < TM) fetchp(j + DW < TM ? j + DW : 0);
       bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)(m_base + j * 16 + ml) * p.ldc + 2 * n_base;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (no hoisted accumulator reads: see the SiLU epilogue)
+      for (int i = 0; i < TN; ++i) pin_acc(acc, i, j);  // (no hoisted accumulator reads: see the SiLU epilogue)
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         u32x2 gq, uq;
@@ -517,7 +541,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
           // (4-wave kernel: the accumulators live in AGPRs; re-pinning this row's here keeps their v_accvgpr_reads from
           // being hoisted over the rows before it -- 150 hoisted reads cost spills that were reloaded behind the stores)
 #pragma unroll
-          for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));
+          for (int i = 0; i < TN; ++i) pin_acc(acc, i, j);
         }
 #pragma unroll
         for (int i = 0; i < TN; i += 4) {
@@ -587,7 +611,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[TN][T
         bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n_base;
         const float rs = rsv[j];  // fused RMSNorm: 1 / rms of the row (gamma is in W)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) asm volatile("" : "+a"(acc[i][j]));  // (see the SiLU epilogue: no hoisted accumulator reads)
+        for (int i = 0; i < TN; ++i) pin_acc(acc, i, j);  // (see the SiLU epilogue: no hoisted accumulator reads)
 #pragma unroll
         for (int hh = 0; hh < TN / 4; ++hh) {
           const bool rot = n_base + hh * 64 < p.rope_cols;  // uniform: q and k heads rotate, v heads do not
@@ -1576,6 +1600,232 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
 #endif
 }
 
+#ifdef TCAVT_EXPERIMENTS
+// ===========================================================================
+// Experiment (round 4, tile code 273): the 4-wave kernel's main loop on v_mfma_f32_32x32x16 instead of 16x16x32.
+// Why: the loop above is ISSUE-bound, not matrix-pipe-bound (round 1's elimination runs: no DMA -58 us, no fragment loads -38 us of
+// 428; matrix pipe busy 0.68) -- one wave per SIMD must issue 128 MFMAs + 32 ds_read_b128 + 16 LDS-DMA pieces + address arithmetic
+// per K-tile, and a 16x16x32 MFMA holds the issue port for 8 of its 16 cycles.  A 32x32x16 MFMA does the same FLOPs per cycle
+// and holds the port for 8 of 32: 64 MFMAs per K-tile leave 3x the issue slack for the same loads.  Against it: the guide's
+// measurement that the chip sustains a ~13 % lower clock on the 32x32 shape in a bare loop.  Same LDS image, same DMA, same
+// fragment count (32 per K-tile); per wave a 128x128 quadrant = 4x4 tiles of 32x32 (16 accumulators of 16 registers).
+// TIMING FIRST: the epilogue below is fed the accumulators in the 16x16 kernel's quad order, which is NOT where this MFMA leaves
+// them (results are wrong); a real epilogue mapping is written only if the loop is faster.
+// ===========================================================================
+template <bool F16>
+__device__ __forceinline__ void mfma32_agpr(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256) void gemm_w4m32_kernel(GemmP p) {
+  constexpr int BM = 256, BN = 256, NW = 4;
+  constexpr int TILE_BYTES = (BM + BN) * 128;
+  constexpr int NP = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr bool RS = EPI == EPI_SILU;
+  float* const rs_base = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+  int rs_sel = 0;
+  const bool pers = p.pers_tiles > 0;
+  const int total_tiles = pers ? p.pers_tiles : (int)gridDim.x;
+  int vb = blockIdx.x;
+  int tile_m, tile_n;
+  block_to_tile(p, tile_m, tile_n, vb, total_tiles);
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int rl = lane >> 3;
+  const int csw = (lane & 7) ^ (((wave & 1) * 4 + (rl >> 1)) & 7);
+  const bf16_t* srcA = p.A + (long)(m0 + wave * 8 + rl) * p.lda + csw * 8;
+  const bf16_t* srcW = p.W + (long)(n0 + wave * 8 + rl) * p.ldw + csw * 8;
+  bool has_next = pers && vb + (int)gridDim.x < total_tiles;
+  int nm0 = m0, nn0 = n0;
+  const bf16_t* nxtA = srcA;
+  const bf16_t* nxtW = srcW;
+  auto locate_next = [&]() {
+    if (has_next) {
+      int tm, tn;
+      block_to_tile(p, tm, tn, vb + (int)gridDim.x, total_tiles);
+      nm0 = tm * BM;
+      nn0 = tn * BN;
+      nxtA = p.A + (long)(nm0 + wave * 8 + rl) * p.lda + csw * 8;
+      nxtW = p.W + (long)(nn0 + wave * 8 + rl) * p.ldw + csw * 8;
+    }
+  };
+  locate_next();
+  const long stepA = 32 * p.lda, stepW = 32 * p.ldw;
+  const int nt = p.K >> 6;
+  struct Src { const bf16_t* a; const bf16_t* w; };
+  auto tsrc = [&](int t) -> Src {
+    if (t >= nt && has_next) return Src{nxtA + (t - nt) * 64, nxtW + (t - nt) * 64};
+    t = min(t, nt - 1);
+    return Src{srcA + t * 64, srcW + t * 64};
+  };
+  auto piece = [&](int buf, const Src& s_, int r) {
+    char* dst = smem + buf * TILE_BYTES + (r * NW + wave) * 1024;
+    if (r < 8) glds16(s_.a + r * stepA, dst);
+    else glds16(s_.w + (r - 8) * stepW, dst);
+  };
+  // fragment read: 32 rows per MFMA tile (row = lane & 31), 8 k-values per lane: 16-byte chunk (2 ks + (lane >> 5)) of the row
+  const int fsw = ((lane & 31) >> 1) & 7;
+  int off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) off[ks] = ((2 * ks + (lane >> 5)) ^ fsw) * 16;
+  const int xrow = (wm * 128 + (lane & 31)) * 128;
+  const int wrow = (BM + wn * 128 + (lane & 31)) * 128;
+  auto ldx = [&](const char* base, int ks, int j) { return *reinterpret_cast<const bf16x8*>(base + xrow + j * 4096 + off[ks]); };
+  auto ldw = [&](const char* base, int ks, int i) { return *reinterpret_cast<const bf16x8*>(base + wrow + i * 4096 + off[ks]); };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8 w0[2][4], x0[2][4], w1[2][4], x1[2][4];  // F0 = k-steps 0, 1; F1 = k-steps 2, 3 of a K-tile
+
+  if constexpr (RS) {
+    if (p.rs_part) rs_base[threadIdx.x] = row_rscale(p, m0 + threadIdx.x);
+  }
+  {
+    const Src s0 = tsrc(0);
+#pragma unroll
+    for (int r = 0; r < NP; ++r) piece(0, s0, r);
+  }
+  __syncthreads();
+  Src sn1 = tsrc(1);
+  if (nt > 1 || has_next) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) piece(1, sn1, r);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      x0[ks][q] = ldx(smem, ks, q);
+      w0[ks][q] = ldw(smem, ks, q);
+    }
+  int cur = 0;
+  auto ktile = [&](int t) {
+    const char* base = smem + cur * TILE_BYTES;
+    const char* nbase = smem + (cur ^ 1) * TILE_BYTES;
+    // ---- phase A: 32 MFMAs on F0 | 16 fragment loads of F1 (one per 2 MFMAs) | DMA pieces 4..15 of tile t+1 (three per 8 MFMAs)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mfma32_agpr<F16>(acc[i][j], w0[ks][i], x0[ks][j]);
+          const int idx = ks * 16 + i * 4 + j;
+          if ((idx & 1) == 0) {
+            const int f = idx >> 1;  // 0..15
+            const int fk = f >> 3, fq = f & 3;
+            if ((f & 4) == 0) x1[fk][fq] = ldx(base, 2 + fk, fq);
+            else w1[fk][fq] = ldw(base, 2 + fk, fq);
+          }
+          const int o = idx & 7;
+          if (o == 2 || o == 5 || o == 7) {
+            const int pc = 4 + (idx >> 3) * 3 + (o == 2 ? 0 : o == 5 ? 1 : 2);
+            piece(cur ^ 1, sn1, pc);
+          }
+        }
+    // ---- phase B1: 24 MFMAs on F1; the source of tile t+2 in their shadow
+    Src sn2;
+#pragma unroll
+    for (int idx = 0; idx < 24; ++idx) {
+      const int ks = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+      mfma32_agpr<F16>(acc[i][j], w1[ks][i], x1[ks][j]);
+      if (idx == 1) sn2 = tsrc(t + 2);
+    }
+    __syncthreads();  // tile t+1 has landed for everyone; nobody reads tile t any more
+    // ---- phase B2: last 8 MFMAs on F1 | 16 fragment loads of F0(t+1), two per MFMA | DMA pieces 0..3 of tile t+2
+#pragma unroll
+    for (int idx = 24; idx < 32; ++idx) {
+      const int ks = 1, i = (idx >> 2) & 3, j = idx & 3;
+      mfma32_agpr<F16>(acc[i][j], w1[ks][i], x1[ks][j]);
+      const int f = idx - 24;  // 0..7
+      x0[f >> 2][f & 3] = ldx(nbase, f >> 2, f & 3);
+      w0[f >> 2][f & 3] = ldw(nbase, f >> 2, f & 3);
+      if (f & 1) piece(cur, sn2, f >> 1);
+    }
+    if (t == nt - 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    cur ^= 1;
+    sn1 = sn2;
+  };
+  for (;;) {
+    for (int t = 0; t < nt; ++t) ktile(t);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+    const int em0 = m0, en0 = n0;
+    const bool cont = has_next;
+    if (cont) {
+      vb += gridDim.x;
+      if constexpr (RS) {
+        if (p.rs_part) rs_base[(rs_sel ^ 1) * 256 + threadIdx.x] = row_rscale(p, nm0 + threadIdx.x);
+      }
+      m0 = nm0;
+      n0 = nn0;
+      srcA = nxtA;
+      srcW = nxtW;
+      has_next = vb + (int)gridDim.x < total_tiles;
+      locate_next();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // TIMING-ONLY epilogue: the 16x16 kernel's quad order over this kernel's accumulator registers (wrong element mapping)
+      Acc32View a4{acc};
+      gemm_epilogue<8, 8, EPI, true, F16>(p, a4, em0 + wm * 128, en0 + wn * 128, lane,
+                                          (RS && p.rs_part) ? rs_base + rs_sel * 256 + wm * 128 : nullptr);
+    }
+    if (!cont) break;
+    rs_sel ^= 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        asm volatile("" : "+a"(acc[i][j]));
+      }
+    asm volatile("s_nop 7" ::: "memory");
+  }
+}
+
+template <int EPI, bool F16>
+static int launch_w4m32(const GemmP& p0, hipStream_t stream) {
+  GemmP p = p0;
+  p.tiles_m = p.M / 256;
+  p.tiles_n = p.N / 256;
+  p.xcd_gx = choose_xcd_partition(p);
+  constexpr int lds = 2 * 512 * 128 + 2048;
+  auto kfn = gemm_w4m32_kernel<EPI, F16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("gemm_bf16(w4m32): hipFuncSetAttribute failed");
+      return TCAVT_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  int wgs = tiles;
+  p.pers_tiles = 0;
+  if (tiles > 256 && p.K >= 128) {
+    p.pers_tiles = tiles;
+    wgs = 256;
+  }
+  hipLaunchKernelGGL(kfn, dim3(wgs), dim3(256), lds, stream, p);
+  TCAVT_CHECK_LAUNCH("gemm_bf16(w4m32)");
+  return TCAVT_OK;
+}
+#endif  // TCAVT_EXPERIMENTS
+
 // the forms of the SiLU*up epilogue the 4-wave kernel is built for (16-byte stores of the 16-bit operand type)
 template <bool F16>
 static bool silu16_ok(const GemmP& p) {
@@ -1721,6 +1971,14 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
         return launch_w4<EPI, 4, 0, false, 192, F16>(q, stream);
       set_error("gemm_bf16: tile 271 (4-wave kernel, 256x192) needs M %% 256 == 0, N %% 192 == 0, no batch");
       return TCAVT_ERR_ARG;
+#ifdef TCAVT_EXPERIMENTS
+    case 273:  // 32x32x16 main loop, TIMING ONLY (wrong results): SiLU / in-place residual / plain 16-bit forms
+      if (batch == 1 && q.K2 == 0 && q.M % 256 == 0 && q.N % 256 == 0) {
+        if constexpr (EPI == EPI_SILU || EPI == EPI_NORM16 || EPI == EPI_GENERIC) return launch_w4m32<EPI, F16>(q, stream);
+      }
+      set_error("gemm_bf16: tile 273 (32x32 MFMA experiment) needs whole 256x256 tiles and the SiLU / NORM16 / generic epilogue");
+      return TCAVT_ERR_ARG;
+#endif
     case 257: case 272:
 #ifdef TCAVT_EXPERIMENTS
     case 258: case 259: case 268: case 269: case 270:
@@ -2304,7 +2562,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
 #ifdef TCAVT_EXPERIMENTS
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 272 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 273 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 #else
   TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || a->tile == 257 || a->tile == 271 || a->tile == 272,

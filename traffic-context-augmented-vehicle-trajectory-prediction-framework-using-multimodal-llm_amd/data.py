@@ -289,7 +289,7 @@ class DeviceFeeder:
     (training.Trainer, frozen-MLLM variant) three batches are alive at once -- step i's head and backward, step i + 1's
     decoder, and the copy of batch i + 2 -- hence the ring.
 
-    The copies are enqueued on the CALLER'S stream (the stream the steps are enqueued on): put(batch i + 1) is called before
+    The copy is ONE kernel launch (tcavt_copy_batch: its lanes read the pinned buffers over the host link) enqueued on the CALLER'S stream (the stream the steps are enqueued on): put(batch i + 1) is called before
     step i is enqueued, so on the card the copy runs after step i - 1's optimizer and before step i's head -- while the decoder
     of step i is busy on its own stream and the caller's stream would be idle anyway (~1.4 MB, nine small copies).  Stream
     order is then all the protection a slot needs: whatever read the slot three batches ago was enqueued, or joined, on the
@@ -324,6 +324,8 @@ class DeviceFeeder:
 
     def put(self, batch):
         """Stage one collated batch (host tensors / lists) and start its copy; returns the FedBatch at once."""
+        from . import ops
+
         k = self._count % len(self._slots)
         self._count += 1
         host = self._host_tensors(batch)
@@ -345,8 +347,10 @@ class DeviceFeeder:
         self.bytes_per_batch = sum(t.numel() * t.element_size() for t in host.values())
         st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         with torch.cuda.stream(st):
-            for n in host:
-                slot["dev"][n].copy_(slot["pin"][n], non_blocking=True)
+            # ONE kernel launch that reads the pinned buffers over the host link (ops.copy_batch), not copy-engine transfers: a
+            # hipMemcpyAsync ordered behind the stream's pending work made the host wait for that work inside the call
+            names = list(host)
+            ops.copy_batch([slot["dev"][n] for n in names], [slot["pin"][n] for n in names])
             ev = torch.cuda.Event()
             ev.record(st)
         slot["ev"] = ev

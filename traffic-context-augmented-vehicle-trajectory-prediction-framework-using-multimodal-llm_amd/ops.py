@@ -913,6 +913,23 @@ def lora_dgrad(g_t, a_qT, a_vT, out, dropout=None, site_v=None):
                                  (site + 1) if site_v is None else int(site_v), _DT[g_t.dtype], stream_ptr()), "tcavt_lora_dgrad")
 
 
+def copy_batch(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for up to 16 (device tensor, pinned host tensor) pairs of equal size, as ONE kernel launch on the
+    current stream (tcavt_copy_batch: the copying lanes read the pinned memory over the host link; no copy-engine transfer)."""
+    n = len(dsts)
+    if n != len(srcs) or not 0 < n <= 16:
+        raise capi.TcavtError("copy_batch: 1 .. 16 (dst, src) pairs")
+    D, S, Bn = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int64 * n)()
+    for i, (d, s) in enumerate(zip(dsts, srcs)):
+        nb = d.numel() * d.element_size()
+        if s.numel() * s.element_size() != nb or d.dtype != s.dtype or not d.is_contiguous() or not s.is_contiguous():
+            raise capi.TcavtError(f"copy_batch: pair {i}: contiguous tensors of one dtype and size required")
+        if not (d.is_cuda or _ALLOW_CPU) or not (s.is_cuda or s.is_pinned() or _ALLOW_CPU):
+            raise capi.TcavtError(f"copy_batch: pair {i}: dst on the GPU, src on the GPU or in pinned host memory")
+        D[i], S[i], Bn[i] = d.data_ptr(), s.data_ptr(), nb
+    check(lib().tcavt_copy_batch(D, S, Bn, n, stream_ptr()), "tcavt_copy_batch")
+
+
 def sample_workspace(B, device):
     """Workspace of the two-stage token selection for B samples (tcavt_sample_workspace_bytes): uint8, zeroed once here; every
     call leaves its control words zero.  Calls that share it must be stream-ordered."""
