@@ -38,6 +38,24 @@ def main():
         t["put"] += t2 - t1
         return f
 
+    import cProfile
+    import gc
+    import pstats
+
+    prof = cProfile.Profile() if "--cprofile" in sys.argv else None
+    if "--no-gc" in sys.argv:
+        gc.disable()
+    gc_t = [0.0]
+    gc_mark = [0.0]
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_mark[0] = time.perf_counter()
+        else:
+            gc_t[0] += time.perf_counter() - gc_mark[0]
+            if time.perf_counter() - gc_mark[0] > 0.005:
+                print(f"  [gc] generation {info['generation']} took {(time.perf_counter() - gc_mark[0]) * 1e3:.1f} ms")
+    gc.callbacks.append(gc_cb)
     cur = fetch(0)
     n = 24
     for i in range(n):
@@ -45,7 +63,10 @@ def main():
             torch.cuda.synchronize()
             for k in t:
                 t[k] = 0.0
+            gc_t[0] = 0.0
             w0 = time.perf_counter()
+            if prof is not None:
+                prof.enable()
         nxt = fetch(i + 1)
         t0 = time.perf_counter()
         tr.step(cur["traj_emb"], cur["vision_emb"], cur["lane_polygon"], cur["lane_polygon_len"], cur["target_traj"], cur["norm_stat"],
@@ -58,8 +79,13 @@ def main():
         t["release"] += t2 - t1
         detail.append((t1 - t0) * 1e3)
         cur = nxt
+    if prof is not None:
+        prof.disable()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - w0) / (n - 8) * 1e3
+    print(f"python gc inside the timed steps: {gc_t[0] * 1e3:.1f} ms in all")
+    if prof is not None:
+        pstats.Stats(prof).sort_stats("tottime").print_stats(18)
     print(f"wall {wall:.2f} ms/step; host per step: " + ", ".join(f"{k} {v / (n - 8) * 1e3:.2f} ms" for k, v in t.items()))
     print("step() host ms:", " ".join(f"{d:.1f}" for d in detail))
 
