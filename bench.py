@@ -430,6 +430,12 @@ def main():
     if args.feed == "host":
         from tcavt_amd import data as tdata
 
+        # The host side of a fed step is a few small torch CPU ops (stack, pad_sequence, staging copies).  Left at its default,
+        # torch's intra-op pool starts one thread per CPU the box SHOWS (not the share this process may use), they spin, the
+        # cgroup's CPU quota runs out and the whole process is frozen until the next scheduler period: 90 ms stalls every few
+        # steps, 31-42 instead of 15 ms per step (tools/feed_probe.py; profiles/r04_feed_host.txt).  Two threads are plenty.
+        torch.set_num_threads(2)
+
         n_sets = 4
         host_sets = [synth.batch_to_samples(synth.make_batch(cfg, B, text_len=args.text_len, seed=100 + rank + 1000 * (j + 1), ragged=True,
                                                              min_text=128 if args.text_len > 128 else max(1, args.text_len // 2)))

@@ -248,8 +248,8 @@ int tcavt_dropout_epoch_advance(uint64_t* epoch_dev, tcavt_stream_t stream);
 
 /* Batched copy as ONE kernel launch: items i < n (n <= 16) copy bytes[i] bytes from src[i] to dst[i] (16-byte aligned; dst, src,
  * bytes are HOST arrays read at call time).  src may be pinned, device-mapped HOST memory (hipHostMalloc / a torch tensor made
- * with pin_memory=True): the upload of a training batch (scripts/train.py:1153-1166) as a launch in the stream's queue rather
- * than a copy-engine transfer, which made the host wait for the stream's pending work (tcavt_amd.data.DeviceFeeder). */
+ * with pin_memory=True): the upload of a training batch (scripts/train.py:1153-1166) as one launch in the stream's queue rather
+ * than nine copy-engine transfers (tcavt_amd.data.DeviceFeeder). */
 int tcavt_copy_batch(void* const* dst, const void* const* src, const int64_t* bytes, int n, tcavt_stream_t stream);
 
 /* fp32 -> fp16 / bf16 (round-to-nearest-even) copy of n elements, n % 8 == 0 not required */

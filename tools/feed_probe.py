@@ -15,6 +15,10 @@ def main():
     from tcavt_amd.weights import make_weights
 
     capi.init(0)
+    if "--threads" in sys.argv:
+        torch.set_num_threads(int(sys.argv[sys.argv.index("--threads") + 1]))
+    print(f"torch intra-op threads: {torch.get_num_threads()}, os.cpu_count() = {os.cpu_count()}, "
+          f"affinity = {len(os.sched_getaffinity(0))}")
     dev = torch.device("cuda", 0)
     cfg = config.PRESETS["llama32_1b"](seq_len=18, out_len=30, use_lora=True)
     B = 32

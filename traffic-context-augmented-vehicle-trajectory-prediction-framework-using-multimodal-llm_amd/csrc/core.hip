@@ -511,11 +511,10 @@ extern "C" int tcavt_cast_f32_16(const float* x, void* out_bf16, int64_t n, int 
 
 // ---------------------------------------------------------------------------
 // Batched host -> device copy AS A KERNEL: up to 16 (dst, src, bytes) items in one launch, src = pinned (device-mapped) host
-// memory read over the host link by the copying lanes.  Why not hipMemcpyAsync: the training loop uploads a ~1.4 MB batch per
-// step (scripts/train.py:1153-1166) from a host that runs a whole step ahead of the card; a copy-engine transfer that is ordered
-// behind pending work of its stream made the host WAIT inside hipMemcpyAsync until that work had drained (measured: the fed step
-// 28-42 ms instead of 15 ms, the card idle half of the time), whereas a kernel is just one more launch in the queue.  At this
-// size the link's latency, not its bandwidth, is what the copy costs (tens of microseconds, on a stream that is idle then).
+// memory read over the host link by the copying lanes.  The training loop uploads a ~1.4 MB batch of nine small tensors per step
+// (scripts/train.py:1153-1166): one launch in the stream's queue, ordered like any other kernel, instead of nine copy-engine
+// transfers with their engine hand-offs.  At this size the link's latency, not its bandwidth, is what the copy costs (tens of
+// microseconds, on a stream that is idle then).
 // ---------------------------------------------------------------------------
 struct CopyBatch {
   void* dst[16];

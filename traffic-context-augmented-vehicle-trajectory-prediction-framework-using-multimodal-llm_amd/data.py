@@ -283,22 +283,25 @@ class DeviceFeeder:
     """Host -> device feeding of the training loop (scripts/train.py:1153-1166).
 
     The reference moves seven tensors of every batch with blocking ``.to(device)`` calls from pageable memory at the head of
-    the step.  Here a batch goes through a ring of `slots` (>= 3) staging sets: pinned host buffers, then
-    ``copy_(non_blocking=True)``, and the step is told WHEN its inputs are ready (``FedBatch.ready``, an event) instead of
-    waiting for them on the host: ``Trainer.step(..., inputs_ready=fed.ready)``.  With the pipelined decoder
-    (training.Trainer, frozen-MLLM variant) three batches are alive at once -- step i's head and backward, step i + 1's
-    decoder, and the copy of batch i + 2 -- hence the ring.
+    the step.  Here a batch goes through a ring of `slots` (>= 3) staging sets: pinned host buffers, then ONE copy kernel
+    (tcavt_copy_batch: its lanes read the pinned buffers over the host link), and the step is told WHEN its inputs are ready
+    (``FedBatch.ready``, an event) instead of waiting for them on the host: ``Trainer.step(..., inputs_ready=fed.ready)``.
+    With the pipelined decoder (training.Trainer, frozen-MLLM variant) three batches are alive at once -- step i's head and
+    backward, step i + 1's decoder, and the copy of batch i + 2 -- hence the ring.
 
-    The copy is ONE kernel launch (tcavt_copy_batch: its lanes read the pinned buffers over the host link) enqueued on the CALLER'S stream (the stream the steps are enqueued on): put(batch i + 1) is called before
-    step i is enqueued, so on the card the copy runs after step i - 1's optimizer and before step i's head -- while the decoder
-    of step i is busy on its own stream and the caller's stream would be idle anyway (~1.4 MB, nine small copies).  Stream
-    order is then all the protection a slot needs: whatever read the slot three batches ago was enqueued, or joined, on the
-    same stream before.  No stream of its own and no stream-side wait for a late event: HIP folds its streams onto four
-    hardware queues, a stream that waits for "the step three batches back has finished" holds its hardware queue until then,
-    and whichever stream shares that queue stands still with it (measured with the copies on a side stream behind such a
-    wait: 42.7 instead of 15.1 ms per step); and the pipelined step keeps its cross-step overlap only while at most five
-    streams are in use.  A `stream` may still be given (e.g. a loader thread's own); its copies then wait
-    for ``release()`` of the slot's previous user on the HOST."""
+    The copy is enqueued on the CALLER'S stream (the stream the steps are enqueued on): put(batch i + 1) is called before
+    step i is enqueued, so on the card it runs after step i - 1's optimizer and before step i's head -- while the decoder of
+    step i is busy on its own stream and the caller's stream would be idle anyway.  Stream order is then all the protection a
+    slot needs (whatever read it three batches ago was enqueued, or joined, on the same stream before), and no sixth stream
+    appears: the pipelined step keeps its cross-step overlap only while at most five are in use.  A
+    `stream` may still be given (e.g. a loader thread's own); its copies then wait for ``release()`` of the slot's previous
+    user on the HOST (a stream-side wait for an event that late would hold the stream's hardware queue).
+
+    Host threads: keep torch's intra-op pool small in the feeding process (``torch.set_num_threads(2)``).  The collate and the
+    staging copies are a few small CPU ops; at its default size the pool starts one thread per CPU the machine SHOWS, not per
+    CPU the process may use, and under a container's CPU quota the spinning threads get the whole process frozen for the
+    rest of the scheduler period: measured 90 ms stalls every few steps, 31-42 instead of 15.3 ms per step
+    (profiles/r04_feed_host.txt)."""
 
     TENSOR_KEYS = ("traj_emb", "target_traj", "vision_emb", "lane_polygon", "input_ids", "attention_mask", "labels")
     LIST_KEYS = (("lane_polygon_len", torch.int32), ("norm_stat", torch.float32))
@@ -347,8 +350,7 @@ class DeviceFeeder:
         self.bytes_per_batch = sum(t.numel() * t.element_size() for t in host.values())
         st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
         with torch.cuda.stream(st):
-            # ONE kernel launch that reads the pinned buffers over the host link (ops.copy_batch), not copy-engine transfers: a
-            # hipMemcpyAsync ordered behind the stream's pending work made the host wait for that work inside the call
+            # ONE kernel launch that reads the pinned buffers over the host link (ops.copy_batch) instead of nine copy-engine transfers
             names = list(host)
             ops.copy_batch([slot["dev"][n] for n in names], [slot["pin"][n] for n in names])
             ev = torch.cuda.Event()
