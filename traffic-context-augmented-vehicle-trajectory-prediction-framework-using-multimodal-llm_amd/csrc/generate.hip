@@ -206,6 +206,22 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {  // (
 // the selected token is the same.  A slice whose threshold bin overflows its list (e.g. constant logits) raises ovf[b] and the
 // sample falls back to the three passes of the one-stage form (its processors are done).
 // ---------------------------------------------------------------------------
+// Does token t occur among the first n entries of an LDS-resident history?  Four entries per LDS read and NO early exit: written
+// as "scan until found", thread i's loop is a chain of up to i dependent LDS round trips (one ~100-cycle latency per entry:
+// 15 us for a 300-token history -- a quarter of the whole selection kernel); without the data-dependent exit the reads pipeline.
+__device__ __forceinline__ bool occurs_before(const int* __restrict__ lds_tok, int n, int t) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  bool dup = false;
+  int j = 0;
+#pragma unroll 4
+  for (; j + 4 <= n; j += 4) {
+    const i32x4 q = *reinterpret_cast<const i32x4*>(lds_tok + j);
+    dup |= (q[0] == t) | (q[1] == t) | (q[2] == t) | (q[3] == t);
+  }
+  for (; j < n; ++j) dup |= lds_tok[j] == t;
+  return dup;
+}
+
 constexpr int SMP_G = 16;      // slices (stage-1 workgroups) per sample
 constexpr int SMP_LCAP = 512;  // candidates per slice
 constexpr int SMP_E4 = 4;      // f32x4 registers per thread: slices of up to 4 * 1024 * 4 scores (V <= 262 144)
@@ -223,7 +239,7 @@ __global__ __launch_bounds__(SMP_T) void sample_slice_kernel(float* __restrict__
                                                              int hist_cap, const int* __restrict__ hist_len, SampleP sp, SliceWs ws) {
   __shared__ int hist_bins[SMP_BINS];
   __shared__ float lv[SMP_LCAP];
-  __shared__ int li[SMP_LCAP];
+  __shared__ __attribute__((aligned(16))) int li[SMP_LCAP];
   __shared__ float rv[SMP_T / 64], rm[SMP_T / 64];
   __shared__ int ri[SMP_T / 64];
   __shared__ float s_max, s_min;
@@ -236,17 +252,22 @@ __global__ __launch_bounds__(SMP_T) void sample_slice_kernel(float* __restrict__
   const int lo4 = g * chunk4, hi4 = min(lo4 + chunk4, V4);
   const long lo = 4L * lo4, hi = 4L * hi4;
   // ---- processors, for the tokens this slice owns (same arithmetic and order as the one-stage form: penalty, then ban)
-  if (sp.rep_penalty != 1.f) {
-    const bool in_lds = hl <= SMP_LCAP;
-    if (in_lds) {
-      for (int i = tid; i < hl; i += SMP_T) li[i] = (int)min(max(hist[i], -1L), 0x7fffffffL);
-      __syncthreads();
-    }
+  // (the history goes to LDS once when it fits, and both processors read it there: every global access the processors make is
+  //  one more dependent round trip at the head of a kernel that is a handful of them long)
+  const bool in_lds = hl <= SMP_LCAP;
+  const int ng = sp.no_repeat_ngram;
+  const bool do_rep = sp.rep_penalty != 1.f, do_ban = ng > 0 && hl + 1 >= ng;
+  if (in_lds && (do_rep || do_ban)) {
+    for (int i = tid; i < hl; i += SMP_T) li[i] = (int)min(max(hist[i], -1L), 0x7fffffffL);  // (ids >= 2^31 - 1 are out of range anyway)
+    __syncthreads();
+  }
+  auto tok_at = [&](int i) -> long { return in_lds ? (long)li[i] : hist[i]; };
+  if (do_rep) {
     for (int i = tid; i < hl; i += SMP_T) {
-      const long t = hist[i];
+      const long t = tok_at(i);
       bool first = t >= lo && t < hi;
       if (in_lds) {
-        for (int j = 0; j < i && first; ++j) first = li[j] != (int)t;
+        first = first && !occurs_before(li, i, (int)t);
       } else {
         for (int j = 0; j < i && first; ++j) first = hist[j] != t;
       }
@@ -257,12 +278,11 @@ __global__ __launch_bounds__(SMP_T) void sample_slice_kernel(float* __restrict__
     }
     __syncthreads();
   }
-  const int ng = sp.no_repeat_ngram;
-  if (ng > 0 && hl + 1 >= ng) {
+  if (do_ban) {
     for (int i = tid; i + ng - 1 < hl; i += SMP_T) {
       bool match = true;
-      for (int k = 0; k < ng - 1 && match; ++k) match = hist[i + k] == hist[hl - (ng - 1) + k];
-      const long t = hist[i + ng - 1];
+      for (int k = 0; k < ng - 1 && match; ++k) match = tok_at(i + k) == tok_at(hl - (ng - 1) + k);
+      const long t = tok_at(i + ng - 1);
       if (match && t >= lo && t < hi) x[t] = -INFINITY;
     }
     __syncthreads();
@@ -415,7 +435,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
   __shared__ int besti;
   __shared__ int hist_bins[SMP_BINS];
   __shared__ float list_v[SMP_LIST];
-  __shared__ int list_i[SMP_LIST];
+  __shared__ __attribute__((aligned(16))) int list_i[SMP_LIST];
   __shared__ int list_n, thr_bin, keep_n;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* x = logits + (long)b * V;
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       const long t = hist[i];
       bool first = t >= 0 && t < V;
       if (in_lds) {
-        for (int j = 0; j < i && first; ++j) first = list_i[j] != (int)t;
+        first = first && !occurs_before(list_i, i, (int)t);
       } else {
         for (int j = 0; j < i && first; ++j) first = hist[j] != t;
       }
@@ -551,18 +571,28 @@ __global__ __launch_bounds__(SMP_T) void sample_kernel(float* __restrict__ logit
       // two-stage form: every slice's candidates at or above the largest of the slices' bounds (>= k scores of ONE slice lie at
       // or above its bound, so the sample's k-th largest score does too: nothing below it can be kept)
       if (tid == 0) { list_n = 0; keep_n = 0; }
-      float lmax = -INFINITY;
-      for (int g_ = 0; g_ < SMP_G; ++g_) lmax = fmaxf(lmax, ws.lb[b * SMP_G + g_]);
+      // (one slice per WAVE -- SMP_G == SMP_T / 64 -- and every load of a phase in flight together: written as a loop over the
+      //  slices this was 2 x 16 dependent round trips to memory that another CU has just written, 40 us for a ~10 us kernel)
+      static_assert(SMP_G == SMP_T / 64, "one wave per slice");
+      float lmax = ws.lb[b * SMP_G + (lane & (SMP_G - 1))];
+#pragma unroll
+      for (int o = 1; o < SMP_G; o <<= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+      const int n_g = ws.cand_n[b * SMP_G + wv];
+      const long s0 = ((long)b * SMP_G + wv) * SMP_LCAP;
+      float cvv[SMP_LCAP / 64];
+      int cii[SMP_LCAP / 64];
+#pragma unroll
+      for (int e = 0; e < SMP_LCAP / 64; ++e) {
+        const int t_ = lane + 64 * e;
+        cvv[e] = t_ < n_g ? ws.cand_v[s0 + t_] : -INFINITY;
+        cii[e] = t_ < n_g ? ws.cand_i[s0 + t_] : 0;
+      }
       __syncthreads();
-      for (int g_ = 0; g_ < SMP_G; ++g_) {
-        const int n_g = ws.cand_n[b * SMP_G + g_];
-        const long s0 = ((long)b * SMP_G + g_) * SMP_LCAP;
-        for (int t_ = tid; t_ < n_g; t_ += SMP_T) {
-          const float v = ws.cand_v[s0 + t_];
-          if (v >= lmax) {
-            const int slot = atomicAdd(&list_n, 1);
-            if (slot < SMP_LIST) { list_v[slot] = v; list_i[slot] = ws.cand_i[s0 + t_]; }
-          }
+#pragma unroll
+      for (int e = 0; e < SMP_LCAP / 64; ++e) {
+        if (lane + 64 * e < n_g && cvv[e] >= lmax) {
+          const int slot = atomicAdd(&list_n, 1);
+          if (slot < SMP_LIST) { list_v[slot] = cvv[e]; list_i[slot] = cii[e]; }
         }
       }
       __syncthreads();
