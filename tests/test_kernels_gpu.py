@@ -726,7 +726,7 @@ def test_gemm_norm_out_fp32_and_16bit_stream(gpu, M, tile, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,H", [(37, 256), (8, 2048), (5, 8192)])
+@pytest.mark.parametrize("M,H", [(37, 256), (8, 2048), (5, 8192), (3, 768), (9, 4352)])
 def test_rmsnorm16(gpu, M, H, dt):
     from tcavt_amd import ops
 

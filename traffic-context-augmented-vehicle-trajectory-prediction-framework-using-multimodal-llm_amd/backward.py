@@ -83,6 +83,7 @@ class Backward:
         self.pl, self.pp = prefix_ltsf, prefix_poly
         self.ws = model.ltsf._ws  # scratch for gradient activations
         self._leaf_streams, self._poly_stream, self._leaf_i = None, None, 0
+        self.poly_after_chain = False  # training.Trainer: True for the LoRA-trainable variant (see _ltsf_stage)
         self._v_ready = None
         self._serial = os.environ.get("TCAVT_BW_SERIAL", "") == "1"
 
@@ -407,6 +408,16 @@ class Backward:
         a.pos_ld = G[pl + "pos_encoding"].shape[-1]
         if on_poly_grad is None:
             ops.ltsf_backward(a, 3)
+        elif self.poly_after_chain and torch.cuda.is_available():
+            # the caller's stream has a long chain to go after this backward (the decoder's, LoRA-trainable variant) and the host
+            # is NOT ahead of the card here: enqueuing the lane-polygon encoder's ~45 launches first left the caller's stream idle
+            # for their whole enqueue time (585 us per step in the timeline).  The chain goes first; the side stream still starts
+            # from the point where d(poly_emb) exists.
+            ops.ltsf_backward(a, 1)
+            ev = torch.cuda.Event()
+            ev.record()
+            ops.ltsf_backward(a, 2)
+            on_poly_grad(g_poly, ev)
         else:
             ops.ltsf_backward(a, 1)
             on_poly_grad(g_poly)  # the lane-polygon encoder's backward can start here, beside the rest of this one
@@ -775,7 +786,12 @@ class Backward:
                 self._v_ready = torch.cuda.Event()
                 self._v_ready.record()
 
-        def start_polygon(g_poly):
+        def start_polygon(g_poly, after=None):
+            if after is not None:  # (ordered after an event recorded earlier on the caller's stream, not after "now")
+                self._poly_stream.wait_event(after)
+                with torch.cuda.stream(self._poly_stream):
+                    self.polygon(g_poly)
+                return
             with _Fork(self._poly_stream):
                 self.polygon(g_poly)
 
@@ -787,6 +803,18 @@ class Backward:
                 self._leaf_streams[0].wait_stream(ls)
             with _Fork(self._leaf_streams[0]):
                 after_ltsf()
-        main.wait_stream(self._poly_stream)
+        # the leaves join here (the LoRA-trainable variant's decoder backward starts from dL/dk, dL/dv, which a leaf stream produced)
         for ls in self._leaf_streams:
             main.wait_stream(ls)
+        self._join_pending = True
+        if not self.poly_after_chain:
+            self.join()
+
+    def join(self):
+        """The caller's stream waits for the lane-polygon encoder's backward (its own side stream).  run() does this itself unless
+        poly_after_chain is set: then the caller continues its own chain first (the decoder's backward) and joins before it
+        reads those gradients (training.Trainer)."""
+        if not getattr(self, "_join_pending", False) or self._poly_stream is None:
+            return
+        torch.cuda.current_stream().wait_stream(self._poly_stream)
+        self._join_pending = False

@@ -328,42 +328,70 @@ namespace {
 template <bool F16>
 __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, float eps,
                                                         bf16_t* __restrict__ out16, float* __restrict__ out_f32, int M, int H) {
+  // one wave per row, 16-byte accesses (8 elements per lane and step: 512 columns per wave-instruction), the row in registers when
+  // H <= 4096, every load of the row requested before the first is used (the first version moved 8 bytes per lane and step and ran
+  // at 0.9 TB/s: 71 us for the decoder's final norm at M = 8192, on the decoder stream's critical path)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const bf16_t* xr = x + row * H;
-  constexpr int NV = 16;  // 16 x 256 = 4096 columns in registers
-  u32x2 w[NV];
+  constexpr int NV = 8;  // 8 x 512 = 4096 columns in registers
+  u32x4 w[NV];
   float ss = 0.f;
-  const int nv = H >> 8;  // (H % 256 == 0)
-  auto sq = [&](const u32x2& v) {
-    const float a = from16_lo<F16>(v[0]), b = from16_hi<F16>(v[0]), c = from16_lo<F16>(v[1]), d = from16_hi<F16>(v[1]);
-    ss += a * a + b * b + c * c + d * d;
+  const int nv = H >> 9, tail = H & 511;  // whole 512-column steps, then one 256-column step (H % 256 == 0)
+  auto sq4 = [&](const u32x4& v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = from16_lo<F16>(v[e]), b = from16_hi<F16>(v[e]);
+      ss += a * a + b * b;
+    }
   };
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (i < nv) {
-      w[i] = *reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4);
-      sq(w[i]);
-    }
-  for (int i = NV; i < nv; ++i) sq(*reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4));
+    if (i < nv) w[i] = *reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8);
+  u32x2 wt = {0u, 0u};
+  if (tail) wt = *reinterpret_cast<const u32x2*>(xr + nv * 512 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i < nv) sq4(w[i]);
+  for (int i = NV; i < nv; ++i) sq4(*reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8));
+  if (tail) {
+    const float a = from16_lo<F16>(wt[0]), b = from16_hi<F16>(wt[0]), c = from16_lo<F16>(wt[1]), d = from16_hi<F16>(wt[1]);
+    ss += a * a + b * b + c * c + d * d;
+  }
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)H + eps);
-  auto emit = [&](int i, const u32x2& v) {
-    const int c = i * 256 + lane * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-    f32x4 y;
-    y[0] = from16_lo<F16>(v[0]) * rs * g[0];
-    y[1] = from16_hi<F16>(v[0]) * rs * g[1];
-    y[2] = from16_lo<F16>(v[1]) * rs * g[2];
-    y[3] = from16_hi<F16>(v[1]) * rs * g[3];
-    if (out16) *reinterpret_cast<u32x2*>(out16 + row * H + c) = u32x2{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
-    if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = y;
+  auto emit8 = [&](int c, const u32x4& v) {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      y[2 * e] = from16_lo<F16>(v[e]) * rs * (e < 2 ? g0[2 * e] : g1[2 * e - 4]);
+      y[2 * e + 1] = from16_hi<F16>(v[e]) * rs * (e < 2 ? g0[2 * e + 1] : g1[2 * e - 3]);
+    }
+    if (out16)
+      *reinterpret_cast<u32x4*>(out16 + row * H + c) = u32x4{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3]),
+                                                             pack16x2<F16>(y[4], y[5]), pack16x2<F16>(y[6], y[7])};
+    if (out_f32) {
+      *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = f32x4{y[0], y[1], y[2], y[3]};
+      *reinterpret_cast<f32x4*>(out_f32 + row * H + c + 4) = f32x4{y[4], y[5], y[6], y[7]};
+    }
   };
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (i < nv) emit(i, w[i]);
-  for (int i = NV; i < nv; ++i) emit(i, *reinterpret_cast<const u32x2*>(xr + i * 256 + lane * 4));
+    if (i < nv) emit8(i * 512 + lane * 8, w[i]);
+  for (int i = NV; i < nv; ++i) emit8(i * 512 + lane * 8, *reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8));
+  if (tail) {
+    const int c = nv * 512 + lane * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 y;
+    y[0] = from16_lo<F16>(wt[0]) * rs * g[0];
+    y[1] = from16_hi<F16>(wt[0]) * rs * g[1];
+    y[2] = from16_lo<F16>(wt[1]) * rs * g[2];
+    y[3] = from16_hi<F16>(wt[1]) * rs * g[3];
+    if (out16) *reinterpret_cast<u32x2*>(out16 + row * H + c) = u32x2{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
+    if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = y;
+  }
 }
 }  // namespace
 

@@ -92,6 +92,7 @@ class Trainer:
         self.bw = Backward(model, self.book)
         self.lbw = None
         if self.lora_trainable:
+            self.bw.poly_after_chain = True  # (the decoder's backward follows on the caller's stream: backward.Backward._ltsf_stage)
             self.lbw = LoraBackward(model, self.book)
             model.mllm.llama_wrapper.save_for_backward = True
             model.ltsf.absorb_kv = False  # _lora_backward starts from dL/dk, dL/dv of the un-absorbed cross-attention
@@ -222,10 +223,13 @@ class Trainer:
             fh_b = m.last.final_hidden_bf16  # [B * L + 64 zeroed pad rows, H]
             self.bw.run(decoded, y.contiguous(), ns, x.contiguous(), m.last.poly_emb, fh_b, L,
                         after_ltsf=lambda: self._allreduce_bucket(0, self.n_ltsf))
-            self._allreduce_bucket(self.n_ltsf, self.n_base)
             if self.lbw is not None:
-                self._lora_backward(B, L)
+                self._lora_backward(B, L)   # (the caller's chain continues; the lane-polygon encoder's backward runs beside it)
+                self.bw.join()
+                self._allreduce_bucket(self.n_ltsf, self.n_base)
                 self._allreduce_bucket(self.n_base, self.book.total)
+            else:
+                self._allreduce_bucket(self.n_ltsf, self.n_base)
         self._last_loss = loss
         return loss, decoded
 
