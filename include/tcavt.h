@@ -447,9 +447,11 @@ int tcavt_rmsnorm_bwd(const void* x, const float* gamma, const void* gy_bf16, co
                       float* gx, void* gx_bf16, int accumulate, int M, int H, int gy_dtype, int out_dtype,
                       const float* gy_scale, int x_dtype, tcavt_stream_t stream);
 /* scale[0] = S = 2^k with max|g_a, g_b| * S in [target / 2, target], scale[1] = 1 / S, decided on the device (S = 1 for
-   all-zero or non-finite input); g_a, g_b (optional) 16-bit [n] of dtype16; scratch: one uint32, zero-initialised once */
+   all-zero or non-finite input); g_a, g_b (optional) 16-bit [n] of dtype16; scratch: one uint32, zero-initialised once.
+   backoff (optional device int32): S is divided by 2^*backoff -- dynamic loss scaling: tcavt_adamw_gated raises its ctl[6] by
+   four when it skips an update for a non-finite gradient norm and gives one back per 256 applied updates */
 int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n, int dtype16, float target, float* scale,
-                          uint32_t* scratch, tcavt_stream_t stream);
+                          uint32_t* scratch, const int32_t* backoff, tcavt_stream_t stream);
 /* fp32 gradient of the rotated q|k|v [M, ncols] -> bf16 gradient of the projection outputs: transposed RoPE rotation on
    the first rope_cols columns (heads of 64), plain conversion on the rest; tables as for TCAVT_EPI_ROPE ([L, 32]) */
 int tcavt_rope_bwd_pack(const float* g32, void* out_bf16, const float* rope_cos, const float* rope_sin, int64_t M,
@@ -731,6 +733,8 @@ typedef struct tcavt_llama_backward_args {
   float lora_dropout_p;                /* > 0: the forward's masks, sites lora_first_site + 2 l (q_proj), + 2 l + 1 (v_proj) */
   uint32_t lora_first_site;
   uint64_t dropout_seed;
+  const int32_t* scale_backoff;        /* optional device int32: extra binary orders of headroom under the picked scale
+                                          (tcavt_grad_scale_pick's `backoff`; tcavt_adamw_gated keeps it in ctl[6]) */
 } tcavt_llama_backward_args;
 
 int tcavt_llama_stack_backward(const tcavt_llama_backward_args* args, tcavt_stream_t stream);
@@ -1067,7 +1071,8 @@ int tcavt_event_elapsed_ms(void* start, void* stop, float* ms);
  * *loss (device fp32 scalar) is not finite -- or, if grad_norm != NULL (e.g. scratch + 1025 of tcavt_clip_grad_norm),
  * when the exchanged gradient's norm is not finite, which keeps data-parallel ranks in step where the reference's
  * rank-local test would not.  The optimizer's step count lives on the device: ctl int32[8], zero-initialised by the
- * caller once; ctl[0] = applied updates so far, ctl[1] = skipped updates, ctl[2] = 1 if this call was skipped. */
+ * caller once; ctl[0] = applied updates so far, ctl[1] = skipped updates, ctl[2] = 1 if this call was skipped, ctl[6] = the
+ * fp16 backward's scale back-off (+4 per skipped update, capped at 24; -1 per 256 applied updates: tcavt_grad_scale_pick). */
 int tcavt_adamw_gated(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, float grad_scale, const float* loss, const float* grad_norm,
                       int32_t* ctl, tcavt_stream_t stream);

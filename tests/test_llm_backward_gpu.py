@@ -389,6 +389,21 @@ def test_adamw_gated_skips_nonfinite_loss(gpu):
     ops.adamw_gated(p, torch.ones(n, device=dev), m, v, 5e-4, 0.9, 0.999, 1e-8, 1e-4,
                     torch.ones(1, device=dev), ctl, grad_norm=torch.full((1,), float("nan"), device=dev))
     assert torch.equal(p, before) and ctl[:3].tolist() == [3, 3, 1]
+    # dynamic loss scaling of the fp16 backward: every skipped update bought four binary orders of headroom (ctl[6], capped at 24) ...
+    assert ctl[6].item() == 12 and ctl[7].item() == 0
+    gfin = (torch.randn(4096, generator=g) * 3.0).to(torch.bfloat16).to(dev)
+    scale, scratch = torch.zeros(2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.grad_scale_pick(gfin, None, scale, scratch)
+    s_plain = scale[0].item()
+    ops.grad_scale_pick(gfin, None, scale, scratch, backoff=ctl[6:7])
+    assert scale[0].item() == s_plain / 4096 and scale[1].item() == 4096 / s_plain
+    amax = gfin.float().abs().max().item()
+    assert 128.0 <= amax * s_plain <= 256.0
+    # ... and 256 applied updates in a row give one back
+    one = torch.ones(1, device=dev)
+    for _ in range(256):
+        ops.adamw_gated(p, torch.zeros(n, device=dev), m, v, 0.0, 0.9, 0.999, 1e-8, 0.0, one, ctl)
+    assert ctl[6].item() == 11 and ctl[7].item() == 0 and ctl[1].item() == 3
 
 
 @pytest.mark.parametrize("xdt", [torch.bfloat16, torch.float16])

@@ -188,7 +188,7 @@ class LlamaBackwardArgs(ctypes.Structure):
         ("I", ctypes.c_int32), ("nq", ctypes.c_int32), ("nkv", ctypes.c_int32), ("dtype16", ctypes.c_int32),
         ("npart", ctypes.c_int32), ("lora_rank", ctypes.c_int32), ("input_grad", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
-        ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
+        ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64), ("scale_backoff", c_void_p),
     ]
 
 
@@ -258,7 +258,7 @@ _SIGNATURES = {
                           c_void_p, c_int, c_void_p],
     "tcavt_lora_dgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.c_uint64, ctypes.c_uint32,
                          ctypes.c_uint32, c_int, c_void_p],
-    "tcavt_grad_scale_pick": [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "tcavt_grad_scale_pick": [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "tcavt_rope_bwd_pack": [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     "tcavt_attn_causal_gqa_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                   c_void_p],

@@ -567,6 +567,11 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // exchanged gradient's norm) and keeps the optimizer's step count on the device, so that the bias corrections of a
 // later step are those of torch.optim.AdamW after the same number of APPLIED updates.
 //   ctl[0] = applied steps, ctl[1] = skipped steps, ctl[2] = 1 if this call is skipped, ctl[4], ctl[5] = bc1, bc2 (float bits)
+//   ctl[6] = scale back-off of the fp16 backward (tcavt_grad_scale_pick reads it), ctl[7] = applied updates since it last changed:
+//   dynamic loss scaling as mixed-precision training does it, decided on the device -- a skipped update (the 16-bit gradient chain
+//   left the half range somewhere, the norm came out non-finite) buys the NEXT steps four more binary orders of headroom; 256
+//   applied updates in a row give one back.  Without it the same overflow recurred step after step until the loss had moved
+//   (full-size whole-set variant: updates 2 and 3 of a run skipped), and nothing would ever recover a run that stays there.
 __global__ void adamw_gate_kernel(const float* __restrict__ loss, const float* __restrict__ norm, int* __restrict__ ctl,
                                   float b1, float b2) {
   const bool ok = isfinite(*loss) && (norm == nullptr || isfinite(*norm));
@@ -575,9 +580,15 @@ __global__ void adamw_gate_kernel(const float* __restrict__ loss, const float* _
     ctl[2] = 0;
     ctl[4] = __float_as_int(1.f - powf(b1, (float)step));
     ctl[5] = __float_as_int(1.f - powf(b2, (float)step));
+    if (ctl[6] > 0 && ++ctl[7] >= 256) {
+      --ctl[6];
+      ctl[7] = 0;
+    }
   } else {
     ++ctl[1];
     ctl[2] = 1;
+    ctl[6] = min(ctl[6] + 4, 24);
+    ctl[7] = 0;
   }
 }
 __global__ void adamw_gated_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

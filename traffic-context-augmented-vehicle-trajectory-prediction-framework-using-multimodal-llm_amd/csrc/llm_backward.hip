@@ -1559,13 +1559,16 @@ __global__ __launch_bounds__(256) void grad_amax_kernel(const bf16_t* __restrict
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax_bits, __float_as_uint(m));  // (non-negative floats order as their bits; NaN is dropped by fmaxf)
 }
-__global__ void grad_scale_set_kernel(unsigned int* __restrict__ amax_bits, float target, float* __restrict__ scale) {
+__global__ void grad_scale_set_kernel(unsigned int* __restrict__ amax_bits, float target, float* __restrict__ scale,
+                                      const int* __restrict__ backoff) {
   const float m = __uint_as_float(*amax_bits);
   float s = 1.f;
   if (m > 0.f && m < 3.0e38f) {
     int e;
     (void)frexpf(target / m, &e);       // target / m = f * 2^e, f in [0.5, 1)
-    e = max(-60, min(60, e - 1));       // 2^(e-1) <= target / m
+    // backoff (tcavt_adamw_gated's ctl[6]): binary orders of extra headroom, raised by four whenever an update was skipped for
+    // a non-finite gradient norm -- the walk grew the gradient by more than the 2^8 the target leaves -- and given back slowly
+    e = max(-60, min(60, e - 1 - (backoff ? *backoff : 0)));       // 2^(e-1) <= target / m
     s = ldexpf(1.f, e);
   }
   scale[0] = s;
@@ -1846,7 +1849,8 @@ extern "C" int tcavt_llama_stack_backward(const tcavt_llama_backward_args* a, tc
   const bool two = lf != st;
   const bool f16 = dt == TCAVT_F16;
   const int gdt = f16 ? TCAVT_BF16 : dt;  // type of the incoming gradients
-  if (f16) TCAVT_TRY(tcavt_grad_scale_pick(a->g_final_a, a->g_final_b, (int64_t)M * H, TCAVT_BF16, 256.f, a->scale, a->scale_scratch, stream));
+  if (f16) TCAVT_TRY(tcavt_grad_scale_pick(a->g_final_a, a->g_final_b, (int64_t)M * H, TCAVT_BF16, 256.f, a->scale, a->scale_scratch,
+                                           a->scale_backoff, stream));
   const float* inv_s = a->scale + 1;
   // final norm: g_h = d(rmsnorm)(h_last) . (g_final_a + g_final_b) * S,  g_hb = its 16-bit copy
   TCAVT_TRY(tcavt_rmsnorm_bwd(a->h_last, a->gamma_final, a->g_final_a, a->g_final_b, a->rms_eps, a->g_h, a->g_hb, 0, M, H, gdt, dt,
@@ -2007,7 +2011,7 @@ extern "C" int tcavt_lora_wgrad_a(const void* x16, const float* part, int npart,
 }
 
 extern "C" int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n, int dtype16, float target, float* scale,
-                                     uint32_t* scratch, tcavt_stream_t stream) {
+                                     uint32_t* scratch, const int32_t* backoff, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(g_a && scale && scratch && n > 0 && n % 8 == 0 && is16(dtype16) && target > 0.f && aligned16(g_a) && aligned16(g_b),
                   "grad_scale_pick: bad args (n %% 8 == 0, 16-byte alignment, scratch = one zero-initialised uint32)");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2016,7 +2020,7 @@ extern "C" int tcavt_grad_scale_pick(const void* g_a, const void* g_b, int64_t n
   auto kfn = dtype16 == TCAVT_F16 ? grad_amax_kernel<true> : grad_amax_kernel<false>;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const bf16_t*>(g_a), static_cast<const bf16_t*>(g_b),
                      (long)(n / 8), scratch);
-  hipLaunchKernelGGL(grad_scale_set_kernel, dim3(1), dim3(1), 0, st, scratch, target, scale);
+  hipLaunchKernelGGL(grad_scale_set_kernel, dim3(1), dim3(1), 0, st, scratch, target, scale, backoff);
   TCAVT_CHECK_LAUNCH("grad_scale_pick");
   return TCAVT_OK;
 }

@@ -112,6 +112,7 @@ def attn_bwd_composed(buf, qkv, dO, kv_len, B, T, nq, nkv, scale, cos, sin, g_qk
 class LoraBackward:
     def __init__(self, model, book):
         self.m, self.book = model, book
+        self.scale_backoff = None  # device int32 [1]: training.Trainer points it at the gated optimizer's ctl[6] (dynamic loss scaling)
         self.lw = model.mllm.llama_wrapper
         if not self.lw.use_lora:
             raise ValueError("LoraBackward: the model has no LoRA adapters (use_lora=False)")
@@ -157,6 +158,7 @@ class LoraBackward:
         a.g_final_a, a.g_final_b = g_final_a.data_ptr(), None if g_final_b is None else g_final_b.data_ptr()
         a.rope_cos, a.rope_sin, a.kv_len = cos.data_ptr(), sin.data_ptr(), tape.kv_len.data_ptr()
         a.scale, a.scale_scratch = scale.data_ptr(), self._buf("scale_scratch", (1,), torch.int32, zero=True).data_ptr()
+        a.scale_backoff = None if self.scale_backoff is None else self.scale_backoff.data_ptr()
         for k in ("g_h", "g_hb", "g_xn", "g_xl", "g_att", "dA", "dB"):
             setattr(a, k, buf[k].data_ptr())
         a.g_qkv0, a.g_qkv1, a.g_t0, a.g_t1 = buf["g_qkv"][0].data_ptr(), buf["g_qkv"][1].data_ptr(), buf["g_t"][0].data_ptr(), buf["g_t"][1].data_ptr()
@@ -241,7 +243,8 @@ class LoraBackward:
                 g_h.mul_(inv_s)
             return g_h if self.input_grad else None
         if scaled:
-            ops.grad_scale_pick(g_final_a, g_final_b, scale, self._buf("scale_scratch", (1,), torch.int32, zero=True))
+            ops.grad_scale_pick(g_final_a, g_final_b, scale, self._buf("scale_scratch", (1,), torch.int32, zero=True),
+                                backoff=self.scale_backoff)
         ops.rmsnorm_bwd(tape.h_last, P.g_final, g_final_a, g_h, eps, gy2=g_final_b, gx_bf16=g_hb,
                         gy_scale=scale[0:1] if scaled else None)
         for li in reversed(range(ll.layers)):

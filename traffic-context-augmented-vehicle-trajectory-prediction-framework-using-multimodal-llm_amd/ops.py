@@ -549,7 +549,7 @@ def _DT16(t):
     return _DT[t.dtype]
 
 
-def grad_scale_pick(g_a, g_b, scale, scratch, target=256.0):
+def grad_scale_pick(g_a, g_b, scale, scratch, target=256.0, backoff=None):
     """scale[0] = 2^k with max|g_a, g_b| * 2^k in [target / 2, target], scale[1] = its inverse -- on the device
     (tcavt_grad_scale_pick).  scratch: one zero-initialised int32."""
     n = g_a.numel()
@@ -559,8 +559,10 @@ def grad_scale_pick(g_a, g_b, scale, scratch, target=256.0):
     _need(scale, 2, "grad_scale_pick.scale")
     if scratch.dtype != torch.int32 or scratch.numel() < 1:
         raise capi.TcavtError("grad_scale_pick.scratch: int32 [1] required")
+    if backoff is not None:
+        _req(backoff, torch.int32, "grad_scale_pick.backoff")
     check(lib().tcavt_grad_scale_pick(ptr(g_a), ptr(g_b) if g_b is not None else None, n, _DT16(g_a), float(target), ptr(scale),
-                                      ptr(scratch), stream_ptr()), "tcavt_grad_scale_pick")
+                                      ptr(scratch), ptr(backoff), stream_ptr()), "tcavt_grad_scale_pick")
 
 
 def rmsnorm_bwd(x, gamma, gy, gx, eps, gy2=None, accumulate=False, gx_bf16=None, gy_scale=None):

@@ -129,6 +129,8 @@ class Trainer:
         self._exchange = True
         self.diag = None       # enable_diagnostics(): per-bucket all-reduce timings of the steps that follow
         self._ctl = torch.zeros(8, dtype=torch.int32, device=dev)  # device-side step counters of the gated optimizer
+        if self.lbw is not None:  # the fp16 backward's scale backs off when an update was skipped for a non-finite norm (ctl[6])
+            self.lbw.scale_backoff = self._ctl[6:7]
         self._last_loss = None
         self._skipped_seen = 0  # check_flags(): gated-optimizer skips already reported
         # hipGraph replay of the whole step (capture()): the optimizer's step count and the dropout epoch live on the device
