@@ -183,11 +183,15 @@ typedef struct tcavt_gemm_args {
    * (leading dimension ldc) and the updated stream written to norm_h16 -- out of place, so that a caller can keep the
    * stream of every layer (the LoRA-trainable variant's tape).  NULL: read from norm_h16 (in place). */
   const void* norm_res16;
-  /* Skinny form only (M <= 32: the decode step), optional: a device workspace that lets the launch split K over several
-   * workgroups per block of output columns (partial sums in fp32 slabs, combined by the last arriver in slice order:
-   * bit-reproducible).  Layout: 4096 int32 tickets, ZEROED ONCE by the caller (every launch leaves them zero), then the slabs;
-   * >= 64 KiB, 8.2 MiB covers every shape of the Llama-3.2-1B decode step.  Launches that share it must be stream-ordered.
-   * NULL: one workgroup per column block over all of K (N / 16 workgroups). */
+  /* Optional device workspace for splitting K.  Layout: 4096 int32 tickets, ZEROED ONCE by the caller (every launch leaves them
+   * zero), then fp32 slabs; >= 64 KiB.  Launches that share it must be stream-ordered.
+   *  - skinny form (M <= 32: the decode step): several workgroups per block of output columns, partial sums in the slabs,
+   *    combined by the last arriver in slice order (bit-reproducible); 8.2 MiB covers every shape of the Llama-3.2-1B decode step;
+   *  - the in-place 16-bit residual form (TCAVT_EPI_NORM_OUT with C == NULL, tile 0) on a grid of fewer than ~256 128 x 128
+   *    tiles (M > 32, e.g. B * L = 1024): TWO launches -- S <= 8 partial products over K / S as a batched launch into S slabs
+   *    [M][N] (needs 16 KiB + S * M * N * 4 bytes, else it is not used), then one kernel that adds the slabs in slice order and
+   *    runs the residual epilogue (bit-reproducible; sums in another order than the one-launch form).
+   * NULL: no split. */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
   /* Skinny form only (decode step), optional: the NEXT layer's LoRA down-projection t = scale * h16 . a_cat^T without a launch
@@ -649,6 +653,10 @@ typedef struct tcavt_llama_stack_args {
      2 + 2 * layer (down_proj) into it if it is still 0 (tcavt_gemm_args.nonfinite_flag): the first layer whose output left
      the 16-bit range, or whose inputs already had */
   int32_t* nonfinite_flag;
+  /* optional: workspace for the two-launch split K of the residual projections on grids that leave CUs idle (small B * L:
+     tcavt_gemm_args.splitk_ws; 16 KiB + S * M * H * 4 bytes, S <= 8: 64 MiB covers M <= 2048).  NULL: one launch each */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } tcavt_llama_stack_args;
 
 int tcavt_llama_stack_forward(const tcavt_llama_stack_args* args, tcavt_stream_t stream);

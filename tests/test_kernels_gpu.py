@@ -726,6 +726,60 @@ def test_gemm_norm_out_fp32_and_16bit_stream(gpu, M, tile, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1024, 2048, 4096), (1024, 2048, 8192), (2048, 2048, 8192), (900, 512, 16384)])
+def test_gemm_norm_out_two_launch_split_k(gpu, M, N, K, dt):
+    """The in-place 16-bit residual form on a grid that cannot fill the chip (config 4's small batches): with a workspace the
+    product runs as S partial products (batched launch into fp32 slabs) + one reduce-and-epilogue kernel.  Same contract as the
+    one-launch form (stream updated in place or out of place, partial sums of the ROUNDED values per 64 columns, norm_scale),
+    bit-reproducible run to run; the K order of the sum differs, so the two forms agree to rounding, not bit for bit."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dt).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(dt).to(dev)
+    s0 = (torch.randn(M, N, generator=g) * 2.0).to(dt).to(dev)
+    wsp = torch.zeros((16 << 10) + 8 * 1024 * 2048 * 4, dtype=torch.uint8, device=dev)
+    npart = N // 64
+
+    def run(ws, nscale=0.0, out_of_place=False):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.ldc, a.C = x.data_ptr(), K, w.data_ptr(), K, N, None
+        a.M, a.N, a.K, a.tile, a.epilogue = M, N, K, 0, capi.EPI_NORM_OUT | capi.EPI_RESIDUAL
+        a.in_dtype, a.out_dtype = ops._DT[dt], capi.F32
+        src = s0.clone() if nscale == 0.0 else (s0.float() * nscale).to(dt)
+        dst = torch.zeros_like(src) if out_of_place else src
+        pt = torch.zeros(M, npart, device=dev)
+        a.norm_h16, a.norm_part, a.norm_scale = dst.data_ptr(), pt.data_ptr(), nscale
+        if out_of_place:
+            a.norm_res16 = src.data_ptr()
+        if ws is not None:
+            a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        return dst, pt
+
+    one, p_one = run(None)
+    two, p_two = run(wsp)
+    two_b, p_two_b = run(wsp)
+    assert torch.equal(two, two_b) and torch.equal(p_two, p_two_b)  # slice-order sum: reproducible
+    want = x.float() @ w.float().T + s0.float()
+    ulp = 2.0 ** (-10 if dt == torch.float16 else -7)
+    assert ((two.float() - want).abs() <= ulp * want.abs().clamp_min(2.0 ** -14) * 1.01 + 1e-4).all()
+    assert _rel(two.float(), one.float()) < (3e-4 if dt == torch.float16 else 3e-3)
+    assert _rel(p_two, two.float().view(M, npart, 64).pow(2).sum(-1)) < 1e-5  # sums of what is stored
+    assert (two != one).float().mean().item() < 0.2  # (most elements are even bit-equal: only rounding-boundary cases move)
+    # out of place (the LoRA-trainable variant's tape) and at a stream scale
+    oop, p_oop = run(wsp, out_of_place=True)
+    assert torch.equal(oop, two) and torch.equal(p_oop, p_two)
+    sc, p_sc = run(wsp, nscale=2.0 ** -3)
+    want_s = (x.float() @ w.float().T) * 2.0 ** -3 + (s0.float() * 2.0 ** -3).to(dt).float()
+    assert _rel(sc.float(), want_s) < (5e-4 if dt == torch.float16 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,H", [(37, 256), (8, 2048), (5, 8192), (3, 768), (9, 4352)])
 def test_rmsnorm16(gpu, M, H, dt):
     from tcavt_amd import ops

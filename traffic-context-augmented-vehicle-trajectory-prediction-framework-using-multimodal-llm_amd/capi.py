@@ -162,7 +162,7 @@ class LlamaStackArgs(ctypes.Structure):
         ("kv_lmax", ctypes.c_int32), ("gemm_tile", ctypes.c_int32), ("npart_in", ctypes.c_int32), ("stream_scale", ctypes.c_float),
         ("rms_eps", ctypes.c_float), ("lora_scale", ctypes.c_float), ("lora_dropout_p", ctypes.c_float),
         ("lora_first_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
-        ("nonfinite_flag", c_void_p),
+        ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
     ]
 
 

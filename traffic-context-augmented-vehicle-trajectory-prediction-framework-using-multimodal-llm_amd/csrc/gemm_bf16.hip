@@ -2504,6 +2504,67 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
   return TCAVT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Split K for residual GEMMs that cannot fill the chip (round 4).  At M = 1024 (BASELINE config 4's low end: B = 8, L = 128) the
+// o / down projections are 128 tiles of 128 x 128 -- half the CUs, one 4-wave workgroup each walking 32 / 128 K-tiles alone at
+// ~1 us per K-tile (its waves issue DMA, fragment loads and MFMAs one after the other; nothing else is resident to overlap
+// them): 30 / 90 us where the arithmetic is worth 7 / 29.  With a workspace the launch becomes TWO: (1) the S partial products
+// over K / S as a batched launch of the generic fp32 form into S slabs [M][N] -- 4 x the workgroups, two per CU on the 64 KiB
+// form, each a quarter of the chain -- and (2) this kernel: slabs added in slice order (bit-reproducible), then exactly the
+// in-place 16-bit residual epilogue of TCAVT_EPI_NORM_OUT (round(norm_scale * acc + h16), partial sums of squares of the rounded
+// values per 64 columns, range flag).  No cross-workgroup hand-off inside a kernel: the launch boundary is the reduction's barrier.
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void splitk_norm16_kernel(const float* __restrict__ slabs, int S, long slab_stride,
+                                                            const bf16_t* __restrict__ res16, bf16_t* __restrict__ out16,
+                                                            float* __restrict__ part, int M, int N, long ldc, int npart, float nscale,
+                                                            int has_res, int* __restrict__ nf_flag, int nf_tag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread: 8 consecutive columns of one row
+  const int per_row = N >> 3;
+  const long m = idx / per_row;
+  const int c0 = (int)(idx - m * per_row) * 8;
+  const bool on = m < M;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  u32x4 old = {0u, 0u, 0u, 0u};
+  if (on) {
+    const float* sp = slabs + m * N + c0;
+    if (has_res) old = *reinterpret_cast<const u32x4*>(res16 + m * ldc + c0);
+    for (int s_ = 0; s_ < S; ++s_) {  // (slice order: the sum does not depend on which workgroup finished first)
+      a0 += *reinterpret_cast<const f32x4*>(sp + s_ * slab_stride);
+      a1 += *reinterpret_cast<const f32x4*>(sp + s_ * slab_stride + 4);
+    }
+  }
+  const f32x4 v0 = fma4(a0, nscale, f32x4{from16_lo<F16>(old[0]), from16_hi<F16>(old[0]), from16_lo<F16>(old[1]), from16_hi<F16>(old[1])});
+  const f32x4 v1 = fma4(a1, nscale, f32x4{from16_lo<F16>(old[2]), from16_hi<F16>(old[2]), from16_lo<F16>(old[3]), from16_hi<F16>(old[3])});
+  const u32x4 w = {pack16x2<F16>(v0[0], v0[1]), pack16x2<F16>(v0[2], v0[3]), pack16x2<F16>(v1[0], v1[1]), pack16x2<F16>(v1[2], v1[3])};
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = from16_lo<F16>(w[e]), hi = from16_hi<F16>(w[e]);
+    ss += lo * lo;
+    ss += hi * hi;
+  }
+  if (on) *reinterpret_cast<u32x4*>(out16 + m * ldc + c0) = w;
+  if (!on) ss = 0.f;
+  ss += __shfl_xor(ss, 1, 64);  // the 8 lanes of a 64-column group are consecutive (N % 64 == 0)
+  ss += __shfl_xor(ss, 2, 64);
+  ss += __shfl_xor(ss, 4, 64);
+  if (on && (threadIdx.x & 7) == 0) {
+    part[m * npart + (c0 >> 6)] = ss;
+    if (nf_flag && !(ss <= 3.0e38f)) atomicCAS(nf_flag, 0, nf_tag);
+  }
+}
+
+// slices for the two-launch split: enough 128 x 128 tiles for ~two workgroups per CU, slices of whole K-tiles and >= 2048 deep --
+// measured at M = 1024 (one box, in the model): down (K = 8192) 87.6 -> 53.7 us with S = 4; o (K = 2048) 29.8 -> 29.7 with S = 4
+// and 31.4 -> 40.0 at M = 2048 with S = 2: a 512-deep slice is all pipeline fill, and the reduce kernel costs what the split saves
+static int splitk_slices(int M, int N, int K) {
+  const long wg = (long)((M + 127) / 128) * (N / 128);
+  int S = 1;
+  while (S < 8 && wg * S * 2 <= 512 && K % (S * 2 * 64) == 0 && K / (S * 2) >= 2048) S *= 2;
+  return S;
+}
+
 }  // namespace tcavt
 
 using namespace tcavt;
@@ -2677,6 +2738,27 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
     TCAVT_CHECK_ARG(p.acc_scale == 1.f, "gemm_bf16: acc_scale is only supported by the generic epilogue");
 
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // ---- two-launch split K (splitk_norm16_kernel above): the in-place 16-bit residual form on a grid that leaves CUs idle
+  static const bool no_splitk2 = getenv("TCAVT_GEMM_NO_SPLITK2") != nullptr;  // (A/B switch)
+  if (a->tile == 0 && stream16 && !no_splitk2 && p.sk_slab && a->M > 32 && !skinny_shape(a->M, a->K) && batch == 1 && K2 == 0 &&
+      a->N % 128 == 0 && a->ldc % 8 == 0 && !a->lora_part && a->dropout_p == 0.f) {
+    const int S = splitk_slices(a->M, a->N, a->K);
+    if (S > 1 && (long)S * a->M * a->N * 4 <= p.sk_slab_bytes) {
+      GemmP q = p;
+      q.C = p.sk_slab; q.ldc = a->N; q.out_kind = TCAVT_F32; q.flags = 0; q.K = a->K / S;
+      q.norm_h16 = nullptr; q.norm_part = nullptr; q.res16 = nullptr; q.nf_flag = nullptr; q.residual = nullptr;
+      q.batch_inner = S; q.w_group = 1;
+      q.sAo = 0; q.sAi = a->K / S; q.sWo = 0; q.sWi = a->K / S; q.sCo = 0; q.sCi = (long)a->M * a->N;
+      const int rc = f16 ? dispatch_tile<EPI_GENERIC, true>(q, 0, S, s) : dispatch_tile<EPI_GENERIC, false>(q, 0, S, s);
+      if (rc != TCAVT_OK) return rc;
+      const long threads = (long)a->M * (a->N / 8);
+      auto kfn = f16 ? splitk_norm16_kernel<true> : splitk_norm16_kernel<false>;
+      hipLaunchKernelGGL(kfn, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p.sk_slab, S, (long)a->M * a->N, p.res16, p.norm_h16,
+                         p.norm_part, a->M, a->N, (long)a->ldc, a->N >> 6, p.norm_scale, (epi & TCAVT_EPI_RESIDUAL) ? 1 : 0, p.nf_flag, p.nf_tag);
+      TCAVT_CHECK_LAUNCH("gemm_bf16(split-K reduce)");
+      return TCAVT_OK;
+    }
+  }
   // ---- skinny form: M <= 32 rows (decode step), auto-selected only (tile == 0); norm_out_npart() mirrors this rule
   if (a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f && a->lda >= a->K) {
     const int e0 = a->epilogue & ~TCAVT_EPI_ROWSCALE;

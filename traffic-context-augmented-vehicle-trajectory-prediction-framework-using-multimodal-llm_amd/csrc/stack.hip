@@ -283,6 +283,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_mid; g.norm_res16 = x16; }
       else g.norm_h16 = a->h16;
       g.norm_part = a->part; g.norm_scale = ss_;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 1 + 2 * li;
       ev.rec(4);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
@@ -309,6 +310,7 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
       if (stream16) { g.C = nullptr; g.residual = nullptr; g.norm_h16 = x_out; g.norm_res16 = x_mid; }
       else g.norm_h16 = a->h16;
       g.norm_part = a->part; g.norm_scale = ss_;
+      g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       g.nonfinite_flag = a->nonfinite_flag; g.nonfinite_tag = 2 + 2 * li;
       ev.rec(8);
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));

@@ -843,6 +843,12 @@ class LlamaWithCrossAttnPEFT(nn.Module, _Prepared):
         args.npart_in = self.norm_npart(M)
         args.rms_eps = ll.rms_eps
         args.lora_scale = (self.lora_alpha / self.lora_r) if self.use_lora else 0.0
+        # few tokens (B * L <= 2048: 128 x 128 tiles of o / down leave CUs idle): workspace for the two-launch split K
+        # (tcavt_llama_stack_args.splitk_ws; TCAVT_GEMM_NO_SPLITK2=1 switches it off in the library, A/B)
+        if M <= 2048 and self.stream16 and dev.type == "cuda":
+            skws = ws.get("ll.splitk", ((16 << 10) + 8 * 1024 * H * 4,), torch.uint8, dev, zero=True)
+            args.splitk_ws, args.splitk_ws_bytes = skws.data_ptr(), skws.numel()
+            keep.append(skws)
         if self.stream_scale != 1.0:
             if self.save_for_backward:
                 raise capi.TcavtError("decoder_stack: the tape of the LoRA-trainable variant keeps the streams at scale 1 (stream_scale)")
