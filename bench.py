@@ -637,11 +637,11 @@ def main():
     # HBM-side traffic of the dominant kernel: PMC counters cannot be read inside this process, they come
     # from the committed rocprofv3 --pmc passes of the same kernel / shape (profiles/)
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r03_gateup_gemm_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r04_gateup_gemm_pmc.json")
     if os.path.exists(pmc_path) and (M, 2 * ll.inter, ll.hidden) == (8192, 16384, 2048):
         with open(pmc_path) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r03_gateup_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
+        traffic_src = "profiles/r04_gateup_gemm_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
 
     if rank == 0:
         total = world * B * args.steps
