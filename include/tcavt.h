@@ -148,7 +148,11 @@ typedef struct tcavt_gemm_args {
    * `batch_w_group` consecutive products share one W (the query heads of a grouped-query attention group share a key /
    * value head).  0 or 1: off. */
   int32_t batch_w_group;
-  int32_t reserved0;
+  /* Layout of W.  0: row-major [N][ldw].  TCAVT_W_FRAG16 (1): the fragment-major copy tcavt_pack_weight16 makes -- skinny form
+   * only (M <= 32, tile 0: the decode step; refused elsewhere), ldw == K.  Same arithmetic in the same order: bit-identical
+   * results; what changes is that one wave instruction reads 1 KiB of consecutive bytes instead of 16 rows x 64 bytes that are
+   * K * 2 bytes apart (decode step 1.09 -> 0.91 ms at B = 8: the weight stream was bound by its access pattern, not by HBM) */
+  int32_t w_layout;
   /* TCAVT_EPI_SILU_MUL only, optional: a bf16 copy of the gate|up pre-activations [M, N] (interleaved layout, leading
    * dimension ld_preact) next to the activated output -- what the backward of silu(gate)*up needs (tcavt_silu_mul_bwd) */
   void* silu_preact;
@@ -1064,9 +1068,22 @@ typedef struct tcavt_decode_args {
                                       per layer less); adapters of rank <= 8 only (lora_rank), B <= 32, NULL = a launch per layer */
   int32_t lora_rank;
   float stream_scale;              /* as tcavt_llama_stack_args.stream_scale (0 means 1) */
+  int32_t w_layout;                /* 0, or TCAVT_W_FRAG16: layers[].w_qkv / w_o / w_gu / w_d point to tcavt_pack_weight16 copies */
+  int32_t reserved1;
+  const void* table_packed;        /* optional: tcavt_pack_weight16 copy of `table` for the lm_head product (the token lookup
+                                      keeps reading `table`) */
 } tcavt_decode_args;
 
 int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream);
+
+/* Fragment-major copy of a 16-bit weight matrix W [N][ldw] (N % 16 == 0, K % 32 == 0) for the skinny form of tcavt_gemm_bf16
+ * (tcavt_gemm_args.w_layout = TCAVT_W_FRAG16): out holds N * K elements; block b (rows 16 b .. 16 b + 15), k-step j (columns
+ * 32 j .. 32 j + 31) is the 1 KiB chunk (b * K / 32 + j), and inside it lane l = 16 q + r of the consuming wave finds its eight
+ * elements W[16 b + r][32 j + 8 q .. + 7] at byte 16 l -- the operand layout of v_mfma_f32_16x16x32, so that every load
+ * instruction of the weight stream reads consecutive bytes.  The Hugging Face generate() of the reference (train.py:628-643)
+ * has no counterpart: this is a layout of the frozen weights made once per checkpoint. */
+#define TCAVT_W_FRAG16 1
+int tcavt_pack_weight16(const void* W, int64_t ldw, void* out, int N, int K, tcavt_stream_t stream);
 
 /* hipEvent helpers for tcavt_llama_stack_args.events (timing enabled); elapsed time in milliseconds between two
  * recorded events after the stream has been synchronised by the caller */

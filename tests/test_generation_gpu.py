@@ -170,3 +170,34 @@ def test_two_stage_token_selection_equals_the_one_stage_form(gpu, V):
                 assert torch.equal(torch.isinf(x), torch.isinf(y)) and torch.equal(torch.nan_to_num(x, neginf=0.0), torch.nan_to_num(y, neginf=0.0)), (do_sample, top_k)
             elif nm != "step":
                 assert torch.equal(x, y), (nm, do_sample, top_k, rep, ngram)
+
+
+def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
+    """generate_batch streams fragment-major copies of the decoder weights in its decode steps (LlamaWithCrossAttnPEFT.
+    decode_weights, tcavt_decode_args.w_layout): sampled token ids are identical to the row-major path (TCAVT_DECODE_ROWMAJOR=1),
+    greedy and sampling, eager and graph replay."""
+    import os
+
+    from tcavt_amd import model
+
+    fx, cfg, w, t = load_generation_case()
+    dev = gpu["device"]
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(w, device=dev).eval()
+    kw = dict(max_new_tokens=12, input_ids=t["input_ids"].to(dev), attention_mask=t["attention_mask"].to(dev))
+    outs = {}
+    for mode in ("frag", "row"):
+        if mode == "row":
+            os.environ["TCAVT_DECODE_ROWMAJOR"] = "1"
+        try:
+            outs[mode] = [m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=False, repetition_penalty=1.0,
+                                                no_repeat_ngram_size=0, **kw).clone(),
+                          m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=True, seed=7, **kw).clone(),
+                          m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=True, seed=7, use_graph=False, **kw).clone()]
+        finally:
+            os.environ.pop("TCAVT_DECODE_ROWMAJOR", None)
+    torch.cuda.synchronize()
+    m.mllm.check_flags()
+    assert m.mllm.llama_wrapper._prep_dec is not None
+    for a_, b_ in zip(outs["frag"], outs["row"]):
+        assert torch.equal(a_, b_)
+    assert torch.equal(outs["frag"][1], outs["frag"][2])

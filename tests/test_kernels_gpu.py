@@ -501,6 +501,91 @@ def test_skinny_gemm_matches_tile_kernels(gpu, M, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 8, 17, 32])
+def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
+    """tcavt_pack_weight16 + tcavt_gemm_args.w_layout = W_FRAG16: the skinny form reads a fragment-major copy of W (1 KiB of
+    consecutive bytes per wave instruction).  Same fragments into the same MFMAs in the same order: every epilogue form of the
+    decode step must return BIT-identical results; the pack itself is checked against its definition; a tiled shape is refused."""
+    import ctypes
+
+    from tcavt_amd import capi, ops
+
+    dev = gpu["device"]
+    g = torch.Generator().manual_seed(900 + M)
+    K, H = 1024, 512
+    x = (torch.randn(M, K, generator=g)).to(dt).to(dev)
+    part = (torch.rand(M, 8, generator=g) * 40 + 10).to(dev)
+
+    def run(w, wl, N, epi, out, **kw):
+        a = capi.GemmArgs()
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), K, (out.data_ptr() if out is not None else None), kw.pop("ldc", N)
+        a.M, a.N, a.K, a.tile, a.epilogue, a.w_layout = M, N, K, 0, epi, wl
+        a.in_dtype, a.out_dtype = ops._DT[dt], ops._DT[out.dtype] if out is not None else capi.F32
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_.data_ptr() if torch.is_tensor(v_) else v_)
+        capi.check(capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()), "gemm")
+        return out
+
+    # the pack against its definition: chunk (b, j), lane l = 16 q + r <- W[16 b + r][32 j + 8 q : + 8]
+    N = 384
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    wp = ops.pack_weight16(w)
+    ref = w.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+    assert torch.equal(wp.view(torch.int16), ref.view(torch.int16))
+    rs = dict(rowscale_part=part, rowscale_npart=8, rowscale_h=K, rowscale_eps=1e-5)
+    # q|k|v: RoPE + LoRA second source + row scale
+    t2 = torch.randn(M, 64, generator=g).to(dt).to(dev)
+    w2 = (torch.randn(N, 64, generator=g) * 0.05).to(dt).to(dev)
+    cos, sin = torch.rand(50, 32, generator=g).to(dev), torch.rand(50, 32, generator=g).to(dev)
+    pos = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(dev)
+    kw = dict(A2=t2, lda2=64, W2=w2, ldw2=64, K2=64, rope_cos=cos, rope_sin=sin, rope_L=50, rope_cols=320, rope_pos=pos, **rs)
+    a_ = run(w, 0, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, N, dtype=dt, device=dev), **kw)
+    b_ = run(wp, capi.W_FRAG16, N, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, N, dtype=dt, device=dev), **kw)
+    assert torch.equal(a_, b_) and a_.float().abs().max() > 0
+    # gate|up: SiLU * up with row scale
+    N = 512
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    wp = ops.pack_weight16(w)
+    a_ = run(w, 0, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2, **rs)
+    b_ = run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2, **rs)
+    assert torch.equal(a_, b_) and a_.float().abs().max() > 0
+    # o / down: in-place 16-bit residual stream (fp16) or fp32 stream + 16-bit copy, partial sums of squares
+    N = H
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    wp = ops.pack_weight16(w)
+    res = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for wt, wl in ((w, 0), (wp, capi.W_FRAG16)):
+        npart = ops.norm_npart(M, N, K)
+        h16 = res.to(dt)
+        pt = torch.zeros(M, npart, device=dev)
+        if dt == torch.float16:
+            run(wt, wl, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h16, norm_part=pt)
+            outs.append((h16, pt))
+        else:
+            c = run(wt, wl, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, torch.empty(M, N, device=dev), residual=res, ldr=N, norm_h16=h16,
+                    norm_part=pt)
+            outs.append((c, h16, pt))
+    for u_, v_ in zip(*outs):
+        assert torch.equal(u_, v_)
+    assert not torch.equal(outs[0][0].float(), res.to(dt).float())
+    # lm_head: plain fp32 output (both column-block forms: N < 8192 and N >= 8192 with M > 16)
+    for N in (1008, 8192):
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+        wp = ops.pack_weight16(w)
+        a_ = run(w, 0, N, 0, torch.empty(M, N, device=dev))
+        b_ = run(wp, capi.W_FRAG16, N, 0, torch.empty(M, N, device=dev))
+        assert torch.equal(a_, b_) and _rel(a_, x.float() @ w.float().T) < 1e-5
+    # refused where no skinny form runs (M > 32)
+    xl = torch.zeros(64, K, dtype=dt, device=dev)
+    a = capi.GemmArgs()
+    o = torch.empty(64, N, device=dev)
+    a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = xl.data_ptr(), K, wp.data_ptr(), K, o.data_ptr(), N, 64, N, K
+    a.in_dtype, a.out_dtype, a.w_layout = ops._DT[dt], capi.F32, capi.W_FRAG16
+    assert capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 8, 32])
 def test_skinny_gemm_split_k_across_workgroups(gpu, M, dt):
     """tcavt_gemm_args.splitk_ws: with a workspace the skinny form splits K over several workgroups per column block (fp32

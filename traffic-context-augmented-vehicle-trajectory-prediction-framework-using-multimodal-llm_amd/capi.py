@@ -22,6 +22,7 @@ ABI_VERSION = 4  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_NORM_OUT, EPI_ROWSCALE, EPI_SILU_BWD = 128, 256, 512
+W_FRAG16 = 1  # tcavt_gemm_args.w_layout / tcavt_decode_args.w_layout: tcavt_pack_weight16 copy
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -49,7 +50,7 @@ class GemmArgs(ctypes.Structure):
         ("batch", ctypes.c_int32), ("batch_inner", ctypes.c_int32),
         ("sAo", c_int64), ("sAi", c_int64), ("sWo", c_int64), ("sWi", c_int64), ("sCo", c_int64), ("sCi", c_int64),
         ("dropout_p", ctypes.c_float), ("dropout_site", ctypes.c_uint32), ("dropout_seed", ctypes.c_uint64),
-        ("batch_w_group", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("batch_w_group", ctypes.c_int32), ("w_layout", ctypes.c_int32),
         ("silu_preact", c_void_p), ("ld_preact", c_int64),
         ("norm_h16", c_void_p), ("norm_part", c_void_p), ("rowscale_part", c_void_p),
         ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
@@ -208,7 +209,8 @@ class DecodeArgs(ctypes.Structure):
         "t", "k_cache", "v_cache", "x16", "logits", "bad_id_flag")] + [(n, ctypes.c_int32) for n in (
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
         ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p),
-        ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("stream_scale", ctypes.c_float)]
+        ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("stream_scale", ctypes.c_float),
+        ("w_layout", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("table_packed", c_void_p)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)
@@ -302,6 +304,7 @@ _SIGNATURES = {
     "tcavt_gather_last": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "tcavt_llama_decode_step": [ctypes.POINTER(DecodeArgs), c_void_p],
     "tcavt_norm_npart": [c_int, c_int, c_int],
+    "tcavt_pack_weight16": [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p],
     "tcavt_lora_down": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, ctypes.c_uint64, ctypes.c_uint32,
                         ctypes.c_uint32, c_int, c_void_p],
     "tcavt_rownorm_prep": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p],

@@ -73,6 +73,7 @@ struct GemmP {
   // skinny form, M > 16: the two 16-token blocks of a column block go to TWO workgroups (sk_msplit = 2) instead of one that
   // loads both blocks' activation rows for every weight fragment (twice the weight bytes through the CU's load path)
   int sk_msplit;
+  int w_frag;  // skinny form: W is the fragment-major copy of tcavt_pack_weight16 (tcavt_gemm_args.w_layout)
   int sk_split;
   float* sk_slab;
   int* sk_cnt;
@@ -2105,9 +2106,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   // this wave's K slice: K / (8 S) (a multiple of 32), 32 per MFMA step
   const int kper = p.K / (SK_WAVES * S);
   const int kbeg = (ks * SK_WAVES + wave) * kper;
+  // Weight fragments: row-major W -> 16 rows x 64 bytes per instruction, K * 2 bytes apart; fragment-major copy (w_frag,
+  // tcavt_pack_weight16) -> the same 1 KiB as consecutive bytes, the wave's K slice one contiguous run (k advances 16 x as fast)
   const bf16_t* wp[NCB];
+  const int wstep = p.w_frag ? 16 : 1;
 #pragma unroll
-  for (int c = 0; c < NCB; ++c) wp[c] = p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
+  for (int c = 0; c < NCB; ++c)
+    wp[c] = p.w_frag ? p.W + (long)ncol[c] * p.K + (long)kbeg * 16 + lane * 8 : p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
   const bf16_t* xp0 = p.A + (long)min(mrow0 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bool two = p.M > 16 && p.sk_msplit <= 1;
@@ -2177,7 +2182,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     for (int u = 0; u < U; ++u) {
       if (k + 32 * u < kper) {
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + k + 32 * u);
+        for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + (k + 32 * u) * wstep);
         x0[u] = *reinterpret_cast<const u32x4*>(xp0 + k + 32 * u);
         if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + k + 32 * u);
       }
@@ -2505,6 +2510,23 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
+// Fragment-major copy of a weight matrix for the skinny form (tcavt.h: tcavt_pack_weight16).  One thread per 16-byte piece:
+// piece (b, j, l) <- W[16 b + (l & 15)][32 j + 8 (l >> 4) .. + 7]; the writes are consecutive, the reads 16 rows x 64 bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight16_kernel(const bf16_t* __restrict__ W, long ldw, bf16_t* __restrict__ out, int N, int K) {
+  const long piece = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)N * K / 8;
+  if (piece >= total) return;
+  const int l = (int)(piece & 63);
+  const long chunk = piece >> 6;
+  const int ksteps = K >> 5;
+  const long b = chunk / ksteps;
+  const int j = (int)(chunk - b * ksteps);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(W + (16 * b + (l & 15)) * ldw + 32 * j + 8 * (l >> 4));
+  *reinterpret_cast<u32x4*>(out + piece * 8) = v;
+}
+
+// ---------------------------------------------------------------------------
 // Split K for residual GEMMs that cannot fill the chip (round 4).  At M = 1024 (BASELINE config 4's low end: B = 8, L = 128) the
 // o / down projections are 128 tiles of 128 x 128 -- half the CUs, one 4-wave workgroup each walking 32 / 128 K-tiles alone at
 // ~1 us per K-tile (its waves issue DMA, fragment loads and MFMAs one after the other; nothing else is resident to overlap
@@ -2568,6 +2590,17 @@ static int splitk_slices(int M, int N, int K) {
 }  // namespace tcavt
 
 using namespace tcavt;
+
+extern "C" int tcavt_pack_weight16(const void* W, int64_t ldw, void* out, int N, int K, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(W && out && W != out && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0 && ldw >= K && ldw % 8 == 0,
+                  "pack_weight16: N %% 16 == 0, K %% 32 == 0, ldw >= K, ldw %% 8 == 0, out != W");
+  TCAVT_CHECK_ARG(aligned16(W) && aligned16(out), "pack_weight16: 16-byte alignment required");
+  const long pieces = (long)N * K / 8;
+  hipLaunchKernelGGL(pack_weight16_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(W), (long)ldw, static_cast<bf16_t*>(out), N, K);
+  TCAVT_CHECK_LAUNCH("pack_weight16");
+  return TCAVT_OK;
+}
 
 extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) {
   TCAVT_CHECK_ARG(a != nullptr, "gemm_bf16: null args");
@@ -2661,6 +2694,14 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.lp_lda = 0;
   p.lp_np = 0;
   p.lp_scale = 1.f;
+  p.w_frag = 0;
+  if (a->w_layout != 0) {
+    TCAVT_CHECK_ARG(a->w_layout == TCAVT_W_FRAG16 && a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f &&
+                        a->lda >= a->K && a->ldw == a->K && a->N % 16 == 0,
+                    "gemm_bf16: w_layout = TCAVT_W_FRAG16 (tcavt_pack_weight16 copy) goes with the skinny form only (M <= 32, "
+                    "K %% 256 == 0, N %% 16 == 0, tile 0, ldw == K)");
+    p.w_frag = 1;
+  }
   if (a->lora_part) {
     // (decode step only: the skinny form; anything else is a caller error rather than a silent no-op)
     TCAVT_CHECK_ARG(a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f && aligned16(a->lora_part),
@@ -2778,6 +2819,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
     }
   }
+  TCAVT_CHECK_ARG(!p.w_frag, "gemm_bf16: w_layout = TCAVT_W_FRAG16: this epilogue / shape has no skinny form");
   if (epi & TCAVT_EPI_SILU_BWD) {  // dgrad of down_proj with d(silu(gate) * up) in the epilogue: the 4-wave kernel only
     TCAVT_CHECK_ARG(epi == TCAVT_EPI_SILU_BWD && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->K >= 128 &&
                         a->silu_preact && aligned16(a->silu_preact) && a->dropout_p == 0.f && p.acc_scale == 1.f &&

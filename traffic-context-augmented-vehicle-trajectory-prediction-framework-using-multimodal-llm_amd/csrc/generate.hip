@@ -831,6 +831,10 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   TCAVT_CHECK_ARG(a->stream_scale >= 0.f && a->stream_scale <= 1.f, "llama_decode_step: stream_scale must be in (0, 1] (0 means 1)");
   const float ss_ = a->stream_scale == 0.f ? 1.f : a->stream_scale;
   const float eps_s = a->rms_eps * ss_ * ss_;
+  // fragment-major weight copies (tcavt_pack_weight16): the projections' weight streams read consecutive bytes
+  const int wl = a->w_layout;
+  TCAVT_CHECK_ARG(wl == 0 || (wl == TCAVT_W_FRAG16 && B <= 32 && I % 256 == 0 && (nq * 64) % 256 == 0),
+                  "llama_decode_step: w_layout must be 0 or TCAVT_W_FRAG16 (B <= 32, I %% 256 == 0, nq * 64 %% 256 == 0)");
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
   // (a->h == NULL: the residual stream is the 16-bit h16 itself, as in tcavt_llama_stack_forward)
@@ -857,7 +861,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv;
+      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv; g.w_layout = wl;
       g.M = B; g.N = nqkv; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       if (t_fused) {
         g.W2 = w.b_ext; g.ldw2 = 64; g.lora_part = a->lora_part; g.lora_part_np = H / 16; g.lora_part_scale = a->lora_scale;
@@ -882,7 +886,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     TCAVT_CHECK_LAUNCH("attn_decode");
     {
       tcavt_gemm_args g = {};
-      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H;
+      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H; g.w_layout = wl;
       g.M = B; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
@@ -892,7 +896,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I;
+      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I; g.w_layout = wl;
       g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
       g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = eps_s;
@@ -901,7 +905,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H;
+      g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H; g.w_layout = wl;
       g.M = B; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
@@ -918,6 +922,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   // lm_head: tied to the embedding table (Llama-3.2-1B: tie_word_embeddings)
   tcavt_gemm_args g = {};
   g.A = a->x16; g.lda = H; g.W = a->table; g.ldw = H; g.C = a->logits; g.ldc = a->V;
+  if (a->table_packed && B <= 32) { g.W = a->table_packed; g.w_layout = TCAVT_W_FRAG16; }
   g.M = B; g.N = a->V; g.K = H; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
   g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
   return tcavt_gemm_bf16(&g, stream);

@@ -310,6 +310,19 @@ def cast_bf16(x, out=None):
     return cast16(x, out, torch.bfloat16)
 
 
+def pack_weight16(w, out=None):
+    """Fragment-major copy of a 16-bit weight matrix [N, K] for the skinny (decode-step) form of gemm_bf16
+    (tcavt_pack_weight16; tcavt_gemm_args.w_layout = W_FRAG16): same N * K elements, every 16-row x 32-column fragment a run
+    of 1 KiB in the consuming wave's lane order."""
+    assert w.dim() == 2 and w.dtype in (torch.float16, torch.bfloat16) and w.stride(1) == 1
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(N * K, dtype=w.dtype, device=w.device)
+    assert out.numel() == N * K and out.dtype == w.dtype and out.is_contiguous()
+    capi.check(capi.lib().tcavt_pack_weight16(w.data_ptr(), w.stride(0), out.data_ptr(), N, K, capi.stream_ptr()), "pack_weight16")
+    return out
+
+
 def norm_npart(M, N, K):
     """Partial sums of squares per row that a NORM_OUT product [M, N] over K writes (tcavt_norm_npart)."""
     return int(lib().tcavt_norm_npart(int(M), int(N), int(K)))
