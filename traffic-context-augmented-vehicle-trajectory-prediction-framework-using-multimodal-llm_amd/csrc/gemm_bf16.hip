@@ -73,6 +73,7 @@ struct GemmP {
   // skinny form, M > 16: the two 16-token blocks of a column block go to TWO workgroups (sk_msplit = 2) instead of one that
   // loads both blocks' activation rows for every weight fragment (twice the weight bytes through the CU's load path)
   int sk_msplit;
+  int sk_dbg_xpack;  // (experiments build: timing-only activation addressing)
   int w_frag;  // skinny form: W is the fragment-major copy of tcavt_pack_weight16 (tcavt_gemm_args.w_layout)
   int sk_split;
   float* sk_slab;
@@ -2066,7 +2067,7 @@ __device__ __forceinline__ f32x4 sk_load(const float* ptr) {
   return v;
 }
 
-template <int EPI, int NCB, bool F16>
+template <int EPI, int NCB, bool F16, bool NT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   __shared__ f32x4 red[SK_WAVES][NCB * 2][64];
   // fused LoRA down-projection, consumer side (RoPE form): group sums of the partials, then t as 16-bit rows [32][32]
@@ -2115,6 +2116,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     wp[c] = p.w_frag ? p.W + (long)ncol[c] * p.K + (long)kbeg * 16 + lane * 8 : p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
   const bf16_t* xp0 = p.A + (long)min(mrow0 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
+#ifdef TCAVT_EXPERIMENTS
+  // TIMING EXPERIMENT (wrong results): activation fragments read as 1 KiB runs too (needs 16 whole rows behind mrow0)
+  const int xstep = p.sk_dbg_xpack ? 16 : 1;
+  if (p.sk_dbg_xpack) {
+    xp0 = p.A + (long)mrow0 * p.lda + (long)kbeg * 16 + lane * 8;
+    xp1 = p.A + (long)16 * p.lda + (long)kbeg * 16 + lane * 8;
+  }
+#else
+  constexpr int xstep = 1;
+#endif
   const bool two = p.M > 16 && p.sk_msplit <= 1;
   constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms in round 2, and again in round 3 for the residual forms alone: 1.155 vs 1.138; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
   // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
@@ -2182,9 +2193,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     for (int u = 0; u < U; ++u) {
       if (k + 32 * u < kper) {
 #pragma unroll
-        for (int c = 0; c < NCB; ++c) wf[u][c] = *reinterpret_cast<const u32x4*>(wp[c] + (k + 32 * u) * wstep);
-        x0[u] = *reinterpret_cast<const u32x4*>(xp0 + k + 32 * u);
-        if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + k + 32 * u);
+        for (int c = 0; c < NCB; ++c) {
+          const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp[c] + (k + 32 * u) * wstep);
+          wf[u][c] = NT ? __builtin_nontemporal_load(wsrc) : *wsrc;
+        }
+        x0[u] = *reinterpret_cast<const u32x4*>(xp0 + (k + 32 * u) * xstep);
+        if (two) x1[u] = *reinterpret_cast<const u32x4*>(xp1 + (k + 32 * u) * xstep);
       }
     }
     if constexpr (EPI == EPI_ROPE) {
@@ -2504,7 +2518,19 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
   //  second read of every weight row costs more than the activation rows it saves: gate|up 25.8 -> 33.2 us, lm_head likewise)
   const int msplit = (S == 1 && p.M > 16 && nblk % 8 == 0 && nblk <= 256 && !no_msplit) ? 2 : 1;
   q.sk_msplit = msplit;
-  hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16>), dim3(nblk * S * msplit), dim3(SK_WAVES * 64), 0, stream, q);
+  q.sk_dbg_xpack = 0;
+#ifdef TCAVT_EXPERIMENTS
+  static const bool dbg_x = getenv("TCAVT_SK_XPACK_TIMING") != nullptr;
+  q.sk_dbg_xpack = dbg_x && p.lda == p.K && (msplit > 1 ? p.M == 32 : (p.M == 16 || p.M == 32)) ? 1 : 0;
+#endif
+  // Non-temporal weight loads where every weight byte is read ONCE per launch (one workgroup per column block) from the
+  // fragment-major copy: 0.925 -> 0.885 ms per decode step at B = 8.  (On row-major weights nt was slower, 1.15 vs 1.09 ms --
+  // the two 64-byte halves of a 128-byte line are fetched by different instructions there; with the token blocks on two
+  // workgroups the second reader wants the L2 copy.)
+  static const bool no_nt = getenv("TCAVT_SK_NO_NT") != nullptr;  // (A/B switch)
+  const dim3 grid(nblk * S * msplit), block(SK_WAVES * 64);
+  if (q.w_frag && msplit == 1 && !no_nt) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16, true>), grid, block, 0, stream, q);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, NCB, F16, false>), grid, block, 0, stream, q);
   TCAVT_CHECK_LAUNCH("gemm_bf16(skinny)");
   return TCAVT_OK;
 }
