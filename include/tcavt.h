@@ -182,7 +182,15 @@ typedef struct tcavt_gemm_args {
    * SET by the kernels; the host reads and clears it (LlamaMultiModal.check_flags).  NULL: no check. */
   int32_t* nonfinite_flag;
   int32_t nonfinite_tag;
-  int32_t reserved2;
+  /* Skinny form only (M <= 32, tile 0: the decode step; refused elsewhere): 16-bit operands / results in FRAGMENT-MAJOR order, so
+   * that the activation fragments of a k-step are 1 KiB of consecutive bytes as well (w_layout does it for the weights).  Element
+   * (m, f) of a [<= 32][K] operand lives at  (m >> 4) * 16 K + (f >> 5) * 512 + ((f >> 3) & 3) * 128 + (m & 15) * 8 + (f & 7)
+   * elements; the buffer holds 16 (M <= 16) or 32 whole rows.  Flags:
+   *   TCAVT_ACT_A_FRAG16   (1)  A is in this order (lda ignored; K % 32 == 0)
+   *   TCAVT_ACT_OUT_FRAG16 (2)  the 16-bit result is: C of TCAVT_EPI_SILU_MUL (row length N / 2), or the in-place 16-bit stream
+   *                             norm_h16 / norm_res16 of TCAVT_EPI_NORM_OUT with C == NULL (row length N)
+   * Same values into the same MFMAs: results are bit-identical to the row-major call. */
+  int32_t act_layout;
   /* TCAVT_EPI_NORM_OUT with C == NULL (16-bit residual stream), optional: the 16-bit residual is READ from here
    * (leading dimension ldc) and the updated stream written to norm_h16 -- out of place, so that a caller can keep the
    * stream of every layer (the LoRA-trainable variant's tape).  NULL: read from norm_h16 (in place). */
@@ -1069,7 +1077,8 @@ typedef struct tcavt_decode_args {
   int32_t lora_rank;
   float stream_scale;              /* as tcavt_llama_stack_args.stream_scale (0 means 1) */
   int32_t w_layout;                /* 0, or TCAVT_W_FRAG16: layers[].w_qkv / w_o / w_gu / w_d point to tcavt_pack_weight16 copies */
-  int32_t reserved1;
+  int32_t act_layout;              /* 0, or 1: h16, att, act and x16 are kept in fragment-major order (tcavt_gemm_args.act_layout;
+                                      each buffer then holds 16 (B <= 16) or 32 whole rows); needs h == NULL, B <= 32, fp16 or bf16 alike */
   const void* table_packed;        /* optional: tcavt_pack_weight16 copy of `table` for the lm_head product (the token lookup
                                       keeps reading `table`) */
 } tcavt_decode_args;
@@ -1083,6 +1092,8 @@ int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream
  * instruction of the weight stream reads consecutive bytes.  The Hugging Face generate() of the reference (train.py:628-643)
  * has no counterpart: this is a layout of the frozen weights made once per checkpoint. */
 #define TCAVT_W_FRAG16 1
+#define TCAVT_ACT_A_FRAG16 1
+#define TCAVT_ACT_OUT_FRAG16 2
 int tcavt_pack_weight16(const void* W, int64_t ldw, void* out, int N, int K, tcavt_stream_t stream);
 
 /* hipEvent helpers for tcavt_llama_stack_args.events (timing enabled); elapsed time in milliseconds between two

@@ -185,9 +185,13 @@ def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(w, device=dev).eval()
     kw = dict(max_new_tokens=12, input_ids=t["input_ids"].to(dev), attention_mask=t["attention_mask"].to(dev))
     outs = {}
-    for mode in ("frag", "row"):
+    for mode in ("frag", "frag_w", "row"):
+        if mode == "frag":  # (fragment-major activations are the default above 8 samples only)
+            os.environ["TCAVT_DECODE_ACT_FRAG"] = "1"
         if mode == "row":
             os.environ["TCAVT_DECODE_ROWMAJOR"] = "1"
+        if mode == "frag_w":  # fragment-major weights, row-major activations
+            os.environ["TCAVT_DECODE_ACT_ROWMAJOR"] = "1"
         try:
             outs[mode] = [m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=False, repetition_penalty=1.0,
                                                 no_repeat_ngram_size=0, **kw).clone(),
@@ -195,9 +199,11 @@ def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
                           m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=True, seed=7, use_graph=False, **kw).clone()]
         finally:
             os.environ.pop("TCAVT_DECODE_ROWMAJOR", None)
+            os.environ.pop("TCAVT_DECODE_ACT_ROWMAJOR", None)
+            os.environ.pop("TCAVT_DECODE_ACT_FRAG", None)
     torch.cuda.synchronize()
     m.mllm.check_flags()
     assert m.mllm.llama_wrapper._prep_dec is not None
-    for a_, b_ in zip(outs["frag"], outs["row"]):
-        assert torch.equal(a_, b_)
+    for a_, b_, c_ in zip(outs["frag"], outs["row"], outs["frag_w"]):
+        assert torch.equal(a_, b_) and torch.equal(c_, b_)
     assert torch.equal(outs["frag"][1], outs["frag"][2])

@@ -576,6 +576,59 @@ def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
         a_ = run(w, 0, N, 0, torch.empty(M, N, device=dev))
         b_ = run(wp, capi.W_FRAG16, N, 0, torch.empty(M, N, device=dev))
         assert torch.equal(a_, b_) and _rel(a_, x.float() @ w.float().T) < 1e-5
+    # ---- fragment-major ACTIVATIONS as well (tcavt_gemm_args.act_layout): A read, SiLU output / in-place stream written in the
+    # operand order of the next skinny GEMM; the layout is the weight pack's with tokens as rows (padded to whole 16-row blocks)
+    Mr = 16 if M <= 16 else 32
+
+    def to_frag(t):  # [M, C] -> fragment-major [Mr * C]
+        pad = torch.zeros(Mr, t.shape[1], dtype=t.dtype, device=dev)
+        pad[:M] = t
+        return ops.pack_weight16(pad)
+
+    def from_frag(f, C):  # inverse, first M rows
+        return f.view(Mr // 16, C // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Mr, C)[:M]
+
+    xf = to_frag(x)
+    x_keep = x
+    N = 512
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    wp = ops.pack_weight16(w)
+    a_ = run(w, 0, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2, **rs)
+    x = xf  # (run() takes A from the enclosing scope)
+    try:
+        of = torch.zeros(Mr * (N // 2), dtype=dt, device=dev)
+        run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, of, ldc=N // 2,
+            act_layout=capi.ACT_A_FRAG16 | capi.ACT_OUT_FRAG16, **rs)
+        assert torch.equal(from_frag(of, N // 2), a_)
+        b_ = run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2,
+                 act_layout=capi.ACT_A_FRAG16, **rs)
+        assert torch.equal(b_, a_)
+        # q|k|v (row-major output) and lm_head from fragment-major A
+        Nq_ = 384
+        wq = (torch.randn(Nq_, K, generator=g) * 0.05).to(dt).to(dev)
+        x = x_keep
+        qa = run(wq, 0, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev), **kw)
+        la = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev))
+        x = xf
+        qb = run(ops.pack_weight16(wq), capi.W_FRAG16, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev),
+                 act_layout=capi.ACT_A_FRAG16, **kw)
+        lb = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev), act_layout=capi.ACT_A_FRAG16)
+        assert torch.equal(qa, qb) and torch.equal(la, lb)
+        # o / down: the in-place 16-bit stream in fragment-major order
+        N = H
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+        res16 = torch.randn(M, N, generator=g).to(dev).to(dt)
+        npart = ops.norm_npart(M, N, K)
+        x = x_keep
+        h_a, p_a = res16.clone(), torch.zeros(M, npart, device=dev)
+        run(w, 0, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h_a, norm_part=p_a)
+        x = xf
+        h_b, p_b = to_frag(res16), torch.zeros(M, npart, device=dev)
+        run(ops.pack_weight16(w), capi.W_FRAG16, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h_b, norm_part=p_b,
+            act_layout=capi.ACT_A_FRAG16 | capi.ACT_OUT_FRAG16)
+        assert torch.equal(from_frag(h_b, N), h_a) and torch.equal(p_a, p_b) and not torch.equal(h_a, res16)
+    finally:
+        x = x_keep
     # refused where no skinny form runs (M > 32)
     xl = torch.zeros(64, K, dtype=dt, device=dev)
     a = capi.GemmArgs()

@@ -22,6 +22,7 @@ ABI_VERSION = 4  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_NORM_OUT, EPI_ROWSCALE, EPI_SILU_BWD = 128, 256, 512
+ACT_A_FRAG16, ACT_OUT_FRAG16 = 1, 2  # tcavt_gemm_args.act_layout
 W_FRAG16 = 1  # tcavt_gemm_args.w_layout / tcavt_decode_args.w_layout: tcavt_pack_weight16 copy
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
@@ -56,7 +57,7 @@ class GemmArgs(ctypes.Structure):
         ("rowscale_npart", ctypes.c_int32), ("rowscale_h", ctypes.c_int32), ("rowscale_eps", ctypes.c_float),
         ("norm_scale", ctypes.c_float),
         ("rope_pos", c_void_p),
-        ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("reserved2", ctypes.c_int32),
+        ("nonfinite_flag", c_void_p), ("nonfinite_tag", ctypes.c_int32), ("act_layout", ctypes.c_int32),
         ("norm_res16", c_void_p), ("splitk_ws", c_void_p), ("splitk_ws_bytes", c_int64),
         ("lora_part", c_void_p), ("lora_part_a", c_void_p), ("lora_part_lda", c_int64), ("lora_part_np", c_int),
         ("lora_part_scale", c_float),
@@ -210,7 +211,7 @@ class DecodeArgs(ctypes.Structure):
             "n_layers", "B", "H", "I", "nq", "nkv", "V", "dtype16", "kv_lmax", "rope_L")] + [
         ("rms_eps", c_float), ("lora_scale", c_float), ("nonfinite_flag", c_void_p), ("splitk_ws", c_void_p),
         ("splitk_ws_bytes", c_int64), ("lora_part", c_void_p), ("lora_rank", c_int), ("stream_scale", ctypes.c_float),
-        ("w_layout", ctypes.c_int32), ("reserved1", ctypes.c_int32), ("table_packed", c_void_p)]
+        ("w_layout", ctypes.c_int32), ("act_layout", ctypes.c_int32), ("table_packed", c_void_p)]
 
 
 # name -> argtypes (return type is always int unless listed in _RESTYPES)

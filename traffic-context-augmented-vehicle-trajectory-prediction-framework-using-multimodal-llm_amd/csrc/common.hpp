@@ -109,6 +109,13 @@ static inline bool skinny_shape(int M, int K) { return M <= 32 && K % 256 == 0; 
 // twice the partial sums)
 static inline int norm_out_npart(int M, int N, int K) { return skinny_shape(M, K) ? N / 16 : N / 64; }
 
+// Fragment-major activations of the decode step (tcavt.h: TCAVT_ACT_*_FRAG16): element (m, f) of a [<= 32][K] 16-bit operand.
+// Tokens in blocks of 16, columns in steps of 32: block (m >> 4) at 16 K elements, step (f >> 5) a 1 KiB chunk, inside it lane
+// 16 q + r (r = m & 15, q = (f >> 3) & 3) holds columns 8 q .. 8 q + 7 of the step -- the B-operand layout of v_mfma_f32_16x16x32.
+__host__ __device__ __forceinline__ long frag16_off(int m, int f, int K) {
+  return (long)(m >> 4) * 16 * K + (long)(f >> 5) * 512 + ((f >> 3) & 3) * 128 + (m & 15) * 8 + (f & 7);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -120,5 +127,13 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// csrc-internal forms of tcavt_embed_fuse / tcavt_rmsnorm16 with a layout switch for their 16-bit rows (frag16 != 0: the rows
+// are written / read through frag16_off; B * (Nq + Lt) resp. M <= 32).  The exported entry points call them with 0.
+int embed_fuse_impl(const void* table16, const int64_t* ids, const float* img, const float* vis_mod, const float* txt_mod, float* h,
+                    int B, int Nq, int Lt, int H, int V, int32_t* bad_id_flag, int table_dtype, void* h16, float* part, int npart,
+                    float stream_scale, int frag16, tcavt_stream_t stream);
+int rmsnorm16_impl(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H, int dtype16, int frag16,
+                   tcavt_stream_t stream);
 
 }  // namespace tcavt

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
                                                          const float* __restrict__ txt_mod,
                                                          float* __restrict__ h, int B, int Nq, int Lt,
                                                          int H, int V, int* bad_flag, bf16_t* __restrict__ h16,
-                                                         float* __restrict__ part, int npart, float sscale) {
+                                                         float* __restrict__ part, int npart, float sscale, int frag16) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int L = Nq + Lt;
@@ -200,13 +200,14 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
   const int b = (int)(row / L), i = (int)(row % L);
   float* out = h ? h + row * H : nullptr;  // (null: the residual stream is the 16-bit h16 itself)
   bf16_t* out16 = h16 ? h16 + row * H : nullptr;
+  const bool frag = frag16 && h16;  // (decode step: the <= 32 rows in the skinny GEMM's operand order, common.hpp frag16_off)
   float ss = 0.f;  // sum of squares of the row (first decoder layer's fused RMSNorm)
   auto emit = [&](int c, f32x4 o) {
     if (out) *reinterpret_cast<f32x4*>(out + c) = o;
     o *= sscale;  // (scaled 16-bit image of the stream: tcavt_llama_stack_args.stream_scale; 1 by default, exact for powers of two)
     if (out16) {
       const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
-      *reinterpret_cast<u32x2*>(out16 + c) = w;
+      *reinterpret_cast<u32x2*>(frag ? h16 + frag16_off((int)row, c, H) : out16 + c) = w;
       if (!out) o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};  // sums of what is stored
     }
     ss += o[0] * o[0];
@@ -561,6 +562,14 @@ extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, cons
                                 const float* vis_mod, const float* txt_mod, float* h, int B, int Nq,
                                 int Lt, int H, int V, int* bad_id_flag, int table_dtype, void* h16, float* part,
                                 int npart, float stream_scale, tcavt_stream_t stream) {
+  return tcavt::embed_fuse_impl(table_bf16, ids, img, vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, table_dtype, h16, part, npart,
+                                stream_scale, 0, stream);
+}
+
+int tcavt::embed_fuse_impl(const void* table_bf16, const int64_t* ids, const float* img, const float* vis_mod, const float* txt_mod,
+                           float* h, int B, int Nq, int Lt, int H, int V, int32_t* bad_id_flag, int table_dtype, void* h16, float* part,
+                           int npart, float stream_scale, int frag16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(!frag16 || ((long)B * (Nq + Lt) <= 32 && H % 32 == 0), "embed_fuse: fragment-major rows: at most 32, H %% 32 == 0");
   TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && (h || h16) && bad_id_flag, "embed_fuse: null pointer");
   TCAVT_CHECK_ARG(stream_scale >= 0.f && stream_scale <= 1.f, "embed_fuse: stream_scale must be in (0, 1] (0 means 1)");
   const float sscale = stream_scale == 0.f ? 1.f : stream_scale;
@@ -571,11 +580,11 @@ extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, cons
   if (table_dtype == TCAVT_F16)
     hipLaunchKernelGGL(embed_fuse_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale, frag16);
   else
     hipLaunchKernelGGL(embed_fuse_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(table_bf16), ids, img,
-                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale);
+                       vis_mod, txt_mod, h, B, Nq, Lt, H, V, bad_id_flag, static_cast<bf16_t*>(h16), part, npart, sscale, frag16);
   TCAVT_CHECK_LAUNCH("embed_fuse");
   return TCAVT_OK;
 }

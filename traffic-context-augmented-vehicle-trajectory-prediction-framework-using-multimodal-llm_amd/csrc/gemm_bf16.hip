@@ -73,7 +73,7 @@ struct GemmP {
   // skinny form, M > 16: the two 16-token blocks of a column block go to TWO workgroups (sk_msplit = 2) instead of one that
   // loads both blocks' activation rows for every weight fragment (twice the weight bytes through the CU's load path)
   int sk_msplit;
-  int sk_dbg_xpack;  // (experiments build: timing-only activation addressing)
+  int a_frag, o_frag;  // skinny form: A / the 16-bit result in fragment-major order (tcavt_gemm_args.act_layout, common.hpp frag16_off)
   int w_frag;  // skinny form: W is the fragment-major copy of tcavt_pack_weight16 (tcavt_gemm_args.w_layout)
   int sk_split;
   float* sk_slab;
@@ -2116,16 +2116,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     wp[c] = p.w_frag ? p.W + (long)ncol[c] * p.K + (long)kbeg * 16 + lane * 8 : p.W + (long)(ncol[c] + r16) * p.ldw + kbeg + kq * 8;
   const bf16_t* xp0 = p.A + (long)min(mrow0 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
-#ifdef TCAVT_EXPERIMENTS
-  // TIMING EXPERIMENT (wrong results): activation fragments read as 1 KiB runs too (needs 16 whole rows behind mrow0)
-  const int xstep = p.sk_dbg_xpack ? 16 : 1;
-  if (p.sk_dbg_xpack) {
-    xp0 = p.A + (long)mrow0 * p.lda + (long)kbeg * 16 + lane * 8;
-    xp1 = p.A + (long)16 * p.lda + (long)kbeg * 16 + lane * 8;
+  // fragment-major activations: the 16 tokens' fragments of a k-step are one 1 KiB run as well (rows >= M of a block hold
+  // whatever the producer left: they only reach output columns >= M, which nobody stores)
+  const int xstep = p.a_frag ? 16 : 1;
+  if (p.a_frag) {
+    xp0 = p.A + (long)mrow0 * p.K + (long)kbeg * 16 + lane * 8;
+    xp1 = p.A + (long)16 * p.K + (long)kbeg * 16 + lane * 8;
   }
-#else
-  constexpr int xstep = 1;
-#endif
   const bool two = p.M > 16 && p.sk_msplit <= 1;
   constexpr int U = 4;  // k-steps in flight (8 made the decode step slower: 3.08 vs 2.60 ms in round 2, and again in round 3 for the residual forms alone: 1.155 vs 1.138; so did 16 waves with K / 16 slices each: 1.55 vs 1.34 ms)
   // Epilogue operands of the two finishing waves (wave mb completes token block mb), fetched while the first batch of weight
@@ -2275,7 +2272,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
       if constexpr (EPI == EPI_NORM16) {
         if (p.flags & TCAVT_EPI_RESIDUAL) {
 #pragma unroll
-          for (int c = 0; c < NCB; ++c) old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + pmm * p.ldc + n0 + c * 16 + 4 * kq);
+          for (int c = 0; c < NCB; ++c)
+            old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + (p.o_frag ? frag16_off((int)pmm, n0 + c * 16 + 4 * kq, p.N)
+                                                                            : pmm * p.ldc + n0 + c * 16 + 4 * kq));
         }
       }
       if constexpr (NORMF) {
@@ -2428,7 +2427,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         }
         o = fma4(o, p.norm_scale, oldv);
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
-        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + off) = w;
+        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + (p.o_frag ? frag16_off(m, n0 + c * 16 + nq, p.N) : off)) = w;
         o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
         hq[c] = o;
       } else {
@@ -2481,7 +2480,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = silu_mul(g[e], u[e]);
-    store_quad(p, m, (n0 >> 1) + nq, o);
+    if (p.o_frag)  // (16-bit output of the operand type: checked by the host)
+      *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(p.C) + frag16_off(m, (n0 >> 1) + nq, p.N >> 1)) =
+          u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
+    else store_quad(p, m, (n0 >> 1) + nq, o);
   } else {  // EPI_ROPE: dimensions d = 16 half + nq .. + 3 and d + 32 of one head
     static_assert(EPI != EPI_ROPE || NCB == 2, "two partner blocks per workgroup");
     if (!rowok) return;
@@ -2518,11 +2520,6 @@ static int launch_skinny(const GemmP& p, hipStream_t stream) {
   //  second read of every weight row costs more than the activation rows it saves: gate|up 25.8 -> 33.2 us, lm_head likewise)
   const int msplit = (S == 1 && p.M > 16 && nblk % 8 == 0 && nblk <= 256 && !no_msplit) ? 2 : 1;
   q.sk_msplit = msplit;
-  q.sk_dbg_xpack = 0;
-#ifdef TCAVT_EXPERIMENTS
-  static const bool dbg_x = getenv("TCAVT_SK_XPACK_TIMING") != nullptr;
-  q.sk_dbg_xpack = dbg_x && p.lda == p.K && (msplit > 1 ? p.M == 32 : (p.M == 16 || p.M == 32)) ? 1 : 0;
-#endif
   // Non-temporal weight loads where every weight byte is read ONCE per launch (one workgroup per column block) from the
   // fragment-major copy: 0.925 -> 0.885 ms per decode step at B = 8.  (On row-major weights nt was slower, 1.15 vs 1.09 ms --
   // the two 64-byte halves of a 128-byte line are fetched by different instructions there; with the token blocks on two
@@ -2720,7 +2717,21 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.lp_lda = 0;
   p.lp_np = 0;
   p.lp_scale = 1.f;
-  p.w_frag = 0;
+  p.w_frag = p.a_frag = p.o_frag = 0;
+  if (a->act_layout != 0) {
+    TCAVT_CHECK_ARG((a->act_layout & ~(TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16)) == 0 && a->tile == 0 && skinny_shape(a->M, a->K) &&
+                        batch == 1 && a->dropout_p == 0.f,
+                    "gemm_bf16: act_layout (fragment-major activations) goes with the skinny form only (M <= 32, K %% 256 == 0, tile 0)");
+    p.a_frag = (a->act_layout & TCAVT_ACT_A_FRAG16) ? 1 : 0;
+    if (a->act_layout & TCAVT_ACT_OUT_FRAG16) {
+      const bool silu = (a->epilogue & ~TCAVT_EPI_ROWSCALE) == TCAVT_EPI_SILU_MUL && a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) &&
+                        a->N % 64 == 0;
+      const bool stream = (a->epilogue & TCAVT_EPI_NORM_OUT) && stream16 && a->N % 32 == 0;
+      TCAVT_CHECK_ARG(silu || stream, "gemm_bf16: TCAVT_ACT_OUT_FRAG16 needs SILU_MUL with a 16-bit output of the operand type, or "
+                                      "NORM_OUT with C == NULL (the in-place 16-bit stream)");
+      p.o_frag = 1;
+    }
+  }
   if (a->w_layout != 0) {
     TCAVT_CHECK_ARG(a->w_layout == TCAVT_W_FRAG16 && a->tile == 0 && skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f &&
                         a->lda >= a->K && a->ldw == a->K && a->N % 16 == 0,
@@ -2845,7 +2856,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
       return f16 ? launch_skinny<EPI_GENERIC, 1, true>(p, s) : launch_skinny<EPI_GENERIC, 1, false>(p, s);
     }
   }
-  TCAVT_CHECK_ARG(!p.w_frag, "gemm_bf16: w_layout = TCAVT_W_FRAG16: this epilogue / shape has no skinny form");
+  TCAVT_CHECK_ARG(!p.w_frag && !p.a_frag && !p.o_frag, "gemm_bf16: w_layout / act_layout: this epilogue / shape has no skinny form");
   if (epi & TCAVT_EPI_SILU_BWD) {  // dgrad of down_proj with d(silu(gate) * up) in the epilogue: the 4-wave kernel only
     TCAVT_CHECK_ARG(epi == TCAVT_EPI_SILU_BWD && batch == 1 && K2 == 0 && a->M % 256 == 0 && a->N % 256 == 0 && a->K >= 128 &&
                         a->silu_preact && aligned16(a->silu_preact) && a->dropout_p == 0.f && p.acc_scale == 1.f &&

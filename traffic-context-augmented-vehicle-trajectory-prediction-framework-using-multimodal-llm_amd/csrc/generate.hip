@@ -38,7 +38,7 @@ template <bool F16, bool PFV>
 __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ vc, const int* __restrict__ pos,
                                                            bf16_t* __restrict__ out, int lmax, int nq, int nkv, float scale,
-                                                           int KS) {
+                                                           int KS, int out_frag) {
   extern __shared__ float sc[];  // [lmax] scores | [KS][2] (max, sum) | [KS][64] partial outputs
   const int group = nq / nkv;
   const int b = blockIdx.x / nq, head = blockIdx.x % nq, kvh = head / group;
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
   if (ks == 0) {
     float o = po[lane];
     for (int k = 1; k < KS; ++k) o += po[k * 64 + lane];
-    out[(long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
+    // (out_frag: the o projection's operand order, common.hpp frag16_off)
+    out[out_frag ? frag16_off(b, head * 64 + lane, nq * 64) : (long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
   }
 }
 
@@ -835,11 +836,16 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
   const int wl = a->w_layout;
   TCAVT_CHECK_ARG(wl == 0 || (wl == TCAVT_W_FRAG16 && B <= 32 && I % 256 == 0 && (nq * 64) % 256 == 0),
                   "llama_decode_step: w_layout must be 0 or TCAVT_W_FRAG16 (B <= 32, I %% 256 == 0, nq * 64 %% 256 == 0)");
+  // fragment-major activations: h16, att, act, x16 in the skinny GEMMs' operand order (16 or 32 whole rows each)
+  const int al = a->act_layout;
+  TCAVT_CHECK_ARG(al == 0 || (al == 1 && a->h == nullptr && B <= 32 && I % 256 == 0 && (nq * 64) % 256 == 0),
+                  "llama_decode_step: act_layout must be 0 or 1 (16-bit residual stream: h == NULL; B <= 32, I %% 256 == 0, nq * 64 %% 256 == 0)");
+  const int gA = al ? TCAVT_ACT_A_FRAG16 : 0, gAO = al ? (TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16) : 0;
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
   // (a->h == NULL: the residual stream is the 16-bit h16 itself, as in tcavt_llama_stack_forward)
-  TCAVT_TRY(tcavt_embed_fuse(a->table, a->cur_tok, a->txt_mod /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
-                             a->bad_id_flag, dt, a->h16, a->part, np_in, ss_, stream));
+  TCAVT_TRY(embed_fuse_impl(a->table, a->cur_tok, a->txt_mod /* unused: Nq = 0 */, a->txt_mod, a->txt_mod, a->h, B, 0, 1, H, a->V,
+                            a->bad_id_flag, dt, a->h16, a->part, np_in, ss_, al, stream));
   const size_t per_layer = (size_t)B * a->kv_lmax * nkv * 64;
   const int KS = std::min(16, (a->kv_lmax + 63) / 64);  // key splits (waves) per query head: one 64-key round each up to 1024 keys
   const size_t lds = ((size_t)a->kv_lmax + (size_t)KS * 66) * sizeof(float);
@@ -854,14 +860,14 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     const bool t_fused = lp_ok && li > 0 && w.a_cat && a->layers[li - 1].w_d;
     if (w.a_cat && !t_fused) {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H;
+      g.A = a->h16; g.lda = H; g.W = w.a_cat; g.ldw = H; g.C = a->t; g.ldc = 64; g.M = B; g.N = 64; g.K = H; g.act_layout = gA;
       g.out_dtype = dt; g.in_dtype = dt; g.acc_scale = a->lora_scale;  // (t is at the stream's scale, like the main term of the accumulator)
       g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv; g.w_layout = wl;
+      g.A = a->h16; g.lda = H; g.W = w.w_qkv; g.ldw = H; g.C = a->qkv; g.ldc = nqkv; g.w_layout = wl; g.act_layout = gA;
       g.M = B; g.N = nqkv; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       if (t_fused) {
         g.W2 = w.b_ext; g.ldw2 = 64; g.lora_part = a->lora_part; g.lora_part_np = H / 16; g.lora_part_scale = a->lora_scale;
@@ -881,12 +887,12 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       auto kfn = dt == TCAVT_F16 ? (pfv ? attn_decode_kernel<true, true> : attn_decode_kernel<true, false>)
                                  : (pfv ? attn_decode_kernel<false, true> : attn_decode_kernel<false, false>);
       hipLaunchKernelGGL(kfn, dim3(B * nq), dim3(KS * 64), lds, st, static_cast<const bf16_t*>(a->qkv), kc, vc, a->pos,
-                         static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS);
+                         static_cast<bf16_t*>(a->att), a->kv_lmax, nq, nkv, 0.125f, KS, al);
     }
     TCAVT_CHECK_LAUNCH("attn_decode");
     {
       tcavt_gemm_args g = {};
-      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H; g.w_layout = wl;
+      g.A = a->att; g.lda = nq * 64; g.W = w.w_o; g.ldw = nq * 64; g.C = a->h; g.ldc = H; g.w_layout = wl; g.act_layout = gAO;
       g.M = B; g.N = H; g.K = nq * 64; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
@@ -896,7 +902,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I; g.w_layout = wl;
+      g.A = a->h16; g.lda = H; g.W = w.w_gu; g.ldw = H; g.C = a->act; g.ldc = I; g.w_layout = wl; g.act_layout = gAO;
       g.M = B; g.N = 2 * I; g.K = H; g.out_dtype = dt; g.in_dtype = dt;
       g.epilogue = TCAVT_EPI_SILU_MUL | TCAVT_EPI_ROWSCALE;
       g.rowscale_part = a->part; g.rowscale_npart = np_post; g.rowscale_h = H; g.rowscale_eps = eps_s;
@@ -905,7 +911,7 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
     }
     {
       tcavt_gemm_args g = {};
-      g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H; g.w_layout = wl;
+      g.A = a->act; g.lda = I; g.W = w.w_d; g.ldw = I; g.C = a->h; g.ldc = H; g.w_layout = wl; g.act_layout = gAO;
       g.M = B; g.N = H; g.K = I; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
       g.residual = a->h; g.ldr = H; g.epilogue = TCAVT_EPI_RESIDUAL | TCAVT_EPI_NORM_OUT;
       g.norm_h16 = a->h16; g.norm_part = a->part; g.norm_scale = ss_;
@@ -917,12 +923,13 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
       TCAVT_TRY(tcavt_gemm_bf16(&g, stream));
     }
   }
-  if (a->h == nullptr) TCAVT_TRY(tcavt_rmsnorm16(a->h16, a->gamma_final, eps_s, a->x16, nullptr, B, H, dt, stream));
+  if (a->h == nullptr) TCAVT_TRY(rmsnorm16_impl(a->h16, a->gamma_final, eps_s, a->x16, nullptr, B, H, dt, al, stream));
   else TCAVT_TRY(tcavt_rmsnorm(a->h, a->gamma_final, a->rms_eps, a->x16, nullptr, B, H, nullptr, 0.f, 0, 0, dt, stream));
   // lm_head: tied to the embedding table (Llama-3.2-1B: tie_word_embeddings)
   tcavt_gemm_args g = {};
   g.A = a->x16; g.lda = H; g.W = a->table; g.ldw = H; g.C = a->logits; g.ldc = a->V;
   if (a->table_packed && B <= 32) { g.W = a->table_packed; g.w_layout = TCAVT_W_FRAG16; }
+  g.act_layout = gA;
   g.M = B; g.N = a->V; g.K = H; g.out_dtype = TCAVT_F32; g.in_dtype = dt;
   g.splitk_ws = a->splitk_ws; g.splitk_ws_bytes = a->splitk_ws_bytes;
   return tcavt_gemm_bf16(&g, stream);

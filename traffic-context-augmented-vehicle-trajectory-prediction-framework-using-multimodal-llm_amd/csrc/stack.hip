@@ -329,14 +329,16 @@ extern "C" int tcavt_llama_stack_forward(const tcavt_llama_stack_args* a, tcavt_
 namespace {
 template <bool F16>
 __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma, float eps,
-                                                        bf16_t* __restrict__ out16, float* __restrict__ out_f32, int M, int H) {
+                                                        bf16_t* __restrict__ out16, float* __restrict__ out_f32, int M, int H, int frag16) {
   // one wave per row, 16-byte accesses (8 elements per lane and step: 512 columns per wave-instruction), the row in registers when
   // H <= 4096, every load of the row requested before the first is used (the first version moved 8 bytes per lane and step and ran
   // at 0.9 TB/s: 71 us for the decoder's final norm at M = 8192, on the decoder stream's critical path)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const bf16_t* xr = x + row * H;
+  // (frag16: the <= 32 rows of a decode step in the skinny GEMM's operand order, in and out: same lanes, same columns, same sums)
+  auto xat = [&](int c) { return frag16 ? x + frag16_off((int)row, c, H) : x + row * H + c; };
+  auto oat = [&](int c) { return frag16 ? out16 + frag16_off((int)row, c, H) : out16 + row * H + c; };
   constexpr int NV = 8;  // 8 x 512 = 4096 columns in registers
   u32x4 w[NV];
   float ss = 0.f;
@@ -350,13 +352,13 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
   };
 #pragma unroll
   for (int i = 0; i < NV; ++i)
-    if (i < nv) w[i] = *reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8);
+    if (i < nv) w[i] = *reinterpret_cast<const u32x4*>(xat(i * 512 + lane * 8));
   u32x2 wt = {0u, 0u};
-  if (tail) wt = *reinterpret_cast<const u32x2*>(xr + nv * 512 + lane * 4);
+  if (tail) wt = *reinterpret_cast<const u32x2*>(xat(nv * 512 + lane * 4));
 #pragma unroll
   for (int i = 0; i < NV; ++i)
     if (i < nv) sq4(w[i]);
-  for (int i = NV; i < nv; ++i) sq4(*reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8));
+  for (int i = NV; i < nv; ++i) sq4(*reinterpret_cast<const u32x4*>(xat(i * 512 + lane * 8)));
   if (tail) {
     const float a = from16_lo<F16>(wt[0]), b = from16_hi<F16>(wt[0]), c = from16_lo<F16>(wt[1]), d = from16_hi<F16>(wt[1]);
     ss += a * a + b * b + c * c + d * d;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
       y[2 * e + 1] = from16_hi<F16>(v[e]) * rs * (e < 2 ? g0[2 * e + 1] : g1[2 * e - 3]);
     }
     if (out16)
-      *reinterpret_cast<u32x4*>(out16 + row * H + c) = u32x4{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3]),
+      *reinterpret_cast<u32x4*>(oat(c)) = u32x4{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3]),
                                                              pack16x2<F16>(y[4], y[5]), pack16x2<F16>(y[6], y[7])};
     if (out_f32) {
       *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = f32x4{y[0], y[1], y[2], y[3]};
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int i = 0; i < NV; ++i)
     if (i < nv) emit8(i * 512 + lane * 8, w[i]);
-  for (int i = NV; i < nv; ++i) emit8(i * 512 + lane * 8, *reinterpret_cast<const u32x4*>(xr + i * 512 + lane * 8));
+  for (int i = NV; i < nv; ++i) emit8(i * 512 + lane * 8, *reinterpret_cast<const u32x4*>(xat(i * 512 + lane * 8)));
   if (tail) {
     const int c = nv * 512 + lane * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
     y[1] = from16_hi<F16>(wt[0]) * rs * g[1];
     y[2] = from16_lo<F16>(wt[1]) * rs * g[2];
     y[3] = from16_hi<F16>(wt[1]) * rs * g[3];
-    if (out16) *reinterpret_cast<u32x2*>(out16 + row * H + c) = u32x2{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
+    if (out16) *reinterpret_cast<u32x2*>(oat(c)) = u32x2{pack16x2<F16>(y[0], y[1]), pack16x2<F16>(y[2], y[3])};
     if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + row * H + c) = y;
   }
 }
@@ -399,16 +401,22 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
 
 extern "C" int tcavt_rmsnorm16(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H,
                                int dtype16, tcavt_stream_t stream) {
+  return tcavt::rmsnorm16_impl(x16, gamma, eps, out16, out_f32, M, H, dtype16, 0, stream);
+}
+
+int tcavt::rmsnorm16_impl(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H, int dtype16,
+                          int frag16, tcavt_stream_t stream) {
+  TCAVT_CHECK_ARG(!frag16 || (M <= 32 && !out_f32), "rmsnorm16: fragment-major rows: at most 32, 16-bit output only");
   TCAVT_CHECK_ARG(x16 && gamma && (out16 || out_f32) && M > 0 && H > 0 && H % 256 == 0 && is16(dtype16),
                   "rmsnorm16: bad args (H %% 256 == 0)");
   TCAVT_CHECK_ARG(aligned16(x16) && aligned16(gamma), "rmsnorm16: unaligned input");
   const dim3 grid((unsigned)((M + 3) / 4)), block(256);
   if (dtype16 == TCAVT_F16)
     hipLaunchKernelGGL(rmsnorm16_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16), gamma,
-                       eps, static_cast<bf16_t*>(out16), out_f32, M, H);
+                       eps, static_cast<bf16_t*>(out16), out_f32, M, H, frag16);
   else
     hipLaunchKernelGGL(rmsnorm16_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(x16), gamma,
-                       eps, static_cast<bf16_t*>(out16), out_f32, M, H);
+                       eps, static_cast<bf16_t*>(out16), out_f32, M, H, frag16);
   TCAVT_CHECK_LAUNCH("rmsnorm16");
   return TCAVT_OK;
 }

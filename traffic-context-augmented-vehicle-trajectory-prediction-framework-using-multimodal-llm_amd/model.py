@@ -1151,24 +1151,35 @@ class LlamaMultiModal(nn.Module, _Prepared):
                 if N > 1:
                     cos, sin = LW._rope_tables(Lmax, dev)
                     a = capi.DecodeArgs()
-                    bufs = dict(h16=ws.get("gen.dh16", (B, H), st, dev),
+                    # fragment-major weight copies for the step's weight streams and, on the 16-bit stream, fragment-major
+                    # activations between its kernels (16 or 32 whole rows per buffer); TCAVT_DECODE_ROWMAJOR=1 /
+                    # TCAVT_DECODE_ACT_ROWMAJOR=1: the row-major forms (A/B, tests)
+                    DW = LW.decode_weights() if (B <= 32 and os.environ.get("TCAVT_DECODE_ROWMAJOR", "0") != "1") else None
+                    # (B <= 8: row-major activation rows are HALF the bytes of a 16-token fragment -- lanes of the empty token slots
+                    #  repeat the last row -- and the step is 0.89 vs 0.91 ms; B = 16: 0.98 vs 1.05, B = 32: 1.09 vs 1.21 ms)
+                    frag_act = (DW is not None and LW.stream16 and os.environ.get("TCAVT_DECODE_ACT_ROWMAJOR", "0") != "1"
+                                and (B > 8 or os.environ.get("TCAVT_DECODE_ACT_FRAG", "0") == "1"))
+                    Br = (16 if B <= 16 else 32) if frag_act else B
+                    bufs = dict(h16=ws.get("gen.dh16", (Br, H), st, dev, zero=True),
                                 part=ws.get("gen.dpart", (B, H // 16), torch.float32, dev),
-                                qkv=ws.get("gen.dqkv", (B, nqkv), st, dev), att=ws.get("gen.datt", (B, ll.n_q_heads * ll.head_dim), st, dev),
-                                act=ws.get("gen.dact", (B, ll.inter), st, dev), t=ws.get("gen.dt", (B, 64), st, dev, zero=True))
+                                qkv=ws.get("gen.dqkv", (B, nqkv), st, dev),
+                                att=ws.get("gen.datt", (Br, ll.n_q_heads * ll.head_dim), st, dev, zero=True),
+                                act=ws.get("gen.dact", (Br, ll.inter), st, dev, zero=True), t=ws.get("gen.dt", (B, 64), st, dev, zero=True))
                     if not LW.stream16:
                         bufs["h"] = ws.get("gen.dh", (B, H), torch.float32, dev)
                     for k_, v_ in bufs.items():
                         setattr(a, k_, v_.data_ptr())
                     a.layers, a.gamma_final = PL.carr, PL.g_final.data_ptr()
-                    # fragment-major weight copies for the step's weight streams (TCAVT_DECODE_ROWMAJOR=1: the prefill's arrays, A/B)
-                    DW = LW.decode_weights() if (B <= 32 and os.environ.get("TCAVT_DECODE_ROWMAJOR", "0") != "1") else None
                     if DW is not None:
                         a.layers, a.w_layout, a.table_packed = DW.carr, capi.W_FRAG16, DW.table.data_ptr()
+                    if frag_act:
+                        a.act_layout = 1
                     a.rope_cos, a.rope_sin, a.rope_L = cos.data_ptr(), sin.data_ptr(), Lmax
                     a.table, a.txt_mod = PL.table.data_ptr(), P.txt.data_ptr()
                     a.cur_tok, a.pos = cur.data_ptr(), pos.data_ptr()
                     a.k_cache, a.v_cache, a.kv_lmax = kc.data_ptr(), vc.data_ptr(), Lmax
-                    a.x16, a.logits, a.bad_id_flag = x16.data_ptr(), logits.data_ptr(), flags.data_ptr()
+                    dx16 = ws.get("gen.dx16", (Br, H), st, dev, zero=True) if frag_act else x16
+                    a.x16, a.logits, a.bad_id_flag = dx16.data_ptr(), logits.data_ptr(), flags.data_ptr()
                     a.nonfinite_flag = flags[2:3].data_ptr()
                     if LW.use_lora and LW.lora_r <= 8 and os.environ.get("TCAVT_DECODE_LORA_LAUNCH", "0") != "1":  # (A/B switch)
                         a.lora_part, a.lora_rank = ws.get("gen.lpart", (B * H,), torch.float32, dev).data_ptr(), LW.lora_r
