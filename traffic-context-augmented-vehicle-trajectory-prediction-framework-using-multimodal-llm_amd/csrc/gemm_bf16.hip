@@ -1312,8 +1312,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   // weight rows).  The swizzle term of a lane does not depend on r (32-row steps), so one base per operand.
   const int rl = lane >> 3;
   const int csw = (lane & 7) ^ (((wave & 1) * 4 + (rl >> 1)) & 7);
+  // WT (DBG & 128, experiments build, TIMING ONLY): W addressed as if stored tile-major -- every 256-row x 64-column K-tile of a
+  // column tile a contiguous 32 KiB, a DMA piece 1 KiB of consecutive bytes instead of 8 rows x 128 bytes ldw apart
+  constexpr bool WT = (DBG & 128) != 0;
+  constexpr int WKT = WT ? BN * 64 : 64;  // elements from one K-tile of W to the next
   const bf16_t* srcA = p.A + (long)(m0 + wave * 8 + rl) * p.lda + csw * 8;
-  const bf16_t* srcW = p.W + (long)(n0 + wave * 8 + rl) * p.ldw + csw * 8;
+  const bf16_t* srcW = WT ? p.W + (long)n0 * p.K + (wave * 8 + rl) * 64 + csw * 8 : p.W + (long)(n0 + wave * 8 + rl) * p.ldw + csw * 8;
   // next output tile of this workgroup (persistent form): where the look-ahead continues
   bool has_next = pers && vb + (int)gridDim.x < total_tiles;
   int nm0 = m0, nn0 = n0;
@@ -1326,11 +1330,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
       nm0 = tm * BM;
       nn0 = tn * BN;
       nxtA = p.A + (long)(nm0 + wave * 8 + rl) * p.lda + csw * 8;
-      nxtW = p.W + (long)(nn0 + wave * 8 + rl) * p.ldw + csw * 8;
+      nxtW = WT ? p.W + (long)nn0 * p.K + (wave * 8 + rl) * 64 + csw * 8 : p.W + (long)(nn0 + wave * 8 + rl) * p.ldw + csw * 8;
     }
   };
   locate_next();
-  const long stepA = 32 * p.lda, stepW = 32 * p.ldw;
+  const long stepA = 32 * p.lda, stepW = WT ? 32 * 64 : 32 * p.ldw;
   // second K source (LoRA: A2 = x.A_cat^T, W2 = B_ext): its 64-deep tiles follow the main ones
   constexpr bool HASK2 = EPI == EPI_ROPE;  // only the fused q|k|v projection uses it
   const bf16_t* srcA2 = nullptr;
@@ -1362,14 +1366,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
   };
   auto tsrc = [&](int t) -> Src {
     if constexpr (PERS_OK) {
-      if (t >= nt && has_next) return Src{nxtA + (t - nt) * 64, nxtW + (t - nt) * 64, stepA, stepW};  // next tile's first K-tiles
+      if (t >= nt && has_next) return Src{nxtA + (t - nt) * 64, nxtW + (t - nt) * WKT, stepA, stepW};  // next tile's first K-tiles
     }
     t = min(t, nt - 1);  // the last two K-tiles re-fetch the last tile into a free buffer (keeps the loop body uniform)
     if constexpr (BUF) return Src{nullptr, nullptr, (long)t * 128, 0};  // only the tile's byte offset along K
     if constexpr (HASK2) {
       if (t >= nt1) return Src{srcA2 + (t - nt1) * 64, srcW2 + (t - nt1) * 64, stepA2, stepW2};
     }
-    return Src{srcA + t * 64, srcW + t * 64, stepA, stepW};
+    return Src{srcA + t * 64, srcW + t * WKT, stepA, stepW};
   };
   // buffer form: resources based at the tile's first row, byte offsets in 32 bits (launch_w4 checks the range)
   __amdgpu_buffer_rsrc_t rsA, rsW;
@@ -1472,7 +1476,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
             koff2 = (second2 ? tt - nt1 : tt) * 64;
           }
           if (idx == 3) sn2.a = (into_next2 ? nxtA : second2 ? srcA2 : srcA) + koff2;
-          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + koff2;
+          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + (WT ? koff2 * (WKT / 64) : koff2);
           if (idx == 9) {
             sn2.sa = second2 ? stepA2 : stepA;
             sn2.sw = second2 ? stepW2 : stepW;
@@ -1507,7 +1511,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmP p) {
           if (idx == 3) sn2 = Src{nullptr, nullptr, (long)koff2 * 2, 0};
         } else {
           if (idx == 3) sn2.a = (into_next2 ? nxtA : second2 ? srcA2 : srcA) + koff2;
-          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + koff2;
+          if (idx == 6) sn2.w = (into_next2 ? nxtW : second2 ? srcW2 : srcW) + (WT ? koff2 * (WKT / 64) : koff2);
           if (idx == 9) {
             sn2.sa = second2 ? stepA2 : stepA;
             sn2.sw = second2 ? stepW2 : stepW;
@@ -1983,7 +1987,7 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
 #endif
     case 257: case 272:
 #ifdef TCAVT_EXPERIMENTS
-    case 258: case 259: case 268: case 269: case 270:
+    case 258: case 259: case 268: case 269: case 270: case 266: case 274:
 #endif
       if (batch == 1 && (q.K2 == 0 || EPI == EPI_ROPE) && q.M % 256 == 0 && q.N % 256 == 0 &&
           (EPI != EPI_ROPE || q.out_kind == (F16 ? TCAVT_F16 : TCAVT_BF16))) {
@@ -1999,6 +2003,10 @@ static int dispatch_tile(const GemmP& p, int tile, int batch, hipStream_t stream
           if (tile == 269) return launch_w4<EPI, 2, 32>(q, stream);
           if (tile == 258) return launch_w4<EPI, 3>(q, stream);
           if (tile == 259) return launch_w4<EPI, 4>(q, stream);
+        }
+        if constexpr (EPI != EPI_ROPE) {  // tile-major W addressing, TIMING ONLY (wrong results): one-barrier / deep form
+          if (tile == 266) return launch_w4<EPI, 2, 128, false, 256, F16>(q, stream);
+          if (tile == 274) return launch_w4<EPI, 2, 128 + 64, false, 256, F16>(q, stream);
         }
 #endif
         return launch_w4<EPI, 2, 0, false, 256, F16>(q, stream);
@@ -2679,7 +2687,7 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
                     "gemm_bf16: ROPE needs cos/sin tables, rope_L > 0, rope_cols %% 64 == 0");
   }
 #ifdef TCAVT_EXPERIMENTS
-  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 273 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
+  TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || (a->tile >= 250 && a->tile <= 274 && a->tile != 251 && a->tile != 254) || (a->tile >= 124 && a->tile <= 127),
                   "gemm_bf16: tile must be 0 (auto), 128 or 256 (or an A/B code: 250, 252, 253, 255, 126, 127)");
 #else
   TCAVT_CHECK_ARG(a->tile == 0 || a->tile == 64 || a->tile == 128 || a->tile == 256 || a->tile == 257 || a->tile == 271 || a->tile == 272,
