@@ -165,6 +165,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="(kept for old command lines; same as --launch eager)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--rccl-self-test", action="store_true",
+                    help="--gpus 1 only: a one-rank RCCL process group takes Trainer's data-parallel path (real all-reduce per "
+                         "bucket, five-stream layout); adds dp_diagnostics to the line")
     ap.add_argument("--feed", choices=["resident", "host"], default="resident",
                     help="resident (default, the driver's contract: inputs in HBM before the timed region): every step runs on one "
                          "resident batch.  host: every step collates a fresh batch on the host (data.custom_collate_fn over "
@@ -357,6 +360,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
+    elif args.rccl_self_test:
+        # one rank, real RCCL: the data-parallel path of Trainer (bucketed all-reduce on the process group's own stream, the
+        # reduced stream layout) on the one GPU of a box -- RCCL refuses two ranks on one device, so this is as close as a
+        # single card gets to the N > 1 run; the line carries dp_diagnostics like an N > 1 line
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ["TCAVT_FORCE_DP"] = "1"
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    dp = world > 1 or args.rccl_self_test
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.dry_run:
@@ -526,7 +541,7 @@ def main():
         for _ in range(args.warmup):
             run_step()
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
@@ -534,7 +549,7 @@ def main():
             run_step()
         enqueue_s = time.perf_counter() - t_start  # host time to enqueue the K steps (eager: must stay below the GPU time)
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t_start
@@ -572,7 +587,7 @@ def main():
         # every bucket's all-reduce held its launching stream, (iii) busy / idle time of the MLLM stream per step, (iv) the
         # number of HIP streams a rank uses (the five-stream budget)
         dp_diag = None
-        if world > 1 and trainer is not None and graph is None:
+        if dp and trainer is not None and graph is None:
             n_diag = max(5, min(args.steps, 20))
 
             def timed_loop(n):
@@ -613,7 +628,7 @@ def main():
 
     if trainer is not None:
         trainer.release_graph()
-    if world > 1:
+    if dp:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -671,7 +686,8 @@ def main():
                              "decoder layers, clip_grad_norm 1.0)")) if (args.lora_trainable and args.mode == "train")
                            else "train.py (MLLM frozen)",
                 "per_gpu_batch": B, "global_batch": world * B, "fused_seq_len": L, "t_in": cfg.seq_len,
-                "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0, "parallelism": f"dp{world}",
+                "t_out": cfg.out_len, "lora_r": cfg.lora_r if cfg.use_lora else 0,
+                "parallelism": f"dp{world}" + (" (one-rank RCCL group: the data-parallel path on one card)" if args.rccl_self_test else ""),
                 "launch": "eager" if graph is None else "hipGraph replay",
                 "pipelining": "; ".join(
                     ([("Q-Former of batch i+1 prefetched on a side stream during step i (every timed step runs one Q-Former "
@@ -712,7 +728,7 @@ def main():
             if out["cpu_baseline"]:
                 out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 

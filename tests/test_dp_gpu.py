@@ -123,3 +123,50 @@ def _initial_params(case, tr):
         o, n, shape = tr.book.offsets[name]
         out[o:o + n] = torch.from_numpy(weights[name]).reshape(-1)
     return out
+
+
+def _rccl_worker(port, case, outdir):
+    import torch.distributed as dist
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    # (1) the plain one-process step
+    _, grads0, params0, loss0 = _step(case, slice(0, 2), dev)
+    # (2) the same step through a ONE-rank RCCL process group taking the data-parallel path (TCAVT_FORCE_DP)
+    os.environ["TCAVT_FORCE_DP"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr, grads1, params1, loss1 = _step(case, slice(0, 2), dev)
+        assert tr._force_dp and tr.world == 1
+        cfg, weights, fx = load_case(case)
+        g = {k: v[0:2].contiguous().to(dev) for k, v in batch_tensors(fx).items()}
+        tr.enable_diagnostics(True)
+        tr.forward_backward(*[g[k] for k in ARGS])
+        torch.cuda.synchronize()
+        d = tr.diagnostics()
+        tr.enable_diagnostics(False)
+        torch.save({"g0": grads0, "g1": grads1, "p0": params0, "p1": params1, "l0": loss0, "l1": loss1, "diag": d},
+                   os.path.join(outdir, "rccl.pt"))
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("TCAVT_FORCE_DP", None)
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_group_takes_the_data_parallel_path(gpu, tmp_path):
+    """The collective library of production on the one card of the box: a one-rank RCCL (backend "nccl") process group with
+    TCAVT_FORCE_DP=1 makes Trainer launch the real per-bucket all-reduce on the process group's stream, with the reduced stream
+    layout of a data-parallel rank.  SUM over one rank is the identity: gradients, parameters and loss must equal the plain step,
+    every bucket must have been launched, and the rank stays within the five-stream budget."""
+    case = "tiny_6_12_lora_ragged"
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), case, str(tmp_path)))
+    p.start()
+    p.join(500)
+    assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    r = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
+    # (equal up to the order of the backward's atomically accumulated column sums, which differs from run to run)
+    assert rel_err(r["g1"], r["g0"]) < 1e-5 and rel_err(r["p1"], r["p0"]) < 1e-6 and abs(r["l0"] - r["l1"]) <= 1e-6 * abs(r["l0"])
+    d = r["diag"]
+    assert len(d["buckets"]) >= 1 and all(b["launches"] == 1 for b in d["buckets"]) and d["hip_streams_in_use"] <= 5, d

@@ -118,10 +118,14 @@ class Trainer:
         # and makes the launching stream wait: the exchange sits in the step's tail, which the next decoder hides), and (ii) fold
         # the side channels onto two streams (no measurable cost: 15.34 vs 15.34 ms).
         self._fake_dp = None  # tools only (TCAVT_FAKE_DP=1): one process with a stand-in for RCCL's stream
-        if dev.type == "cuda" and (self.world > 1 or os.environ.get("TCAVT_FAKE_DP", "0") == "1"):
+        # TCAVT_FORCE_DP=1 (tests, bench.py --rccl-self-test): a ONE-rank process group takes the data-parallel path -- the real
+        # RCCL all-reduce per bucket on the real process-group stream, the reduced stream layout -- on the one GPU a box has
+        self._force_dp = (self.world == 1 and os.environ.get("TCAVT_FORCE_DP", "0") == "1" and dist.is_available()
+                          and dist.is_initialized())
+        if dev.type == "cuda" and (self.world > 1 or self._force_dp or os.environ.get("TCAVT_FAKE_DP", "0") == "1"):
             streams.set_active_slots(2)
             model._side = model.ltsf._kv_stream = model.mllm._pf_stream = None  # (re-drawn from the pool on next use)
-            if self.world == 1:
+            if self.world == 1 and not self._force_dp:
                 self._fake_dp = torch.cuda.Stream(device=dev)
         # Measurement only (bench.py's same-build single-rank comparison leg): local_steps() switches the gradient exchange off
         # for a few steps and re-synchronises the replicas afterwards -- without the exchange every rank steps on its own
@@ -177,7 +181,7 @@ class Trainer:
         """SUM all-reduce of grads[lo:hi], launched from the current stream (the one that completed the bucket); the mean is
         taken by the clip / AdamW kernels.  torch.distributed runs it on the process group's own RCCL stream, ordered after
         the current stream, and makes the current stream wait for it."""
-        if (self.world == 1 and self._fake_dp is None) or not self._exchange:
+        if (self.world == 1 and self._fake_dp is None and not self._force_dp) or not self._exchange:
             return
         view = self.book.grads[lo:hi]
         if self.diag is not None and self._fake_dp is None:
@@ -375,13 +379,13 @@ class Trainer:
             b = buckets.setdefault((lo, hi), [])
             b.append(e0.elapsed_time(e1))
         m = self.model
-        n_streams = 1 + (S._ACTIVE or S.N_SLOTS) + (1 if getattr(m, "pipeline_decoder", False) else 0) + (1 if self.world > 1 else 0)
+        n_streams = 1 + (S._ACTIVE or S.N_SLOTS) + (1 if getattr(m, "pipeline_decoder", False) else 0) + (1 if (self.world > 1 or self._force_dp) else 0)
         return {
             "buckets": [{"first_element": lo, "bytes": 4 * (hi - lo), "launches": len(v), "mean_ms": round(sum(v) / len(v), 4),
                          "max_ms": round(max(v), 4)} for (lo, hi), v in sorted(buckets.items())],
             "hip_streams_in_use": n_streams,
             "hip_streams_note": "caller's stream + side-channel pool" + (" + MLLM stream" if getattr(m, "pipeline_decoder", False) else "")
-                                + (" + the process group's RCCL stream" if self.world > 1 else ""),
+                                + (" + the process group's RCCL stream" if (self.world > 1 or self._force_dp) else ""),
         }
 
     def check_flags(self):
