@@ -27,7 +27,7 @@ if [ "$part" = "a" ]; then
   done
   exit 0
 fi
-for v in "forward:--mode forward" "nopipeline:--no-pipeline" "bf16:--storage bf16" "feed_host:--feed host"; do
+for v in "forward:--mode forward" "nopipeline:--no-pipeline" "bf16:--storage bf16" "feed_host:--feed host" "rccl1:--rccl-self-test"; do
   n=${v%%:*}; f=${v#*:}
   python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline $f > $O/bench_$n.json 2> $O/bench_$n.err; echo "$n: $(tail -1 $O/bench_$n.err)"
 done
@@ -37,7 +37,7 @@ python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --lora-trainable --s
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lora -o lora -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --lora-trainable > $O/prof_lora.log 2>&1; echo "rocprof lora rc=$?"
 python3 $R/tools/lora_timeline.py $O/prof_lora/lora_kernel_trace.csv > $O/lora_timeline.txt 2>&1; head -3 $O/lora_timeline.txt
 cp $O/prof_lora/lora_kernel_stats.csv $O/lora_kernel_stats.csv; rm -rf $O/prof_lora
-for bs in 8 32; do python3 $R/tools/bench_generate.py --batch $bs 2>/dev/null | tail -1 > $O/generate_b$bs.json; cut -c1-330 $O/generate_b$bs.json; done
+for bs in 8 16 32; do python3 $R/tools/bench_generate.py --batch $bs 2>/dev/null | tail -1 > $O/generate_b$bs.json; cut -c1-330 $O/generate_b$bs.json; done
 python3 $R/tools/bench_generate.py --batch 8 --greedy 2>/dev/null | tail -1 > $O/generate_b8_greedy.json
 TCAVT_SAMPLE_ONE_STAGE=1 python3 $R/tools/bench_generate.py --batch 8 2>/dev/null | tail -1 > $O/generate_b8_one_stage_sampler.json
 for bs in 8 32; do
