@@ -189,6 +189,9 @@ typedef struct tcavt_gemm_args {
    *   TCAVT_ACT_A_FRAG16   (1)  A is in this order (lda ignored; K % 32 == 0)
    *   TCAVT_ACT_OUT_FRAG16 (2)  the 16-bit result is: C of TCAVT_EPI_SILU_MUL (row length N / 2), or the in-place 16-bit stream
    *                             norm_h16 / norm_res16 of TCAVT_EPI_NORM_OUT with C == NULL (row length N)
+   *   TCAVT_ACT_BLOCK8     (4)  with either: M <= 8, ONE block of 8 tokens -- element (m, f) at (f >> 5) * 256 + ((f >> 3) & 3) * 64
+   *                             + m * 8 + (f & 7), the buffer holds 8 whole rows (a k-step is 512 consecutive bytes: at M <= 8 a
+   *                             16-token fragment would be half padding)
    * Same values into the same MFMAs: results are bit-identical to the row-major call. */
   int32_t act_layout;
   /* TCAVT_EPI_NORM_OUT with C == NULL (16-bit residual stream), optional: the 16-bit residual is READ from here
@@ -1077,8 +1080,9 @@ typedef struct tcavt_decode_args {
   int32_t lora_rank;
   float stream_scale;              /* as tcavt_llama_stack_args.stream_scale (0 means 1) */
   int32_t w_layout;                /* 0, or TCAVT_W_FRAG16: layers[].w_qkv / w_o / w_gu / w_d point to tcavt_pack_weight16 copies */
-  int32_t act_layout;              /* 0, or 1: h16, att, act and x16 are kept in fragment-major order (tcavt_gemm_args.act_layout;
-                                      each buffer then holds 16 (B <= 16) or 32 whole rows); needs h == NULL, B <= 32, fp16 or bf16 alike */
+  int32_t act_layout;              /* 0; 1: h16, att, act and x16 are kept in fragment-major order (tcavt_gemm_args.act_layout; each
+                                      buffer then holds 16 (B <= 16) or 32 whole rows, B <= 32); 2: the same in ONE block of 8
+                                      tokens (TCAVT_ACT_BLOCK8; buffers of 8 whole rows, B <= 8).  Needs h == NULL */
   const void* table_packed;        /* optional: tcavt_pack_weight16 copy of `table` for the lm_head product (the token lookup
                                       keeps reading `table`) */
 } tcavt_decode_args;
@@ -1094,6 +1098,7 @@ int tcavt_llama_decode_step(const tcavt_decode_args* args, tcavt_stream_t stream
 #define TCAVT_W_FRAG16 1
 #define TCAVT_ACT_A_FRAG16 1
 #define TCAVT_ACT_OUT_FRAG16 2
+#define TCAVT_ACT_BLOCK8 4
 int tcavt_pack_weight16(const void* W, int64_t ldw, void* out, int N, int K, tcavt_stream_t stream);
 
 /* hipEvent helpers for tcavt_llama_stack_args.events (timing enabled); elapsed time in milliseconds between two

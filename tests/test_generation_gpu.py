@@ -185,9 +185,9 @@ def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
     m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(w, device=dev).eval()
     kw = dict(max_new_tokens=12, input_ids=t["input_ids"].to(dev), attention_mask=t["attention_mask"].to(dev))
     outs = {}
-    for mode in ("frag", "frag_w", "row"):
-        if mode == "frag":  # (fragment-major activations are the default above 8 samples only)
-            os.environ["TCAVT_DECODE_ACT_FRAG"] = "1"
+    for mode in ("frag", "frag16", "frag_w", "row"):  # "frag": the default (one block of 8 tokens at this batch size)
+        if mode == "frag16":  # blocks of 16 tokens, as above 8 samples
+            os.environ["TCAVT_DECODE_ACT_FRAG"] = "16"
         if mode == "row":
             os.environ["TCAVT_DECODE_ROWMAJOR"] = "1"
         if mode == "frag_w":  # fragment-major weights, row-major activations
@@ -204,6 +204,6 @@ def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
     torch.cuda.synchronize()
     m.mllm.check_flags()
     assert m.mllm.llama_wrapper._prep_dec is not None
-    for a_, b_, c_ in zip(outs["frag"], outs["row"], outs["frag_w"]):
-        assert torch.equal(a_, b_) and torch.equal(c_, b_)
+    for a_, b_, c_, d_ in zip(outs["frag"], outs["row"], outs["frag_w"], outs["frag16"]):
+        assert torch.equal(a_, b_) and torch.equal(c_, b_) and torch.equal(d_, b_)
     assert torch.equal(outs["frag"][1], outs["frag"][2])

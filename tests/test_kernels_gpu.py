@@ -516,9 +516,10 @@ def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
     x = (torch.randn(M, K, generator=g)).to(dt).to(dev)
     part = (torch.rand(M, 8, generator=g) * 40 + 10).to(dev)
 
-    def run(w, wl, N, epi, out, **kw):
+    def run(w, wl, N, epi, out, xin=None, **kw):
         a = capi.GemmArgs()
-        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = x.data_ptr(), K, w.data_ptr(), K, (out.data_ptr() if out is not None else None), kw.pop("ldc", N)
+        a.A, a.lda, a.W, a.ldw = (x if xin is None else xin).data_ptr(), K, w.data_ptr(), K
+        a.C, a.ldc = (out.data_ptr() if out is not None else None), kw.pop("ldc", N)
         a.M, a.N, a.K, a.tile, a.epilogue, a.w_layout = M, N, K, 0, epi, wl
         a.in_dtype, a.out_dtype = ops._DT[dt], ops._DT[out.dtype] if out is not None else capi.F32
         for k_, v_ in kw.items():
@@ -579,6 +580,7 @@ def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
     # ---- fragment-major ACTIVATIONS as well (tcavt_gemm_args.act_layout): A read, SiLU output / in-place stream written in the
     # operand order of the next skinny GEMM; the layout is the weight pack's with tokens as rows (padded to whole 16-row blocks)
     Mr = 16 if M <= 16 else 32
+    AF, AO = capi.ACT_A_FRAG16, capi.ACT_A_FRAG16 | capi.ACT_OUT_FRAG16
 
     def to_frag(t):  # [M, C] -> fragment-major [Mr * C]
         pad = torch.zeros(Mr, t.shape[1], dtype=t.dtype, device=dev)
@@ -588,47 +590,17 @@ def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
     def from_frag(f, C):  # inverse, first M rows
         return f.view(Mr // 16, C // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(Mr, C)[:M]
 
-    xf = to_frag(x)
-    x_keep = x
-    N = 512
-    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
-    wp = ops.pack_weight16(w)
-    a_ = run(w, 0, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2, **rs)
-    x = xf  # (run() takes A from the enclosing scope)
-    try:
-        of = torch.zeros(Mr * (N // 2), dtype=dt, device=dev)
-        run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, of, ldc=N // 2,
-            act_layout=capi.ACT_A_FRAG16 | capi.ACT_OUT_FRAG16, **rs)
-        assert torch.equal(from_frag(of, N // 2), a_)
-        b_ = run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2,
-                 act_layout=capi.ACT_A_FRAG16, **rs)
-        assert torch.equal(b_, a_)
-        # q|k|v (row-major output) and lm_head from fragment-major A
-        Nq_ = 384
-        wq = (torch.randn(Nq_, K, generator=g) * 0.05).to(dt).to(dev)
-        x = x_keep
-        qa = run(wq, 0, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev), **kw)
-        la = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev))
-        x = xf
-        qb = run(ops.pack_weight16(wq), capi.W_FRAG16, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev),
-                 act_layout=capi.ACT_A_FRAG16, **kw)
-        lb = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev), act_layout=capi.ACT_A_FRAG16)
-        assert torch.equal(qa, qb) and torch.equal(la, lb)
-        # o / down: the in-place 16-bit stream in fragment-major order
-        N = H
-        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
-        res16 = torch.randn(M, N, generator=g).to(dev).to(dt)
-        npart = ops.norm_npart(M, N, K)
-        x = x_keep
-        h_a, p_a = res16.clone(), torch.zeros(M, npart, device=dev)
-        run(w, 0, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h_a, norm_part=p_a)
-        x = xf
-        h_b, p_b = to_frag(res16), torch.zeros(M, npart, device=dev)
-        run(ops.pack_weight16(w), capi.W_FRAG16, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h_b, norm_part=p_b,
-            act_layout=capi.ACT_A_FRAG16 | capi.ACT_OUT_FRAG16)
-        assert torch.equal(from_frag(h_b, N), h_a) and torch.equal(p_a, p_b) and not torch.equal(h_a, res16)
-    finally:
-        x = x_keep
+    _frag_activation_forms(M, dt, dev, g, run, x, rs, kw, K, H, to_frag, from_frag, AF, AO, Mr)
+    if M <= 8:  # ONE block of 8 tokens (TCAVT_ACT_BLOCK8): element (m, f) at (f >> 5) * 256 + ((f >> 3) & 3) * 64 + m * 8 + (f & 7)
+        def to_frag8(t):
+            pad = torch.zeros(8, t.shape[1], dtype=t.dtype, device=dev)
+            pad[:M] = t
+            return pad.view(8, t.shape[1] // 32, 4, 8).permute(1, 2, 0, 3).contiguous().view(-1)
+
+        def from_frag8(f, C):
+            return f.view(C // 32, 4, 8, 8).permute(2, 0, 1, 3).reshape(8, C)[:M]
+
+        _frag_activation_forms(M, dt, dev, g, run, x, rs, kw, K, H, to_frag8, from_frag8, AF | capi.ACT_BLOCK8, AO | capi.ACT_BLOCK8, 8)
     # refused where no skinny form runs (M > 32)
     xl = torch.zeros(64, K, dtype=dt, device=dev)
     a = capi.GemmArgs()
@@ -636,6 +608,45 @@ def test_skinny_gemm_fragment_major_weights_bit_equal(gpu, M, dt):
     a.A, a.lda, a.W, a.ldw, a.C, a.ldc, a.M, a.N, a.K = xl.data_ptr(), K, wp.data_ptr(), K, o.data_ptr(), N, 64, N, K
     a.in_dtype, a.out_dtype, a.w_layout = ops._DT[dt], capi.F32, capi.W_FRAG16
     assert capi.lib().tcavt_gemm_bf16(ctypes.byref(a), capi.stream_ptr()) != 0
+
+
+def _frag_activation_forms(M, dt, dev, g, run, x, rs, kw, K, H, to_frag, from_frag, AF, AO, Mr):
+    """Every epilogue form of the decode step with fragment-major activations (A read / 16-bit result written in the next skinny
+    GEMM's operand order; AF / AO = the act_layout flags of an A-only / A-and-output call) against the row-major call:
+    bit-identical."""
+    from tcavt_amd import capi, ops
+
+    xf = to_frag(x)
+    N = 512
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    wp = ops.pack_weight16(w)
+    a_ = run(w, 0, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), ldc=N // 2, **rs)
+    of = torch.zeros(Mr * (N // 2), dtype=dt, device=dev)
+    run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, of, xin=xf, ldc=N // 2, act_layout=AO, **rs)
+    assert torch.equal(from_frag(of, N // 2), a_)
+    b_ = run(wp, capi.W_FRAG16, N, capi.EPI_SILU_MUL | capi.EPI_ROWSCALE, torch.empty(M, N // 2, dtype=dt, device=dev), xin=xf,
+             ldc=N // 2, act_layout=AF, **rs)
+    assert torch.equal(b_, a_)
+    # q|k|v (row-major output) and lm_head from fragment-major A
+    Nq_ = 384
+    wq = (torch.randn(Nq_, K, generator=g) * 0.05).to(dt).to(dev)
+    qa = run(wq, 0, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev), **kw)
+    la = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev))
+    qb = run(ops.pack_weight16(wq), capi.W_FRAG16, Nq_, capi.EPI_ROPE | capi.EPI_ROWSCALE, torch.empty(M, Nq_, dtype=dt, device=dev),
+             xin=xf, act_layout=AF, **kw)
+    lb = run(wq, 0, Nq_, 0, torch.empty(M, Nq_, device=dev), xin=xf, act_layout=AF)
+    assert torch.equal(qa, qb) and torch.equal(la, lb)
+    # o / down: the in-place 16-bit stream in fragment-major order
+    N = H
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(dev)
+    res16 = torch.randn(M, N, generator=g).to(dev).to(dt)
+    npart = ops.norm_npart(M, N, K)
+    h_a, p_a = res16.clone(), torch.zeros(M, npart, device=dev)
+    run(w, 0, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, norm_h16=h_a, norm_part=p_a)
+    h_b, p_b = to_frag(res16), torch.zeros(M, npart, device=dev)
+    run(ops.pack_weight16(w), capi.W_FRAG16, N, capi.EPI_RESIDUAL | capi.EPI_NORM_OUT, None, xin=xf, norm_h16=h_b, norm_part=p_b,
+        act_layout=AO)
+    assert torch.equal(from_frag(h_b, N), h_a) and torch.equal(p_a, p_b) and not torch.equal(h_a, res16)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

@@ -22,7 +22,7 @@ ABI_VERSION = 4  # TCAVT_ABI_VERSION of include/tcavt.h
 F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SILU_MUL, EPI_ROPE, EPI_BIAS_ROW, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_NORM_OUT, EPI_ROWSCALE, EPI_SILU_BWD = 128, 256, 512
-ACT_A_FRAG16, ACT_OUT_FRAG16 = 1, 2  # tcavt_gemm_args.act_layout
+ACT_A_FRAG16, ACT_OUT_FRAG16, ACT_BLOCK8 = 1, 2, 4  # tcavt_gemm_args.act_layout
 W_FRAG16 = 1  # tcavt_gemm_args.w_layout / tcavt_decode_args.w_layout: tcavt_pack_weight16 copy
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float

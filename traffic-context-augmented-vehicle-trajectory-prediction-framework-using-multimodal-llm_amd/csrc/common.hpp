@@ -115,6 +115,12 @@ static inline int norm_out_npart(int M, int N, int K) { return skinny_shape(M, K
 __host__ __device__ __forceinline__ long frag16_off(int m, int f, int K) {
   return (long)(m >> 4) * 16 * K + (long)(f >> 5) * 512 + ((f >> 3) & 3) * 128 + (m & 15) * 8 + (f & 7);
 }
+// ... and for at most 8 tokens (TCAVT_ACT_BLOCK8): one block of 8, a k-step is 512 bytes -- lanes r and r + 8 of the consuming wave
+// read the same 16 bytes (the empty token slots repeat the real ones), so an instruction touches 512 consecutive bytes.
+// mode: 1 = blocks of 16 tokens, 2 = one block of 8.
+__host__ __device__ __forceinline__ long frag_off(int m, int f, int K, int mode) {
+  return mode == 2 ? (long)(f >> 5) * 256 + ((f >> 3) & 3) * 64 + (m & 7) * 8 + (f & 7) : frag16_off(m, f, K);
+}
 
 // ---- wave / block reductions (wave = 64 lanes) ----------------------------
 __device__ __forceinline__ float wave_sum(float v) {

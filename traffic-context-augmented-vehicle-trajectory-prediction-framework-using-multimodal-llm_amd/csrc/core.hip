@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void embed_fuse_kernel(const bf16_t* __restric
     o *= sscale;  // (scaled 16-bit image of the stream: tcavt_llama_stack_args.stream_scale; 1 by default, exact for powers of two)
     if (out16) {
       const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
-      *reinterpret_cast<u32x2*>(frag ? h16 + frag16_off((int)row, c, H) : out16 + c) = w;
+      *reinterpret_cast<u32x2*>(frag ? h16 + frag_off((int)row, c, H, frag16) : out16 + c) = w;
       if (!out) o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};  // sums of what is stored
     }
     ss += o[0] * o[0];
@@ -569,7 +569,8 @@ extern "C" int tcavt_embed_fuse(const void* table_bf16, const int64_t* ids, cons
 int tcavt::embed_fuse_impl(const void* table_bf16, const int64_t* ids, const float* img, const float* vis_mod, const float* txt_mod,
                            float* h, int B, int Nq, int Lt, int H, int V, int32_t* bad_id_flag, int table_dtype, void* h16, float* part,
                            int npart, float stream_scale, int frag16, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(!frag16 || ((long)B * (Nq + Lt) <= 32 && H % 32 == 0), "embed_fuse: fragment-major rows: at most 32, H %% 32 == 0");
+  TCAVT_CHECK_ARG(!frag16 || ((frag16 == 1 || frag16 == 2) && (long)B * (Nq + Lt) <= (frag16 == 2 ? 8 : 32) && H % 32 == 0),
+                  "embed_fuse: fragment-major rows: mode 1 (at most 32 rows) or 2 (at most 8), H %% 32 == 0");
   TCAVT_CHECK_ARG(table_bf16 && ids && img && vis_mod && txt_mod && (h || h16) && bad_id_flag, "embed_fuse: null pointer");
   TCAVT_CHECK_ARG(stream_scale >= 0.f && stream_scale <= 1.f, "embed_fuse: stream_scale must be in (0, 1] (0 means 1)");
   const float sscale = stream_scale == 0.f ? 1.f : stream_scale;

@@ -73,7 +73,8 @@ struct GemmP {
   // skinny form, M > 16: the two 16-token blocks of a column block go to TWO workgroups (sk_msplit = 2) instead of one that
   // loads both blocks' activation rows for every weight fragment (twice the weight bytes through the CU's load path)
   int sk_msplit;
-  int a_frag, o_frag;  // skinny form: A / the 16-bit result in fragment-major order (tcavt_gemm_args.act_layout, common.hpp frag16_off)
+  int a_frag, o_frag;  // skinny form: A / the 16-bit result in fragment-major order (tcavt_gemm_args.act_layout): 0, 1 = blocks of 16
+                       // tokens, 2 = one block of 8 (common.hpp frag_off)
   int w_frag;  // skinny form: W is the fragment-major copy of tcavt_pack_weight16 (tcavt_gemm_args.w_layout)
   int sk_split;
   float* sk_slab;
@@ -2126,8 +2127,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
   const bf16_t* xp1 = p.A + (long)min(16 + r16, p.M - 1) * p.lda + kbeg + kq * 8;
   // fragment-major activations: the 16 tokens' fragments of a k-step are one 1 KiB run as well (rows >= M of a block hold
   // whatever the producer left: they only reach output columns >= M, which nobody stores)
-  const int xstep = p.a_frag ? 16 : 1;
-  if (p.a_frag) {
+  // (one block of 8 tokens, M <= 8: a k-step is 512 bytes, lanes r and r + 8 read the same 16)
+  const int xstep = p.a_frag == 2 ? 8 : p.a_frag ? 16 : 1;
+  if (p.a_frag == 2) {
+    xp0 = p.A + (long)kbeg * 8 + kq * 64 + (r16 & 7) * 8;
+  } else if (p.a_frag) {
     xp0 = p.A + (long)mrow0 * p.K + (long)kbeg * 16 + lane * 8;
     xp1 = p.A + (long)16 * p.K + (long)kbeg * 16 + lane * 8;
   }
@@ -2281,7 +2285,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         if (p.flags & TCAVT_EPI_RESIDUAL) {
 #pragma unroll
           for (int c = 0; c < NCB; ++c)
-            old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + (p.o_frag ? frag16_off((int)pmm, n0 + c * 16 + 4 * kq, p.N)
+            old16[c] = *reinterpret_cast<const u32x2*>(p.res16 + (p.o_frag ? frag_off((int)pmm, n0 + c * 16 + 4 * kq, p.N, p.o_frag)
                                                                             : pmm * p.ldc + n0 + c * 16 + 4 * kq));
         }
       }
@@ -2435,7 +2439,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
         }
         o = fma4(o, p.norm_scale, oldv);
         const u32x2 w = u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
-        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + (p.o_frag ? frag16_off(m, n0 + c * 16 + nq, p.N) : off)) = w;
+        if (rowok) *reinterpret_cast<u32x2*>(p.norm_h16 + (p.o_frag ? frag_off(m, n0 + c * 16 + nq, p.N, p.o_frag) : off)) = w;
         o = f32x4{from16_lo<F16>(w[0]), from16_hi<F16>(w[0]), from16_lo<F16>(w[1]), from16_hi<F16>(w[1])};
         hq[c] = o;
       } else {
@@ -2489,7 +2493,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(GemmP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = silu_mul(g[e], u[e]);
     if (p.o_frag)  // (16-bit output of the operand type: checked by the host)
-      *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(p.C) + frag16_off(m, (n0 >> 1) + nq, p.N >> 1)) =
+      *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(p.C) + frag_off(m, (n0 >> 1) + nq, p.N >> 1, p.o_frag)) =
           u32x2{pack16x2<F16>(o[0], o[1]), pack16x2<F16>(o[2], o[3])};
     else store_quad(p, m, (n0 >> 1) + nq, o);
   } else {  // EPI_ROPE: dimensions d = 16 half + nq .. + 3 and d + 32 of one head
@@ -2727,17 +2731,19 @@ extern "C" int tcavt_gemm_bf16(const tcavt_gemm_args* a, tcavt_stream_t stream) 
   p.lp_scale = 1.f;
   p.w_frag = p.a_frag = p.o_frag = 0;
   if (a->act_layout != 0) {
-    TCAVT_CHECK_ARG((a->act_layout & ~(TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16)) == 0 && a->tile == 0 && skinny_shape(a->M, a->K) &&
-                        batch == 1 && a->dropout_p == 0.f,
+    TCAVT_CHECK_ARG((a->act_layout & ~(TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16 | TCAVT_ACT_BLOCK8)) == 0 && a->tile == 0 &&
+                        skinny_shape(a->M, a->K) && batch == 1 && a->dropout_p == 0.f,
                     "gemm_bf16: act_layout (fragment-major activations) goes with the skinny form only (M <= 32, K %% 256 == 0, tile 0)");
-    p.a_frag = (a->act_layout & TCAVT_ACT_A_FRAG16) ? 1 : 0;
+    const int fmode = (a->act_layout & TCAVT_ACT_BLOCK8) ? 2 : 1;
+    TCAVT_CHECK_ARG(fmode == 1 || a->M <= 8, "gemm_bf16: TCAVT_ACT_BLOCK8 holds at most 8 rows");
+    p.a_frag = (a->act_layout & TCAVT_ACT_A_FRAG16) ? fmode : 0;
     if (a->act_layout & TCAVT_ACT_OUT_FRAG16) {
       const bool silu = (a->epilogue & ~TCAVT_EPI_ROWSCALE) == TCAVT_EPI_SILU_MUL && a->out_dtype == (f16 ? TCAVT_F16 : TCAVT_BF16) &&
                         a->N % 64 == 0;
       const bool stream = (a->epilogue & TCAVT_EPI_NORM_OUT) && stream16 && a->N % 32 == 0;
       TCAVT_CHECK_ARG(silu || stream, "gemm_bf16: TCAVT_ACT_OUT_FRAG16 needs SILU_MUL with a 16-bit output of the operand type, or "
                                       "NORM_OUT with C == NULL (the in-place 16-bit stream)");
-      p.o_frag = 1;
+      p.o_frag = fmode;
     }
   }
   if (a->w_layout != 0) {

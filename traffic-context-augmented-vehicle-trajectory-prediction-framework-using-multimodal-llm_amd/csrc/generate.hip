@@ -154,7 +154,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(const bf16_t* __restr
     float o = po[lane];
     for (int k = 1; k < KS; ++k) o += po[k * 64 + lane];
     // (out_frag: the o projection's operand order, common.hpp frag16_off)
-    out[out_frag ? frag16_off(b, head * 64 + lane, nq * 64) : (long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
+    out[out_frag ? frag_off(b, head * 64 + lane, nq * 64, out_frag) : (long)b * nq * 64 + head * 64 + lane] = to16<F16>(o);
   }
 }
 
@@ -838,9 +838,11 @@ extern "C" int tcavt_llama_decode_step(const tcavt_decode_args* a, tcavt_stream_
                   "llama_decode_step: w_layout must be 0 or TCAVT_W_FRAG16 (B <= 32, I %% 256 == 0, nq * 64 %% 256 == 0)");
   // fragment-major activations: h16, att, act, x16 in the skinny GEMMs' operand order (16 or 32 whole rows each)
   const int al = a->act_layout;
-  TCAVT_CHECK_ARG(al == 0 || (al == 1 && a->h == nullptr && B <= 32 && I % 256 == 0 && (nq * 64) % 256 == 0),
-                  "llama_decode_step: act_layout must be 0 or 1 (16-bit residual stream: h == NULL; B <= 32, I %% 256 == 0, nq * 64 %% 256 == 0)");
-  const int gA = al ? TCAVT_ACT_A_FRAG16 : 0, gAO = al ? (TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16) : 0;
+  TCAVT_CHECK_ARG(al == 0 || ((al == 1 || al == 2) && a->h == nullptr && B <= (al == 2 ? 8 : 32) && I % 256 == 0 && (nq * 64) % 256 == 0),
+                  "llama_decode_step: act_layout must be 0, 1 (B <= 32) or 2 (B <= 8) (16-bit residual stream: h == NULL; I %% 256 == 0, "
+                  "nq * 64 %% 256 == 0)");
+  const int blk8 = al == 2 ? TCAVT_ACT_BLOCK8 : 0;
+  const int gA = al ? (TCAVT_ACT_A_FRAG16 | blk8) : 0, gAO = al ? (TCAVT_ACT_A_FRAG16 | TCAVT_ACT_OUT_FRAG16 | blk8) : 0;
   // h = table[cur_tok] + text modality embedding (generated tokens are text tokens: scripts/train.py:526-527); + the fused
   // norm's inputs
   // (a->h == NULL: the residual stream is the 16-bit h16 itself, as in tcavt_llama_stack_forward)

@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256) void rmsnorm16_kernel(const bf16_t* __restrict
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   // (frag16: the <= 32 rows of a decode step in the skinny GEMM's operand order, in and out: same lanes, same columns, same sums)
-  auto xat = [&](int c) { return frag16 ? x + frag16_off((int)row, c, H) : x + row * H + c; };
-  auto oat = [&](int c) { return frag16 ? out16 + frag16_off((int)row, c, H) : out16 + row * H + c; };
+  auto xat = [&](int c) { return frag16 ? x + frag_off((int)row, c, H, frag16) : x + row * H + c; };
+  auto oat = [&](int c) { return frag16 ? out16 + frag_off((int)row, c, H, frag16) : out16 + row * H + c; };
   constexpr int NV = 8;  // 8 x 512 = 4096 columns in registers
   u32x4 w[NV];
   float ss = 0.f;
@@ -406,7 +406,8 @@ extern "C" int tcavt_rmsnorm16(const void* x16, const float* gamma, float eps, v
 
 int tcavt::rmsnorm16_impl(const void* x16, const float* gamma, float eps, void* out16, float* out_f32, int M, int H, int dtype16,
                           int frag16, tcavt_stream_t stream) {
-  TCAVT_CHECK_ARG(!frag16 || (M <= 32 && !out_f32), "rmsnorm16: fragment-major rows: at most 32, 16-bit output only");
+  TCAVT_CHECK_ARG(!frag16 || ((frag16 == 1 || frag16 == 2) && M <= (frag16 == 2 ? 8 : 32) && !out_f32),
+                  "rmsnorm16: fragment-major rows: mode 1 (at most 32 rows) or 2 (at most 8), 16-bit output only");
   TCAVT_CHECK_ARG(x16 && gamma && (out16 || out_f32) && M > 0 && H > 0 && H % 256 == 0 && is16(dtype16),
                   "rmsnorm16: bad args (H %% 256 == 0)");
   TCAVT_CHECK_ARG(aligned16(x16) && aligned16(gamma), "rmsnorm16: unaligned input");

@@ -1157,9 +1157,11 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     DW = LW.decode_weights() if (B <= 32 and os.environ.get("TCAVT_DECODE_ROWMAJOR", "0") != "1") else None
                     # (B <= 8: row-major activation rows are HALF the bytes of a 16-token fragment -- lanes of the empty token slots
                     #  repeat the last row -- and the step is 0.89 vs 0.91 ms; B = 16: 0.98 vs 1.05, B = 32: 1.09 vs 1.21 ms)
-                    frag_act = (DW is not None and LW.stream16 and os.environ.get("TCAVT_DECODE_ACT_ROWMAJOR", "0") != "1"
-                                and (B > 8 or os.environ.get("TCAVT_DECODE_ACT_FRAG", "0") == "1"))
-                    Br = (16 if B <= 16 else 32) if frag_act else B
+                    frag_act = DW is not None and LW.stream16 and os.environ.get("TCAVT_DECODE_ACT_ROWMAJOR", "0") != "1"
+                    # up to 8 samples: ONE block of 8 tokens (a k-step of activations = 512 consecutive bytes); blocks of 16 beyond
+                    # (TCAVT_DECODE_ACT_FRAG=16: blocks of 16 at any B, A/B)
+                    act_mode = 0 if not frag_act else (2 if B <= 8 and os.environ.get("TCAVT_DECODE_ACT_FRAG", "") != "16" else 1)
+                    Br = B if not frag_act else (8 if act_mode == 2 else 16 if B <= 16 else 32)
                     bufs = dict(h16=ws.get("gen.dh16", (Br, H), st, dev, zero=True),
                                 part=ws.get("gen.dpart", (B, H // 16), torch.float32, dev),
                                 qkv=ws.get("gen.dqkv", (B, nqkv), st, dev),
@@ -1172,8 +1174,7 @@ class LlamaMultiModal(nn.Module, _Prepared):
                     a.layers, a.gamma_final = PL.carr, PL.g_final.data_ptr()
                     if DW is not None:
                         a.layers, a.w_layout, a.table_packed = DW.carr, capi.W_FRAG16, DW.table.data_ptr()
-                    if frag_act:
-                        a.act_layout = 1
+                    a.act_layout = act_mode
                     a.rope_cos, a.rope_sin, a.rope_L = cos.data_ptr(), sin.data_ptr(), Lmax
                     a.table, a.txt_mod = PL.table.data_ptr(), P.txt.data_ptr()
                     a.cur_tok, a.pos = cur.data_ptr(), pos.data_ptr()
