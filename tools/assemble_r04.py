@@ -12,7 +12,7 @@ DST = os.path.join(ROOT, "profiles")
 def main():
     var = {}
     for name in ("bench_forward", "bench_nopipeline", "bench_bf16", "bench_feed_host", "bench_rccl1", "bench_lora", "bench_lora_full", "bench_lora_bf16",
-                 "bench_gloo2", "generate_b8", "generate_b16", "generate_b32", "generate_b8_greedy", "generate_b8_one_stage_sampler", "generate_b8_row_major_weights",
+                 "bench_gloo2", "generate_b4", "generate_b8", "generate_b16", "generate_b32", "generate_b8_row_major_activations", "generate_b8_greedy", "generate_b8_one_stage_sampler", "generate_b8_row_major_weights",
                  "generate_b32_row_major_weights", "generate_b32_row_major_activations"):
         p = os.path.join(SRC, name + ".json")
         if not os.path.exists(p):
