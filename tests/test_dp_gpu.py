@@ -167,6 +167,8 @@ def test_one_rank_rccl_group_takes_the_data_parallel_path(gpu, tmp_path):
     assert p.exitcode == 0, f"worker exit code {p.exitcode}"
     r = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
     # (equal up to the order of the backward's atomically accumulated column sums, which differs from run to run)
-    assert rel_err(r["g1"], r["g0"]) < 1e-5 and rel_err(r["p1"], r["p0"]) < 1e-6 and abs(r["l0"] - r["l1"]) <= 1e-6 * abs(r["l0"])
+    # (parameters: AdamW's first step is lr * g / |g| per element -- where a gradient is a rounding away from zero its sign, and so
+    #  2 lr of that parameter, follows the summation order)
+    assert rel_err(r["g1"], r["g0"]) < 1e-5 and rel_err(r["p1"], r["p0"]) < 1e-3 and abs(r["l0"] - r["l1"]) <= 1e-6 * abs(r["l0"])
     d = r["diag"]
     assert len(d["buckets"]) >= 1 and all(b["launches"] == 1 for b in d["buckets"]) and d["hip_streams_in_use"] <= 5, d
