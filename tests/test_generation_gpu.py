@@ -207,3 +207,37 @@ def test_decode_step_on_fragment_major_weights_is_bit_equal(gpu):
     for a_, b_, c_, d_ in zip(outs["frag"], outs["row"], outs["frag_w"], outs["frag16"]):
         assert torch.equal(a_, b_) and torch.equal(c_, b_) and torch.equal(d_, b_)
     assert torch.equal(outs["frag"][1], outs["frag"][2])
+
+
+@pytest.mark.parametrize("storage", ["bf16", "fp16_wide"])
+def test_decode_step_on_fragment_major_weights_other_stream_contracts(gpu, storage):
+    """The contracts whose residual stream is fp32 (bf16 storage; fp16 operands with wide_stream): the decode step still streams
+    fragment-major WEIGHTS (activations stay row-major: the fp32 stream's norm kernels are row-major) and samples the same tokens
+    as on row-major weights."""
+    import os
+
+    from tcavt_amd import model
+
+    fx, cfg, w, t = load_generation_case()
+    dev = gpu["device"]
+    m = model.MultiModalTrajectoryModel.from_config(cfg).load_weights(w, device=dev).eval()
+    if storage == "bf16":
+        m.set_storage(torch.bfloat16)
+    else:
+        m.set_storage(torch.float16, wide_stream=True)
+    kw = dict(max_new_tokens=10, input_ids=t["input_ids"].to(dev), attention_mask=t["attention_mask"].to(dev))
+    outs = {}
+    for mode in ("frag", "row"):
+        if mode == "row":
+            os.environ["TCAVT_DECODE_ROWMAJOR"] = "1"
+        try:
+            outs[mode] = [m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=False, repetition_penalty=1.0,
+                                                no_repeat_ngram_size=0, **kw).clone(),
+                          m.mllm.generate_batch(t["vision_emb"].to(dev), None, do_sample=True, seed=11, **kw).clone()]
+        finally:
+            os.environ.pop("TCAVT_DECODE_ROWMAJOR", None)
+    torch.cuda.synchronize()
+    m.mllm.check_flags()
+    assert m.mllm.llama_wrapper._prep_dec is not None and not m.mllm.llama_wrapper.stream16
+    for a_, b_ in zip(outs["frag"], outs["row"]):
+        assert torch.equal(a_, b_)
