@@ -23,3 +23,20 @@ for name, drop in (("eval", None), ("train p=0.1", (0.1, 1234, 7))):
     e1.record()
     torch.cuda.synchronize()
     print(f"lora_down {name}: {e0.elapsed_time(e1) / 48 * 1e3:.1f} us", flush=True)
+
+# ---- tcavt_lora_dgrad (the adapters' input gradients, LoRA-trainable backward): 33.5 MB written per call
+g_t = (torch.randn(M, 64, device=dev) * 0.1).half()
+aqT = (torch.randn(H, 64, device=dev) * 0.02).half()
+avT = (torch.randn(H, 64, device=dev) * 0.02).half()
+outs = [torch.empty(M, H, dtype=torch.float16, device=dev) for _ in range(12)]
+for name, drop in (("eval", None), ("train p=0.1", (0.1, 1234, 7))):
+    for i in range(4):
+        ops.lora_dgrad(g_t, aqT, avT, outs[i], dropout=drop)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(48):
+        ops.lora_dgrad(g_t, aqT, avT, outs[i % 12], dropout=drop)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"lora_dgrad {name}: {e0.elapsed_time(e1) / 48 * 1e3:.1f} us", flush=True)
